@@ -1,0 +1,719 @@
+"""CPU ORACLE for the FateZero DDIM-inversion -> attention-fusion denoise hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import this module; the product (`fatezero_amd/`) never does.
+
+What it is: a plain-PyTorch **fp32** functional restatement of the reference algorithm
+(ChenyangQiQi/FateZero @ /root/reference), each function citing the reference file:line it follows.
+Third-party arithmetic that is absent from /root/reference (diffusers==0.11.1, pinned by
+requirements.txt:4) is restated from its published algorithm.
+
+Pinning: `oracle/gen_golden.py` runs the *unmodified* reference (through `oracle/refshim`) in the
+authoring container and stores its outputs under `tests/golden/`; `tests/test_oracle_golden.py`
+checks this restatement against those vectors.  The reference itself ships no golden vectors for
+this path, so the third-party pieces (diffusers classes, DDIM scheduler) stay
+"parity unpinned" beyond the reference's own call sites.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# 0. host-side prompt algebra (exact / integer)  -- ptp_utils.py, seq_aligner.py
+# --------------------------------------------------------------------------------------------
+
+
+def get_word_inds(text: str, word_place, tokenizer) -> np.ndarray:
+    """ptp_utils.py:144-162 (identical copy at seq_aligner.py:132-149)."""
+    split_text = text.split(" ")
+    if isinstance(word_place, str):
+        word_place = [i for i, word in enumerate(split_text) if word_place == word]
+    elif isinstance(word_place, int):
+        word_place = [word_place]
+    out = []
+    if len(word_place) > 0:
+        words_encode = [tokenizer.decode([item]).strip("#") for item in tokenizer.encode(text)][1:-1]
+        cur_len, ptr = 0, 0
+        for i in range(len(words_encode)):
+            cur_len += len(words_encode[i])
+            if ptr in word_place:
+                out.append(i + 1)
+            if cur_len >= len(split_text[ptr]):
+                ptr += 1
+                cur_len = 0
+    return np.array(out)
+
+
+def get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer, max_num_words=77):
+    """ptp_utils.py:165-199 -> float tensor [num_steps+1, len(prompts)-1, 1, 1, 77] of 0/1."""
+    if not isinstance(cross_replace_steps, dict):
+        cross_replace_steps = {"default_": cross_replace_steps}
+    cross_replace_steps = dict(cross_replace_steps)
+    if "default_" not in cross_replace_steps:
+        cross_replace_steps["default_"] = (0.0, 1.0)
+    alpha = torch.zeros(num_steps + 1, len(prompts) - 1, max_num_words)
+
+    def update(alpha, bounds, prompt_ind, word_inds=None):
+        if isinstance(bounds, float):
+            bounds = 0, bounds
+        start, end = int(bounds[0] * alpha.shape[0]), int(bounds[1] * alpha.shape[0])
+        if word_inds is None:
+            word_inds = torch.arange(alpha.shape[2])
+        alpha[:start, prompt_ind, word_inds] = 0
+        alpha[start:end, prompt_ind, word_inds] = 1
+        alpha[end:, prompt_ind, word_inds] = 0
+        return alpha
+
+    for i in range(len(prompts) - 1):
+        alpha = update(alpha, cross_replace_steps["default_"], i)
+    for key, item in cross_replace_steps.items():
+        if key != "default_":
+            inds = [get_word_inds(prompts[i], key, tokenizer) for i in range(1, len(prompts))]
+            for i, ind in enumerate(inds):
+                if len(ind) > 0:
+                    alpha = update(alpha, item, i, ind)
+    return alpha.reshape(num_steps + 1, len(prompts) - 1, 1, 1, max_num_words)
+
+
+def _global_align(x, y, gap=0, match=1, mismatch=-1):
+    """seq_aligner.py:61-78 (Needleman-Wunsch with ScoreParams(0, 1, -1))."""
+    m = np.zeros((len(x) + 1, len(y) + 1), dtype=np.int32)
+    m[0, 1:] = (np.arange(len(y)) + 1) * gap
+    m[1:, 0] = (np.arange(len(x)) + 1) * gap
+    tb = np.zeros((len(x) + 1, len(y) + 1), dtype=np.int32)
+    tb[0, 1:] = 1
+    tb[1:, 0] = 2
+    tb[0, 0] = 4
+    for i in range(1, len(x) + 1):
+        for j in range(1, len(y) + 1):
+            left = m[i, j - 1] + gap
+            up = m[i - 1, j] + gap
+            diag = m[i - 1, j - 1] + (match if x[i - 1] == y[j - 1] else mismatch)
+            m[i, j] = max(left, up, diag)
+            if m[i, j] == left:
+                tb[i, j] = 1
+            elif m[i, j] == up:
+                tb[i, j] = 2
+            else:
+                tb[i, j] = 3
+    return m, tb
+
+
+def _aligned_mapper(x, y, tb):
+    """seq_aligner.py:81-105: mapper_y_to_x rows (j, i) / (j, -1)."""
+    i, j = len(x), len(y)
+    out = []
+    while i > 0 or j > 0:
+        if tb[i, j] == 3:
+            i, j = i - 1, j - 1
+            out.append((j, i))
+        elif tb[i, j] == 1:
+            j -= 1
+            out.append((j, -1))
+        elif tb[i, j] == 2:
+            i -= 1
+        elif tb[i, j] == 4:
+            break
+    out.reverse()
+    return torch.tensor(out, dtype=torch.int64)
+
+
+def get_refinement_mapper(prompts, tokenizer, max_len=77):
+    """seq_aligner.py:108-129 -> (mapper int64 [P-1,77], alphas float [P-1,77])."""
+    mappers, alphas = [], []
+    for i in range(1, len(prompts)):
+        x_seq, y_seq = tokenizer.encode(prompts[0]), tokenizer.encode(prompts[i])
+        _, tb = _global_align(x_seq, y_seq)
+        base = _aligned_mapper(x_seq, y_seq, tb)
+        a = torch.ones(max_len)
+        a[: base.shape[0]] = base[:, 1].ne(-1).float()
+        mp = torch.zeros(max_len, dtype=torch.int64)
+        mp[: base.shape[0]] = base[:, 1]
+        mp[base.shape[0]:] = len(y_seq) + torch.arange(max_len - len(y_seq))
+        mappers.append(mp)
+        alphas.append(a)
+    return torch.stack(mappers), torch.stack(alphas)
+
+
+def get_replacement_mapper(prompts, tokenizer, max_len=77):
+    """seq_aligner.py:152-196 -> float [P-1,77,77]."""
+    mappers = []
+    for p in range(1, len(prompts)):
+        x, y = prompts[0], prompts[p]
+        words_x, words_y = x.split(" "), y.split(" ")
+        if len(words_x) != len(words_y):
+            raise ValueError(
+                f"attention replacement edit can only be applied on prompts with the same length"
+                f" but prompt A has {len(words_x)} words and prompt B has {len(words_y)} words.")
+        inds_replace = [i for i in range(len(words_y)) if words_y[i] != words_x[i]]
+        inds_source = [get_word_inds(x, i, tokenizer) for i in inds_replace]
+        inds_target = [get_word_inds(y, i, tokenizer) for i in inds_replace]
+        mapper = np.zeros((max_len, max_len))
+        i = j = 0
+        cur = 0
+        while i < max_len and j < max_len:
+            if cur < len(inds_source) and inds_source[cur][0] == i:
+                s_, t_ = inds_source[cur], inds_target[cur]
+                if len(s_) == len(t_):
+                    mapper[s_, t_] = 1
+                else:
+                    ratio = 1 / len(t_)
+                    for i_t in t_:
+                        mapper[s_, i_t] = ratio
+                cur += 1
+                i += len(s_)
+                j += len(t_)
+            elif cur < len(inds_source):
+                mapper[i, j] = 1
+                i += 1
+                j += 1
+            else:
+                mapper[j, j] = 1
+                i += 1
+                j += 1
+        mappers.append(torch.from_numpy(mapper).float())
+    return torch.stack(mappers)
+
+
+def get_equalizer(text, word_select, values, tokenizer):
+    """attention_util.py:307-316 -> float [1,77]."""
+    if isinstance(word_select, (int, str)):
+        word_select = (word_select,)
+    eq = torch.ones(1, 77)
+    for word, val in zip(word_select, values):
+        inds = get_word_inds(text, word, tokenizer)
+        eq[:, inds] = val
+    return eq
+
+
+def blend_alpha_layers(prompts, words, tokenizer):
+    """spatial_blend.py:145-153 -> float [P,1,1,1,1,77]."""
+    al = torch.zeros(len(prompts), 1, 1, 1, 1, 77)
+    for i, (prompt, words_) in enumerate(zip(prompts, words)):
+        if isinstance(words_, str):
+            words_ = [words_]
+        for word in words_:
+            ind = get_word_inds(prompt, word, tokenizer)
+            al[i, :, :, :, :, ind] = 1
+    return al
+
+
+# --------------------------------------------------------------------------------------------
+# 1. DDIM schedule and the two latent updates -- diffusers 0.11.1 DDIMScheduler [3P] + p2p_ddim:150-161
+# --------------------------------------------------------------------------------------------
+
+
+class DDIMSchedule:
+    """SD-1.x DDIM constants: scaled_linear betas [0.00085, 0.012], 1000 train steps, steps_offset 1,
+    set_alpha_to_one False (stable_diffusion.py:56-81 forces offset 1 / no clipping)."""
+
+    def __init__(self, num_inference_steps: int, num_train_timesteps: int = 1000,
+                 beta_start: float = 0.00085, beta_end: float = 0.012, steps_offset: int = 1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.num_train_timesteps = num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ratio = num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts) + steps_offset  # e.g. T=50: 981, 961, ..., 1
+
+    def step(self, eps, t: int, x):
+        """DDIMScheduler.step(eta=0) [3P]."""
+        t = int(t)
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+
+    def inverse_step(self, eps, t: int, x):
+        """p2p_ddim_spatial_temporal.py:150-161 (next_clean2noise_step, eta=0)."""
+        t = int(t)
+        cur, nxt = min(t - self.num_train_timesteps // self.num_inference_steps, 999), t
+        a_t = self.alphas_cumprod[cur] if cur >= 0 else self.final_alpha_cumprod
+        a_next = self.alphas_cumprod[nxt]
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        return a_next ** 0.5 * x0 + (1 - a_next) ** 0.5 * eps
+
+
+# --------------------------------------------------------------------------------------------
+# 2. the pseudo-3D UNet, functional over a reference-named state_dict -- video_diffusion/models/*
+# --------------------------------------------------------------------------------------------
+
+
+class UNetConfig:
+    """Architecture knobs of UNetPseudo3DConditionModel (unet_3d_condition.py:39-80) for SD-1.x-shaped nets."""
+
+    def __init__(self, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, attention_head_dim=8,
+                 cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5, in_channels=4, out_channels=4,
+                 model_config: Optional[dict] = None):
+        self.block_out_channels = tuple(block_out_channels)
+        self.layers_per_block = layers_per_block
+        self.heads = attention_head_dim  # used as the head COUNT (unet_3d_blocks.py:269-272)
+        self.cross_attention_dim = cross_attention_dim
+        self.groups = norm_num_groups
+        self.eps = norm_eps
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.model_config = dict(model_config or {})
+
+    def sc_index(self, dim: int):
+        """attention.py:169-173 + default argument of SparseCausalAttention.forward (attention.py:347)."""
+        mc = self.model_config
+        if "least_sc_channel" in mc and dim < mc["least_sc_channel"]:
+            return []
+        return list(mc.get("SparseCausalAttention_index", [-1, "first"]))
+
+
+def sparse_causal_frame_indices(index_list, clip_length: int) -> List[List[int]]:
+    """attention_register.py:162-183: per K/V slot, the source frame of every frame."""
+    out = []
+    for index in index_list:
+        if isinstance(index, str):
+            if index == "first":
+                fi = [0] * clip_length
+            elif index == "last":
+                fi = [clip_length - 1] * clip_length
+            elif index in ("mid", "middle"):
+                fi = [int((clip_length - 1) // 2)] * clip_length
+            else:
+                raise ValueError(index)
+        else:
+            assert isinstance(index, int), "relative index must be int"
+            fi = [min(max(f + index, 0), clip_length - 1) for f in range(clip_length)]
+        out.append(fi)
+    return out
+
+
+def _heads_to_batch(t, h):
+    b, s, dim = t.shape
+    return t.reshape(b, s, h, dim // h).permute(0, 2, 1, 3).reshape(b * h, s, dim // h)
+
+
+def _batch_to_heads(t, h):
+    bh, s, d = t.shape
+    return t.reshape(bh // h, h, s, d).permute(0, 2, 1, 3).reshape(bh // h, s, d * h)
+
+
+def controlled_attention(q, k, v, heads, scale, controller, is_cross, place):
+    """attention_register.py:23-59: S=scale*QK^T, softmax, P<-controller(P[BF,h,Lq,Lk]), O=PV."""
+    q, k, v = _heads_to_batch(q, heads), _heads_to_batch(k, heads), _heads_to_batch(v, heads)
+    probs = (scale * torch.bmm(q, k.transpose(-1, -2))).softmax(dim=-1)
+    if controller is not None:
+        p4 = probs.reshape(-1, heads, probs.shape[1], probs.shape[2])
+        p4 = controller(p4, is_cross, place)
+        probs = p4.reshape(-1, probs.shape[1], probs.shape[2])
+    return _batch_to_heads(torch.bmm(probs, v), heads)
+
+
+class OracleUNet:
+    """Functional forward of UNetPseudo3DConditionModel.forward (unet_3d_condition.py:307-446)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: UNetConfig):
+        self.sd = {k: v.float() for k, v in state_dict.items()}
+        self.cfg = cfg
+
+    # -- primitives ---------------------------------------------------------------------------
+    def _lin(self, x, name, bias=True):
+        return F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias") if bias else None)
+
+    def _pseudo_conv3d(self, x, name, stride=1, padding=1):
+        """resnet.py:57-80 (PseudoConv3d.forward) + lora.py:46-54 (LoRALinearLayer.forward)."""
+        b, c, f, h, w = x.shape
+        x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+        x = F.conv2d(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"), stride=stride, padding=padding)
+        _, c2, h2, w2 = x.shape
+        x = x.reshape(b, f, c2, h2, w2).permute(0, 2, 1, 3, 4)
+        if name + ".conv_temporal.down.weight" in self.sd:  # model_config['lora'] path
+            t = x.permute(0, 3, 4, 1, 2).reshape(b * h2 * w2, c2, f)
+            d = F.conv1d(t, self.sd[name + ".conv_temporal.down.weight"], None, padding=1)
+            u = F.conv1d(d, self.sd[name + ".conv_temporal.up.weight"], None, padding=1)
+            t = u + t
+            x = t.reshape(b, h2, w2, c2, f).permute(0, 3, 4, 1, 2)
+        elif name + ".conv_temporal.weight" in self.sd:  # no 'lora' key: plain Conv1d (resnet.py:42-55)
+            wt = self.sd[name + ".conv_temporal.weight"]
+            t = x.permute(0, 3, 4, 1, 2).reshape(b * h2 * w2, c2, f)
+            t = F.conv1d(t, wt, self.sd[name + ".conv_temporal.bias"], padding=wt.shape[-1] // 2)
+            x = t.reshape(b, h2, w2, c2, f).permute(0, 3, 4, 1, 2)
+        return x
+
+    def _resnet(self, x, temb, name):
+        """resnet.py:335-394 (ResnetBlockPseudo3D.forward, time_embedding_norm='default')."""
+        cfg = self.cfg
+        h = F.group_norm(x, cfg.groups, self.sd[name + ".norm1.weight"], self.sd[name + ".norm1.bias"], cfg.eps)
+        h = F.silu(h)
+        h = self._pseudo_conv3d(h, name + ".conv1")
+        t = self._lin(F.silu(temb), name + ".time_emb_proj")  # [B, C]
+        h = h + t[:, :, None, None, None]
+        h = F.group_norm(h, cfg.groups, self.sd[name + ".norm2.weight"], self.sd[name + ".norm2.bias"], cfg.eps)
+        h = F.silu(h)
+        h = self._pseudo_conv3d(h, name + ".conv2")
+        if name + ".conv_shortcut.weight" in self.sd:
+            x = self._pseudo_conv3d(x, name + ".conv_shortcut", padding=0)
+        return x + h  # output_scale_factor == 1 for every block of this UNet
+
+    def _transformer(self, x, ctx, name, place, controller):
+        """attention.py:95-144 (SpatioTemporalTransformerModel) + :271-337 (block) with the patched
+        attention of attention_register.py:71-218."""
+        cfg = self.cfg
+        b, c, f, hh, ww = x.shape
+        heads = cfg.heads
+        scale = (c // heads) ** -0.5
+        xs = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, hh, ww)
+        ctx_r = ctx.repeat_interleave(f, 0)
+        residual = xs
+        hs = F.group_norm(xs, cfg.groups, self.sd[name + ".norm.weight"], self.sd[name + ".norm.bias"], 1e-6)
+        hs = F.conv2d(hs, self.sd[name + ".proj_in.weight"], self.sd[name + ".proj_in.bias"])
+        hs = hs.permute(0, 2, 3, 1).reshape(b * f, hh * ww, c)
+        tb = name + ".transformer_blocks.0"
+        ln = lambda t, n: F.layer_norm(t, (c,), self.sd[f"{tb}.{n}.weight"], self.sd[f"{tb}.{n}.bias"])
+        # 1. sparse-causal self attention (attention_register.py:131-218)
+        n1 = ln(hs, "norm1")
+        q = self._lin(n1, tb + ".attn1.to_q", bias=False)
+        k = self._lin(n1, tb + ".attn1.to_k", bias=False)
+        v = self._lin(n1, tb + ".attn1.to_v", bias=False)
+        idx = sparse_causal_frame_indices(cfg.sc_index(c), f)
+        if len(idx) > 0:
+            k5, v5 = k.reshape(b, f, -1, c), v.reshape(b, f, -1, c)
+            k = torch.cat([k5[:, fi] for fi in idx], dim=2).reshape(b * f, -1, c)
+            v = torch.cat([v5[:, fi] for fi in idx], dim=2).reshape(b * f, -1, c)
+        a = controlled_attention(q, k, v, heads, scale, controller, False, place)
+        hs = hs + self._lin(a, tb + ".attn1.to_out.0")
+        # 2. cross attention (attention_register.py:71-128)
+        n2 = ln(hs, "norm2")
+        q = self._lin(n2, tb + ".attn2.to_q", bias=False)
+        k = self._lin(ctx_r, tb + ".attn2.to_k", bias=False)
+        v = self._lin(ctx_r, tb + ".attn2.to_v", bias=False)
+        a = controlled_attention(q, k, v, heads, scale, controller, True, place)
+        hs = hs + self._lin(a, tb + ".attn2.to_out.0")
+        # 3. GEGLU feed-forward (diffusers FeedForward [3P])
+        n3 = ln(hs, "norm3")
+        g = self._lin(n3, tb + ".ff.net.0.proj")
+        hp, gate = g.chunk(2, dim=-1)
+        hs = hs + self._lin(hp * F.gelu(gate), tb + ".ff.net.2")
+        # 4. temporal attention over frames, NOT controlled (attention.py:327-337; register skips attn_temporal)
+        d = hs.shape[1]
+        ht = hs.reshape(b, f, d, c).permute(0, 2, 1, 3).reshape(b * d, f, c)
+        nt = ln(ht, "norm_temporal")
+        q = self._lin(nt, tb + ".attn_temporal.to_q", bias=False)
+        k = self._lin(nt, tb + ".attn_temporal.to_k", bias=False)
+        v = self._lin(nt, tb + ".attn_temporal.to_v", bias=False)
+        a = controlled_attention(q, k, v, heads, scale, None, False, place)
+        ht = ht + self._lin(a, tb + ".attn_temporal.to_out.0")
+        hs = ht.reshape(b, d, f, c).permute(0, 2, 1, 3).reshape(b * f, d, c)
+        # output
+        hs = hs.reshape(b * f, hh, ww, c).permute(0, 3, 1, 2)
+        hs = F.conv2d(hs, self.sd[name + ".proj_out.weight"], self.sd[name + ".proj_out.bias"])
+        out = hs + residual
+        return out.reshape(b, f, c, hh, ww).permute(0, 2, 1, 3, 4)
+
+    def time_embedding(self, timestep, batch):
+        """Timesteps(320, flip_sin_to_cos=True, shift 0) + TimestepEmbedding [3P]; unet_3d_condition.py:338-362."""
+        c0 = self.cfg.block_out_channels[0]
+        half = c0 // 2
+        t = torch.as_tensor([float(timestep)], dtype=torch.float32).expand(batch)
+        freq = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        e = t[:, None] * freq[None]
+        e = torch.cat([torch.cos(e), torch.sin(e)], dim=-1)
+        e = self._lin(e, "time_embedding.linear_1")
+        return self._lin(F.silu(e), "time_embedding.linear_2")
+
+    # -- forward --------------------------------------------------------------------------------
+    def __call__(self, sample, timestep, ctx, controller=None):
+        cfg = self.cfg
+        sample, ctx = sample.float(), ctx.float()
+        emb = self.time_embedding(timestep, sample.shape[0])
+        x = self._pseudo_conv3d(sample, "conv_in")
+        skips = [x]
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            has_attn = i < nb - 1
+            for j in range(cfg.layers_per_block):
+                x = self._resnet(x, emb, f"down_blocks.{i}.resnets.{j}")
+                if has_attn:
+                    x = self._transformer(x, ctx, f"down_blocks.{i}.attentions.{j}", "down", controller)
+                skips.append(x)
+            if i < nb - 1:
+                x = self._pseudo_conv3d(x, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
+                skips.append(x)
+        x = self._resnet(x, emb, "mid_block.resnets.0")
+        x = self._transformer(x, ctx, "mid_block.attentions.0", "mid", controller)
+        x = self._resnet(x, emb, "mid_block.resnets.1")
+        for i in range(nb):
+            has_attn = i > 0
+            for j in range(cfg.layers_per_block + 1):
+                x = torch.cat([x, skips.pop()], dim=1)
+                x = self._resnet(x, emb, f"up_blocks.{i}.resnets.{j}")
+                if has_attn:
+                    x = self._transformer(x, ctx, f"up_blocks.{i}.attentions.{j}", "up", controller)
+            if i < nb - 1:
+                b, c, f, h, w = x.shape  # resnet.py:123-175: nearest 2x per frame, then conv
+                x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+                x = x.reshape(b, f, c, 2 * h, 2 * w).permute(0, 2, 1, 3, 4)
+                x = self._pseudo_conv3d(x, f"up_blocks.{i}.upsamplers.0.conv")
+        x = F.group_norm(x, cfg.groups, self.sd["conv_norm_out.weight"], self.sd["conv_norm_out.bias"], cfg.eps)
+        x = F.silu(x)
+        return self._pseudo_conv3d(x, "conv_out")
+
+
+# --------------------------------------------------------------------------------------------
+# 3. controllers -- attention_store.py, attention_util.py, spatial_blend.py
+# --------------------------------------------------------------------------------------------
+
+_KEYS = ("down_cross", "mid_cross", "up_cross", "down_self", "mid_self", "up_self")
+
+
+def _empty_store():
+    return {k: [] for k in _KEYS}
+
+
+class StoreController:
+    """AttentionStore (attention_store.py:63-137) incl. AttentionControl.__call__ (:38-49)."""
+
+    def __init__(self, save_self_attention=True):
+        self.LOW_RESOURCE = False
+        self.cur_step = 0
+        self.cur_att_layer = 0
+        self.step_store = _empty_store()
+        self.attention_store: Dict[str, List[torch.Tensor]] = {}
+        self.attention_store_all_step: List[Dict[str, List[torch.Tensor]]] = []
+        self.latents_store: List[torch.Tensor] = []
+        self.save_self_attention = save_self_attention
+
+    def __call__(self, attn, is_cross, place):
+        if self.LOW_RESOURCE:
+            attn = self.forward(attn, is_cross, place)
+        else:
+            h = attn.shape[0]
+            attn[h // 2:] = self.forward(attn[h // 2:], is_cross, place)
+        self.cur_att_layer += 1
+        return attn
+
+    def forward(self, attn, is_cross, place):
+        key = f"{place}_{'cross' if is_cross else 'self'}"
+        if attn.shape[-2] <= 32 ** 2 and (is_cross or self.save_self_attention):
+            self.step_store[key].append(attn.detach().clone())
+        return attn
+
+    def between_steps(self):
+        if len(self.attention_store) == 0:
+            self.attention_store = {k: [t.clone() for t in v] for k, v in self.step_store.items()}
+        else:
+            for key in self.attention_store:
+                for i in range(len(self.attention_store[key])):
+                    self.attention_store[key][i] = self.attention_store[key][i] + self.step_store[key][i]
+        self.attention_store_all_step.append(self.step_store)
+        self.step_store = _empty_store()
+
+    def step_callback(self, x_t):
+        self.cur_att_layer = 0
+        self.cur_step += 1
+        self.between_steps()
+        self.latents_store.append(x_t.detach().clone())
+        return x_t
+
+
+def blend_get_mask(maps, alpha, th, use_pool, h, w, prompt_choose):
+    """spatial_blend.py:24-56 (SpatialBlender.get_mask) without the PNG dump. maps [P,L*heads,F,r,r,77]."""
+    maps = (maps * alpha).sum(-1).mean(1)
+    if use_pool:
+        maps = F.max_pool2d(maps, (3, 3), (1, 1), padding=(1, 1))
+    mask = F.interpolate(maps, size=(h, w))
+    mask = mask / mask.max(-2, keepdim=True)[0].max(-1, keepdim=True)[0]
+    mask = mask.gt(th[1 - int(use_pool)])
+    if prompt_choose == "both":
+        assert mask.shape[0] == 2
+        mask = mask[:1] + mask
+    return mask
+
+
+class Blender:
+    """SpatialBlender (spatial_blend.py:19-176), substruct_words unsupported (never set by make_controller)."""
+
+    def __init__(self, alpha_layers, th, num_ddim_steps, start_blend, end_blend, prompt_choose):
+        self.alpha_layers = alpha_layers
+        self.th = th
+        self.start_blend = int(start_blend * num_ddim_steps)
+        self.end_blend = int(end_blend * num_ddim_steps)
+        self.prompt_choose = prompt_choose
+        self.counter = 0
+        self.mask_list: List[torch.Tensor] = []
+
+    def __call__(self, attention_store, target_h=None, target_w=None, x_t=None):
+        if target_h is None and x_t is not None:
+            target_h, target_w = x_t.shape[-2:]
+        self.counter += 1
+        maps = attention_store["down_cross"][2:4] + attention_store["up_cross"][:3]
+        rearranged = []
+        for item in maps:
+            if item.dim() == 4:
+                item = item[None]
+            p, c, heads, r, w = item.shape
+            res = int(np.sqrt(r))
+            assert r == res * res
+            # "p c h (res_h res_w) w -> p h c res_h res_w w"
+            rearranged.append(item.reshape(p, c, heads, res, res, w).permute(0, 2, 1, 3, 4, 5).float())
+        maps = torch.cat(rearranged, dim=1)
+        alpha = self.alpha_layers[0:1] if self.prompt_choose == "source" else self.alpha_layers
+        mask = blend_get_mask(maps, alpha, self.th, True, target_h, target_w, self.prompt_choose).float()
+        self.mask_list.append(mask[0][:, None, :, :].clone())
+        if x_t is not None:
+            if x_t.dim() == 5:
+                mask = mask[:, None]
+            if self.start_blend < self.counter < self.end_blend:
+                x_t = x_t[:1] + mask * (x_t - x_t[:1])
+            return x_t
+        return mask
+
+
+class EditController(StoreController):
+    """AttentionControlEdit + Replace/Refine/Reweight (attention_util.py:39-304) for batch_size 1 with an
+    inversion-time `additional_attention_store`."""
+
+    def __init__(self, store: StoreController, num_steps, cross_replace_alpha, self_replace_steps,
+                 mode: str, mapper=None, alphas=None, equalizer=None,
+                 attention_blend: Optional[Blender] = None, latent_blend: Optional[Blender] = None,
+                 use_inversion_attention=True, save_self_attention=True):
+        super().__init__(save_self_attention=save_self_attention)
+        self.store = store
+        self.cross_replace_alpha = cross_replace_alpha  # [T+1, 1, 1, 1, 77]
+        if isinstance(self_replace_steps, float):
+            self_replace_steps = 0, self_replace_steps
+        self.num_self_replace = int(num_steps * self_replace_steps[0]), int(num_steps * self_replace_steps[1])
+        assert mode in ("replace", "refine")
+        self.mode = mode
+        self.mapper = mapper
+        self.alphas = None if alphas is None else alphas.reshape(alphas.shape[0], 1, 1, alphas.shape[1])
+        self.equalizer = equalizer
+        self.attention_blend = attention_blend
+        self.latent_blend = latent_blend
+        self.use_inversion_attention = use_inversion_attention
+        self.pos = {k: 0 for k in _KEYS}
+
+    def replace_cross_attention(self, base, cur):
+        if self.mode == "replace":  # attention_util.py:213-223
+            out = torch.einsum("thpw,bwn->bthpn", base, self.mapper)
+        else:  # attention_util.py:243-253
+            br = base[:, :, :, self.mapper].permute(3, 0, 1, 2, 4)
+            out = br * self.alphas + cur * (1 - self.alphas)
+        if self.equalizer is not None:  # attention_util.py:282-286 (6-D result broadcasts back on assignment)
+            out = out[None] * self.equalizer[:, None, None, :]
+            out = out.reshape(out.shape[-5:]) if out.dim() == 6 else out
+        return out
+
+    def forward(self, attn, is_cross, place):
+        super().forward(attn, is_cross, place)
+        if attn.shape[-2] <= 32 ** 2:
+            key = f"{place}_{'cross' if is_cross else 'self'}"
+            pos = self.pos[key]
+            all_step = self.store.attention_store_all_step
+            sis = len(all_step) - self.cur_step - 1 if self.use_inversion_attention else self.cur_step
+            step_dict = all_step[sis]
+            base = step_dict[key][pos]
+            self.pos[key] += 1
+            if is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]):
+                f = attn.shape[0]
+                attn5 = attn.reshape(1, f, *attn.shape[1:]).clone()
+                if is_cross:
+                    aw = self.cross_replace_alpha[self.cur_step]
+                    attn5 = self.replace_cross_attention(base, attn5) * aw + (1 - aw) * attn5
+                else:
+                    if self.attention_blend is not None:
+                        h = int(np.sqrt(attn5.shape[-2]))
+                        mask = self.attention_blend(step_dict, target_h=h, target_w=h)  # [1,F,h,w]
+                        m = mask.permute(1, 0, 2, 3).reshape(mask.shape[1], mask.shape[0], h * h)[..., None]
+                        attn5 = m * attn5 + (1 - m) * base[None]
+                    else:
+                        attn5 = base[None].expand_as(attn5)
+                attn = attn5.reshape(f, *attn5.shape[2:])
+        return attn
+
+    def between_steps(self):
+        super().between_steps()
+        self.pos = {k: 0 for k in _KEYS}
+
+    def step_callback(self, x_t):
+        x_t = super().step_callback(x_t)
+        if self.latent_blend is not None:  # attention_util.py:47-78
+            if self.use_inversion_attention:
+                sis = len(self.store.latents_store) - self.cur_step
+            else:
+                sis = self.cur_step
+            inverted = self.store.latents_store[sis]
+            sd = self.store.attention_store_all_step[sis]
+            blend = {k: [torch.cat([a[None], self.attention_store[k][i][None]], dim=0)
+                         for i, a in enumerate(sd[k])] for k in ("down_cross", "mid_cross", "up_cross")}
+            x_t = self.latent_blend(blend, x_t=torch.cat([inverted, x_t], dim=0))[1:]
+        return x_t
+
+
+def make_edit_controller(tokenizer, prompts, store, num_steps, is_replace_controller, cross_replace_steps,
+                         self_replace_steps, blend_words=None, eq_params=None, blend_th=(0.3, 0.3),
+                         blend_self_attention=False, blend_latents=False, use_inversion_attention=True,
+                         save_self_attention=True) -> EditController:
+    """attention_util.py:320-387 (make_controller) with additional_attention_store=store."""
+    latent_blend = attention_blend = None
+    if blend_words is not None and blend_words != "None":
+        al = blend_alpha_layers(prompts, blend_words, tokenizer)
+        if blend_latents:
+            latent_blend = Blender(al, blend_th, num_steps, 0.2, 0.8, "both")
+        if blend_self_attention:
+            attention_blend = Blender(al, blend_th, num_steps, 0.0, 2, "source")
+    cra = get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer)
+    if is_replace_controller:
+        kw = dict(mode="replace", mapper=get_replacement_mapper(prompts, tokenizer))
+    else:
+        mp, al2 = get_refinement_mapper(prompts, tokenizer)
+        kw = dict(mode="refine", mapper=mp, alphas=al2)
+    eq = None
+    if eq_params is not None:
+        eq = get_equalizer(prompts[1], eq_params["words"], eq_params["values"], tokenizer)
+    return EditController(store, num_steps, cra, self_replace_steps, equalizer=eq,
+                          attention_blend=attention_blend, latent_blend=latent_blend,
+                          use_inversion_attention=use_inversion_attention,
+                          save_self_attention=save_self_attention, **kw)
+
+
+# --------------------------------------------------------------------------------------------
+# 4. the two hot loops -- p2p_ddim_spatial_temporal.py:132-148 and :386-421
+# --------------------------------------------------------------------------------------------
+
+
+def ddim_inversion(unet: OracleUNet, sched: DDIMSchedule, latent, cond_emb, store: Optional[StoreController]):
+    """ddim_clean2noisy_loop (p2p_ddim:132-148) with LOW_RESOURCE=True (p2p_ddim:80)."""
+    if store is not None:
+        store.LOW_RESOURCE = True
+    all_latent = [latent]
+    latent = latent.clone()
+    T = len(sched.timesteps)
+    for i in range(T):
+        t = int(sched.timesteps[T - i - 1])
+        eps = unet(latent, t, cond_emb, store)
+        latent = sched.inverse_step(eps, t, latent)
+        if store is not None:
+            store.step_callback(latent)
+        all_latent.append(latent)
+    if store is not None:
+        store.LOW_RESOURCE = False
+    return all_latent
+
+
+def ddim_edit(unet: OracleUNet, sched: DDIMSchedule, latents, text_emb, controller, guidance_scale=7.5):
+    """sd_ddim_pipeline denoise loop (p2p_ddim:386-421), text_emb = [uncond; cond]."""
+    for t in sched.timesteps:
+        t = int(t)
+        inp = torch.cat([latents] * 2)
+        eps2 = unet(inp, t, text_emb, controller)
+        eu, ec = eps2.chunk(2)
+        eps = eu + guidance_scale * (ec - eu)
+        latents = sched.step(eps, t, latents)
+        if controller is not None:
+            latents = controller.step_callback(latents)
+    return latents
