@@ -1,0 +1,180 @@
+"""Pin oracle/fatezero_oracle.py (the CPU restatement) against vectors produced by the UNMODIFIED
+reference (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ReplayTokenizer, assert_digest_close, load_json, load_npz, tensor_digest, unpack_bits
+from oracle import fatezero_oracle as O
+from oracle.weights import procedural_state_dict
+
+TINY = {
+    "tiny16": dict(block_out_channels=(32, 64, 128, 128), norm_num_groups=8, cross_attention_dim=64, attention_head_dim=2),
+    "tiny40": dict(block_out_channels=(80, 160, 320, 320), norm_num_groups=16, cross_attention_dim=64, attention_head_dim=2),
+}
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return ReplayTokenizer()
+
+
+def test_host_constants_exact(tok):
+    gold = load_json("host_constants.json")
+    for name, c in gold.items():
+        prompts, T = c["prompts"], c["T"]
+        for key, inds in c["word_inds"].items():
+            p, w = key.rsplit("|", 1)
+            assert O.get_word_inds(p, w, tok).tolist() == inds, (name, key)
+        crs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c["cross_replace_steps"].items()}
+        a = O.get_time_words_attention_alpha(prompts, T, crs, tok)
+        assert a.reshape(T + 1, 77).to(torch.uint8).tolist() == c["cross_replace_alpha"], name
+        if c["is_replace"]:
+            assert O.get_replacement_mapper(prompts, tok)[0].tolist() == c["replacement_mapper"], name
+        else:
+            mp, al = O.get_refinement_mapper(prompts, tok)
+            assert mp[0].tolist() == c["refinement_mapper"], name
+            assert al[0].tolist() == c["refinement_alphas"], name
+        if c["eq_params"] is not None:
+            eq = O.get_equalizer(prompts[1], c["eq_params"]["words"], c["eq_params"]["values"], tok)
+            assert eq[0].tolist() == c["equalizer"], name
+        if c["blend_words"] is not None:
+            al = O.blend_alpha_layers(prompts, c["blend_words"], tok)
+            assert al.reshape(2, 77).tolist() == c["alpha_layers"], name
+
+
+def _oracle_unet(meta_case, shapes):
+    cfg = O.UNetConfig(**TINY[meta_case["kind"]], model_config=meta_case["model_config"])
+    return O.OracleUNet(procedural_state_dict([(n, tuple(s)) for n, s in shapes]), cfg)
+
+
+@pytest.mark.parametrize("name", ["unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d", "unet_tiny40_default"])
+def test_unet_forward_matches_reference(name):
+    meta = load_json("unet_meta.json")
+    m = meta[name]
+    shapes = m["state_dict_shapes"] or meta["unet_tiny16_default"]["state_dict_shapes"]
+    unet = _oracle_unet(m, shapes)
+    g = load_npz(name + ".npz")
+    store = O.StoreController()
+    store.LOW_RESOURCE = True
+    y = unet(torch.from_numpy(g["x"]), int(g["t"]), torch.from_numpy(g["ctx"]), store)
+    err = (y - torch.from_numpy(g["y"])).abs().max().item()
+    assert err < 2e-4, err
+    for key, lst in m["map_shapes"].items():
+        assert [list(t.shape) for t in store.step_store[key]] == lst, key
+        for i, dg in enumerate(m["map_digests"][key]):
+            assert_digest_close(tensor_digest(store.step_store[key][i]), dg, what=f"{key}[{i}]")
+
+
+def _calls(F_, heads, n_kv, g, batch, peaky=4.0):
+    """Same synthetic call stream as oracle/gen_golden.py:synthetic_layer_calls (same RNG consumption)."""
+    order = [("down", 4096, 4), ("down", 1024, 4), ("down", 256, 4), ("mid", 64, 2),
+             ("up", 256, 6), ("up", 1024, 6), ("up", 4096, 6)]
+    for place, lq, n in order:
+        for i in range(n):
+            is_cross = (i % 2 == 1)
+            if lq > 1024:
+                yield torch.zeros(batch * F_, heads, lq, 1).expand(batch * F_, heads, lq, 2), is_cross, place
+                continue
+            lk = 77 if is_cross else n_kv * lq
+            logits = torch.randn(batch * F_, heads, lq, lk, generator=g) * peaky
+            if is_cross:
+                r = int(lq ** 0.5)
+                yy, xx = torch.meshgrid(torch.arange(r), torch.arange(r), indexing="ij")
+                cx = torch.rand(batch * F_, 1, 1, lk, generator=g) * r
+                cy = torch.rand(batch * F_, 1, 1, lk, generator=g) * r
+                d2 = (xx.reshape(1, 1, lq, 1) - cx) ** 2 + (yy.reshape(1, 1, lq, 1) - cy) ** 2
+                logits = logits * 0.3 - d2 / (2 * (r / 4) ** 2)
+            yield logits.softmax(-1), is_cross, place
+
+
+PROMPT_CASES = {c: load_json("host_constants.json")[c] for c in ("teaser_posche", "teaser_watercolor")}
+
+
+@pytest.mark.parametrize("case", ["teaser_posche", "teaser_watercolor"])
+@pytest.mark.parametrize("variant", ["attn_blend", "latent_blend"])
+def test_controllers_on_synthetic_maps(tok, case, variant):
+    meta = load_json("controller_meta.json")
+    F_, heads, T = meta["F"], meta["heads"], meta["T"]
+    c = PROMPT_CASES[case]
+    gold_d = meta["cases"][f"{case}_{variant}"]["digests"]
+    gz = load_npz(f"controller_{case}_{variant}.npz")
+    g = torch.Generator().manual_seed(meta["seed"])
+    store = O.StoreController()
+    store.LOW_RESOURCE = True
+    for s in range(T):
+        for attn, is_cross, place in _calls(F_, heads, 2, g, 1):
+            store(attn.clone(), is_cross, place)
+        store.step_callback(torch.randn(1, 4, F_, 64, 64, generator=g))
+    store.LOW_RESOURCE = False
+    ctrl = O.make_edit_controller(tok, c["prompts"], store, T, c["is_replace"], dict(c["cross_replace_steps"]), 0.7,
+                                  blend_words=c["blend_words"], eq_params=c["eq_params"], blend_th=(0.3, 0.3),
+                                  blend_self_attention=(variant == "attn_blend"),
+                                  blend_latents=(variant == "latent_blend"), save_self_attention=False)
+    lat_d = []
+    for s in range(T):
+        k = 0
+        for attn, is_cross, place in _calls(F_, heads, 2, g, 2):
+            out = ctrl(attn.clone(), is_cross, place)
+            if attn.shape[-2] <= 1024:
+                assert_digest_close(tensor_digest(out[F_:]), gold_d[s][k], what=f"step{s} call{k} {place} cross={is_cross}")
+                k += 1
+        lat2 = ctrl.step_callback(torch.randn(1, 4, F_, 64, 64, generator=g))
+        d = tensor_digest(lat2)
+        lat_d.append([d["sum"], d["wsum"], d["abs"]])
+    assert np.allclose(np.array(lat_d), gz["latents_out_digest"], rtol=1e-5, atol=1e-4)
+    blender = ctrl.attention_blend if variant == "attn_blend" else ctrl.latent_blend
+    packed = {}
+    for m in blender.mask_list:
+        packed.setdefault(m.shape[-1], []).append(m.bool())
+    for r, v in packed.items():
+        got = torch.stack(v).numpy()
+        want = unpack_bits(gz[f"mask_r{r}"], gz[f"mask_r{r}_shape"])
+        assert got.shape == want.shape and (got != want).sum() == 0, f"mask r{r}: {(got != want).sum()} differing elements"
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["pipe_replace_blend", "pipe_refine_reweight_latentblend", "pipe_refine_noblend"])
+def test_pipeline_matches_reference(tok, name):
+    meta = load_json("pipeline_meta.json")[name]
+    consts = load_json("host_constants.json")[meta["prompt_case"]]
+    gz = load_npz(name + ".npz")
+    shapes = load_json("unet_meta.json")["unet_tiny16_default"]["state_dict_shapes"]
+    cfg = O.UNetConfig(**TINY["tiny16"], model_config=meta["model_config"])
+    unet = O.OracleUNet(procedural_state_dict([(n, tuple(s)) for n, s in shapes]), cfg)
+    T = meta["T"]
+    sched = O.DDIMSchedule(T)
+    assert [int(t) for t in sched.timesteps] == meta["timesteps"]
+    store = O.StoreController()
+    emb_src, emb_tgt = torch.from_numpy(gz["emb_src"]), torch.from_numpy(gz["emb_tgt"])
+    lat_all = O.ddim_inversion(unet, sched, torch.from_numpy(gz["z0"]), emb_src[1:], store)
+    dg = np.array([[d["sum"], d["wsum"], d["abs"]] for d in map(tensor_digest, lat_all)])
+    assert np.allclose(dg, gz["inv_latents_digest"], rtol=2e-4, atol=1e-2), (dg, gz["inv_latents_digest"])
+    assert (lat_all[-1] - torch.from_numpy(gz["zT"])).abs().max() < 2e-3
+    m0 = store.attention_store_all_step[0]
+    for key, lst in meta["map_shapes"].items():
+        assert [list(t.shape) for t in m0[key]] == lst
+        for i, d in enumerate(meta["map_digests_step0"][key]):
+            assert_digest_close(tensor_digest(m0[key][i]), d, what=f"{key}[{i}]")
+    kw = meta["kwargs"]
+    ctrl = O.make_edit_controller(
+        tok, consts["prompts"], store, T, kw["is_replace_controller"], dict(kw["cross_replace_steps"]),
+        kw["self_replace_steps"], blend_words=kw.get("blend_words"), eq_params=kw.get("eq_params"),
+        blend_th=tuple(kw["blend_th"]), blend_self_attention=kw.get("blend_self_attention", False),
+        blend_latents=kw.get("blend_latents", False), save_self_attention=kw["save_self_attention"])
+    edited = O.ddim_edit(unet, sched, torch.from_numpy(gz["zT"]), emb_tgt, ctrl, guidance_scale=kw["guidance_scale"])
+    ref = torch.from_numpy(gz["edited"])
+    err = (edited - ref).abs().max().item()
+    assert err < 5e-3 * max(1.0, ref.abs().max().item()), err
+    if ctrl.attention_blend is not None:
+        packed = {}
+        for m in ctrl.attention_blend.mask_list:
+            packed.setdefault(m.shape[-1], []).append(m.bool())
+        for r, v in packed.items():
+            got = torch.stack(v).numpy()
+            want = unpack_bits(gz[f"attn_mask_r{r}_bits"], gz[f"attn_mask_r{r}_shape"])
+            assert got.shape == want.shape and (got != want).sum() == 0
+    if ctrl.latent_blend is not None:
+        got = torch.stack(ctrl.latent_blend.mask_list).bool().numpy()
+        want = unpack_bits(gz["latent_mask_bits"], gz["latent_mask_shape"])
+        assert got.shape == want.shape and (got != want).sum() == 0
