@@ -1,0 +1,98 @@
+// attn_temporal.hip -- temporal attention over the F frames of every (batch, pixel, head): the un-patched
+// diffusers CrossAttention.forward applied on '(b d) f c' (attention.py:327-337 of the reference).
+//
+// The sequence length is the clip length (8..32), so this is a bandwidth problem, not an MFMA one: q, k, v stay
+// in their native token-major layout [(b f)][token][channel] (no '(b f) d c -> (b d) f c' rearrange is ever
+// materialised); one thread owns one (token, head, query frame), the F key/value rows of its pixel are shared
+// through L1 by the F threads of that pixel, and scores live in LDS.
+#include "fz_rt.h"
+#include "../../include/fatezero_hip.h"
+
+#define TMAXF 64
+#define TTHREADS 256
+
+struct TemporalArgs {
+    const half_t *q, *k, *v;
+    half_t* o;
+    int batch, F, tokens, heads, dh;
+    int64_t in_stride, out_stride;
+    float scale;
+    int tok_per_block;
+};
+
+FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) {
+    FZ_DYN_SMEM(raw);
+    float* S = reinterpret_cast<float*>(raw);  // [TTHREADS][F]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int tok0 = blockIdx.x * a.tok_per_block;
+    const int items = a.tok_per_block * a.heads * a.F;
+    const int nvec = a.dh >> 3;
+    float* myS = S + tid * a.F;
+    for (int w = tid; w < items; w += TTHREADS) {
+        const int h = w % a.heads;
+        const int tl = (w / a.heads) % a.tok_per_block;
+        const int i = w / (a.heads * a.tok_per_block);
+        const int tok = tok0 + tl;
+        if (tok >= a.tokens) continue;
+        const int64_t col = (int64_t)h * a.dh;
+        const half_t* qrow = a.q + ((int64_t)(b * a.F + i) * a.tokens + tok) * a.in_stride + col;
+        // pass 1: scores
+        float mx = -1e30f;
+        for (int j = 0; j < a.F; ++j) {
+            const half_t* krow = a.k + ((int64_t)(b * a.F + j) * a.tokens + tok) * a.in_stride + col;
+            float acc = 0.0f;
+            for (int c = 0; c < nvec; ++c) {
+                const half8_t qv = fz_ld_h8(qrow + 8 * c), kv = fz_ld_h8(krow + 8 * c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)qv[e] * (float)kv[e];
+            }
+            acc *= a.scale;
+            myS[j] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        float sum = 0.0f;
+        for (int j = 0; j < a.F; ++j) {
+            const float e = __builtin_expf(myS[j] - mx);
+            myS[j] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < a.F; ++j) myS[j] = (float)(half_t)(myS[j] * inv);  // P is cast to fp16 before P.V
+        // pass 2: O = P V
+        half_t* orow = a.o + ((int64_t)(b * a.F + i) * a.tokens + tok) * a.out_stride + col;
+        for (int c = 0; c < nvec; ++c) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+            for (int j = 0; j < a.F; ++j) {
+                const half8_t vv = fz_ld_h8(a.v + ((int64_t)(b * a.F + j) * a.tokens + tok) * a.in_stride + col + 8 * c);
+                const float pj = myS[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+            }
+            half8_t ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (half_t)acc[e];
+            fz_st_h8(orow + 8 * c, ov);
+        }
+    }
+}
+
+extern "C" int fz_attn_temporal(const void* q, const void* k, const void* v, void* o, int batch, int clip_len,
+                                int tokens, int heads, int head_dim, int64_t qkv_row_stride, int64_t o_row_stride,
+                                float scale, void* stream) {
+    if (!q || !k || !v || !o || batch <= 0 || clip_len <= 0 || clip_len > TMAXF || tokens <= 0) return FZ_ERR_BAD_ARG;
+    if ((head_dim & 7) || (qkv_row_stride & 7) || (o_row_stride & 7)) return FZ_ERR_BAD_ARG;
+    TemporalArgs a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.o = (half_t*)o;
+    a.batch = batch; a.F = clip_len; a.tokens = tokens; a.heads = heads; a.dh = head_dim;
+    a.in_stride = qkv_row_stride; a.out_stride = o_row_stride; a.scale = scale;
+    int tpb = TTHREADS / (heads * clip_len);
+    if (tpb < 1) tpb = 1;
+    a.tok_per_block = tpb;
+    dim3 grid((tokens + tpb - 1) / tpb, batch), block(TTHREADS);
+    const size_t smem = (size_t)TTHREADS * clip_len * sizeof(float);
+    FZ_LAUNCH(attn_temporal_kernel, grid, block, smem, stream, a);
+    return fz_last_launch_status();
+}

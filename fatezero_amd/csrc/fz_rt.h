@@ -1,0 +1,166 @@
+// fz_rt.h -- runtime layer shared by every kernel translation unit of libfatezero_hip.so
+//
+// Two build modes of the SAME kernel sources:
+//   * default (hipcc --offload-arch=gfx950): real HIP; this is the product.
+//   * -DFZ_EMU (host clang++): a deterministic CPU emulation of the HIP execution model
+//     (blocks -> OS threads, lanes -> fibers, 64-wide waves, LDS, __syncthreads, wave shuffles, MFMA
+//     fragment semantics).  TEST INFRASTRUCTURE ONLY: it produces libfatezero_emu.so, which nothing in
+//     the product ever loads; tests use it to exercise kernel index math and the host orchestration
+//     in the GPU-less authoring container.  It is not a fallback and is never shipped as one.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FZ_OK 0
+#define FZ_ERR_BAD_ARG -1
+#define FZ_ERR_UNSUPPORTED -2
+#define FZ_ERR_LAUNCH -3
+
+#ifndef FZ_EMU
+// ============================================================================================
+//                                       real HIP (gfx950)
+// ============================================================================================
+#include <hip/hip_runtime.h>
+
+#define FZ_KERNEL __global__
+#define FZ_DEVICE __device__ __forceinline__
+#define FZ_SHARED __shared__
+#define FZ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+typedef hipStream_t fz_stream_t;
+
+#define FZ_LAUNCH(kernel, grid, block, smem, stream, ...)                                    \
+    do {                                                                                     \
+        hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__);   \
+    } while (0)
+
+static inline int fz_last_launch_status() { return hipGetLastError() == hipSuccess ? FZ_OK : FZ_ERR_LAUNCH; }
+
+FZ_DEVICE f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+FZ_DEVICE float fz_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+FZ_DEVICE int fz_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+FZ_DEVICE float fz_shfl(float v, int lane) { return __shfl(v, lane, 64); }
+FZ_DEVICE unsigned long long fz_ballot(int pred) { return __ballot(pred); }
+FZ_DEVICE float fz_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+FZ_DEVICE float fz_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+FZ_DEVICE float fz_rsqrt(float x) { return rsqrtf(x); }
+
+#else
+// ============================================================================================
+//                                CPU emulation (tests only)
+// ============================================================================================
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <functional>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* fz_stream_t;
+
+namespace fz_emu {
+struct BlockCtx;
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local unsigned char* t_dyn_smem;
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void sync_block();                                  // __syncthreads
+void wave_exchange(const void* mine, void* all, size_t bytes);  // gather `bytes` from each of the wave's 64 lanes
+int lane_id();
+}  // namespace fz_emu
+
+#define threadIdx (fz_emu::t_threadIdx)
+#define blockIdx (fz_emu::t_blockIdx)
+#define blockDim (fz_emu::t_blockDim)
+#define gridDim (fz_emu::t_gridDim)
+
+#define FZ_KERNEL
+#define FZ_DEVICE static inline
+#define FZ_SHARED static thread_local
+#define FZ_DYN_SMEM(name) unsigned char* name = fz_emu::t_dyn_smem
+#define __launch_bounds__(...)
+#define __restrict__
+
+#define FZ_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    fz_emu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+
+static inline int fz_last_launch_status() { return FZ_OK; }
+static inline void __syncthreads() { fz_emu::sync_block(); }
+
+// v_mfma_f32_32x32x16_f16 fragment semantics (cdna_hip_programming.md §3):
+//   A[i][k]: lane = i + 32*(k/8), element k%8;  B[k][n]: lane = n + 32*(k/8), element k%8
+//   C/D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
+    struct Pair { half8_t a, b; } mine = {a, b}, all[64];
+    fz_emu::wave_exchange(&mine, all, sizeof(Pair));
+    const int lane = fz_emu::lane_id();
+    const int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const float av = (float)all[row + 32 * (k >> 3)].a[k & 7];
+            const float bv = (float)all[col + 32 * (k >> 3)].b[k & 7];
+            acc += av * bv;
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+static inline float fz_shfl_xor(float v, int mask) {
+    float all[64];
+    fz_emu::wave_exchange(&v, all, sizeof(float));
+    return all[fz_emu::lane_id() ^ mask];
+}
+static inline int fz_shfl_xor_i(int v, int mask) {
+    int all[64];
+    fz_emu::wave_exchange(&v, all, sizeof(int));
+    return all[fz_emu::lane_id() ^ mask];
+}
+static inline float fz_shfl(float v, int lane) {
+    float all[64];
+    fz_emu::wave_exchange(&v, all, sizeof(float));
+    return all[lane & 63];
+}
+static inline unsigned long long fz_ballot(int pred) {
+    int all[64];
+    fz_emu::wave_exchange(&pred, all, sizeof(int));
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) m |= (unsigned long long)(all[i] != 0) << i;
+    return m;
+}
+static inline float fz_exp2(float x) { return exp2f(x); }
+static inline float fz_rcp(float x) { return 1.0f / x; }
+static inline float fz_rsqrt(float x) { return 1.0f / sqrtf(x); }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+#endif
+
+// --------------------------------------------------------------------------------------------
+// small helpers common to both modes
+// --------------------------------------------------------------------------------------------
+FZ_DEVICE half8_t fz_zero_h8() {
+    half8_t z;
+    for (int i = 0; i < 8; ++i) z[i] = (half_t)0.0f;
+    return z;
+}
+FZ_DEVICE f32x16 fz_zero_f16v() {
+    f32x16 z;
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+FZ_DEVICE half8_t fz_ld_h8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
+FZ_DEVICE void fz_st_h8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
+
+static inline int fz_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int fz_round_up(int a, int b) { return fz_ceil_div(a, b) * b; }

@@ -1,0 +1,241 @@
+// norms.hip -- GroupNorm(+SiLU) over token-major activations and LayerNorm, for gfx950.
+//
+// GroupNorm replaces torch.nn.GroupNorm + F.silu of the reference: on 5-D tensors [b,c,f,h,w] inside
+// ResnetBlockPseudo3D (resnet.py:338-339, :369, :384) and conv_norm_out (unet_3d_condition.py:439-440) the
+// statistics of one (batch, group) span ALL frames ("span" = F); inside SpatioTemporalTransformerModel
+// (attention.py:110) the input is 4-D [(b f),c,h,w] so they are per frame (span = 1).
+// Layout is x[n][token][C] fp16.  Three small HBM-bound kernels:
+//   gn_stats    : per (frame, 64-token chunk) Welford partials (n, mean, M2) for each group   (reads x once)
+//   gn_finalize : deterministic Chan merge of the partials of a span -> (mean, rstd) per (span, group)
+//   gn_apply    : y = silu?((x - mean) * rstd * gamma + beta)                          (reads x once, writes y)
+// Split stats/apply is also the form frame-sharded multi-GPU needs: the finalize step is where the per-rank
+// partials are all-reduced.
+#include "fz_rt.h"
+#include "../../include/fatezero_hip.h"
+
+#define GN_TB 64 /* tokens per block */
+
+extern "C" int fz_groupnorm_chunks(int tokens, int channels) {
+    (void)channels;
+    return (tokens + GN_TB - 1) / GN_TB;
+}
+
+struct GnArgs {
+    const half_t* x;
+    half_t* y;
+    const half_t *gamma, *beta;
+    float* partial;  // [n_frames][chunks][G][3]
+    float* stats;    // [n_frames/span][G][2]
+    int n_frames, span, tokens, C, G, chunks, V, R;
+    float eps;
+    int silu;
+};
+
+FZ_KERNEL void gn_stats_kernel(GnArgs a) {
+    // two sweeps over the chunk (the second one hits L2): exact chunk mean first, then sum (x-mean)^2, so the
+    // partial variance never suffers the E[x^2]-E[x]^2 cancellation
+    FZ_DYN_SMEM(raw);
+    float* red = reinterpret_cast<float*>(raw);  // [R][C]
+    float* gmean = red + a.R * a.C;              // [G]
+    const int tid = threadIdx.x, v = tid % a.V, r = tid / a.V;
+    const int chunk = blockIdx.x, n = blockIdx.y;
+    const int t0 = chunk * GN_TB;
+    const int t1 = min(t0 + GN_TB, a.tokens);
+    const int cg = a.C / a.G;
+    const float cnt = (float)((t1 - t0) * cg);
+    const half_t* base = a.x + ((int64_t)n * a.tokens) * a.C + v * 8;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.0f;
+    for (int t = t0 + r; t < t1; t += a.R) {
+        const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)xv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[r * a.C + v * 8 + e] = s[e];
+    __syncthreads();
+    if (tid < a.G) {
+        float sum = 0.0f;
+        for (int rr = 0; rr < a.R; ++rr)
+            for (int c = tid * cg; c < (tid + 1) * cg; ++c) sum += red[rr * a.C + c];
+        gmean[tid] = sum / cnt;
+    }
+    __syncthreads();
+    float mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mu[e] = gmean[(v * 8 + e) / cg];
+        s[e] = 0.0f;
+    }
+    for (int t = t0 + r; t < t1; t += a.R) {
+        const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dlt = (float)xv[e] - mu[e];
+            s[e] += dlt * dlt;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[r * a.C + v * 8 + e] = s[e];
+    __syncthreads();
+    if (tid < a.G) {
+        float m2 = 0.0f;
+        for (int rr = 0; rr < a.R; ++rr)
+            for (int c = tid * cg; c < (tid + 1) * cg; ++c) m2 += red[rr * a.C + c];
+        float* out = a.partial + (((int64_t)n * a.chunks + chunk) * a.G + tid) * 3;
+        out[0] = cnt;
+        out[1] = gmean[tid];
+        out[2] = m2;
+    }
+}
+
+FZ_KERNEL void gn_finalize_kernel(GnArgs a) {
+    // one thread per (span, group): Chan's parallel-variance merge in a fixed order
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nspan = a.n_frames / a.span;
+    if (idx >= nspan * a.G) return;
+    const int sp = idx / a.G, g = idx % a.G;
+    float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
+    for (int f = 0; f < a.span; ++f)
+        for (int c = 0; c < a.chunks; ++c) {
+            const float* pp = a.partial + (((int64_t)(sp * a.span + f) * a.chunks + c) * a.G + g) * 3;
+            const float nb = pp[0], mb = pp[1], m2b = pp[2];
+            const float tot = cnt + nb;
+            const float delta = mb - mean;
+            mean += delta * (nb / tot);
+            m2 += m2b + delta * delta * (cnt * nb / tot);
+            cnt = tot;
+        }
+    const float var = m2 / cnt;  // biased, as torch.nn.GroupNorm
+    a.stats[idx * 2 + 0] = mean;
+    a.stats[idx * 2 + 1] = 1.0f / sqrtf(var + a.eps);
+}
+
+FZ_KERNEL void gn_apply_kernel(GnArgs a) {
+    const int tid = threadIdx.x, v = tid % a.V, r = tid / a.V;
+    const int chunk = blockIdx.x, n = blockIdx.y;
+    const int t0 = chunk * GN_TB;
+    const int t1 = min(t0 + GN_TB, a.tokens);
+    const int cg = a.C / a.G;
+    const int sp = n / a.span;
+    float sc[8], sh[8];
+    const half8_t gv = fz_ld_h8(a.gamma + v * 8), bv = fz_ld_h8(a.beta + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (v * 8 + e) / cg;
+        const float mean = a.stats[(sp * a.G + g) * 2 + 0], rstd = a.stats[(sp * a.G + g) * 2 + 1];
+        sc[e] = rstd * (float)gv[e];
+        sh[e] = (float)bv[e] - mean * sc[e];
+    }
+    const half_t* xb = a.x + ((int64_t)n * a.tokens) * a.C + v * 8;
+    half_t* yb = a.y + ((int64_t)n * a.tokens) * a.C + v * 8;
+    for (int t = t0 + r; t < t1; t += a.R) {
+        const half8_t xv = fz_ld_h8(xb + (int64_t)t * a.C);
+        half8_t yv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)xv[e] * sc[e] + sh[e];
+            if (a.silu) f = f / (1.0f + __builtin_expf(-f));
+            yv[e] = (half_t)f;
+        }
+        fz_st_h8(yb + (int64_t)t * a.C, yv);
+    }
+}
+
+extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
+                            int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream) {
+    if (!x || !y || !gamma || !beta || !partial) return FZ_ERR_BAD_ARG;
+    if (n_frames <= 0 || span <= 0 || n_frames % span || channels % 8 || channels % groups || groups > 64)
+        return FZ_ERR_BAD_ARG;
+    GnArgs a;
+    a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
+    a.n_frames = n_frames; a.span = span; a.tokens = tokens; a.C = channels; a.G = groups;
+    a.chunks = fz_groupnorm_chunks(tokens, channels);
+    a.V = channels / 8;
+    if (a.V > 1024) return FZ_ERR_UNSUPPORTED;
+    a.R = a.V >= 256 ? 1 : 256 / a.V;
+    a.eps = eps; a.silu = silu;
+    a.partial = partial;
+    a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
+    const int threads = a.V * a.R < 64 ? 64 : a.V * a.R;  // >= G threads are needed for the per-group reduction
+    // threads beyond V*R would alias rows: keep r < R by construction (threads == V*R unless tiny C)
+    if (a.V * a.R < 64) return FZ_ERR_UNSUPPORTED;
+    dim3 grid(a.chunks, n_frames), block(threads);
+    const size_t smem = ((size_t)a.R * channels + groups) * sizeof(float);
+    FZ_LAUNCH(gn_stats_kernel, grid, block, smem, stream, a);
+    const int nst = (n_frames / span) * groups;
+    FZ_LAUNCH(gn_finalize_kernel, dim3((nst + 63) / 64), dim3(64), 0, stream, a);
+    FZ_LAUNCH(gn_apply_kernel, grid, block, 0, stream, a);
+    return fz_last_launch_status();
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// LayerNorm over channels (attention.py:193-233: norm1/2/3, norm_temporal): one wave per token row, the row is
+// held in registers (<= 5 x 8 channels per lane), two-pass mean / variance like torch.
+// ----------------------------------------------------------------------------------------------------------
+#define LN_MAXV 5
+
+FZ_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += fz_shfl_xor(v, m);
+    return v;
+}
+
+FZ_KERNEL void __launch_bounds__(256)
+layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const half_t* __restrict__ gamma,
+                 const half_t* __restrict__ beta, int64_t rows, int C, float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    const bool rvalid = row < rows;  // keep every lane alive for the shuffles
+    const int V = C >> 3;
+    half8_t xv[LN_MAXV];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (rvalid && v < V) {
+            xv[i] = fz_ld_h8(x + row * C + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)xv[i][e];
+        } else {
+            xv[i] = fz_zero_h8();
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dlt = (float)xv[i][e] - mean;
+                sq += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (rvalid && v < V) {
+            const half8_t gv = fz_ld_h8(gamma + v * 8), bv = fz_ld_h8(beta + v * 8);
+            half8_t yv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yv[e] = (half_t)(((float)xv[i][e] - mean) * rstd * (float)gv[e] + (float)bv[e]);
+            fz_st_h8(y + row * C + v * 8, yv);
+        }
+    }
+}
+
+extern "C" int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,
+                            float eps, void* stream) {
+    if (!x || !y || !gamma || !beta || rows <= 0) return FZ_ERR_BAD_ARG;
+    if (channels % 8 || channels / 8 > 64 * LN_MAXV) return FZ_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    FZ_LAUNCH(layernorm_kernel, grid, block, 0, stream, (const half_t*)x, (half_t*)y, (const half_t*)gamma,
+              (const half_t*)beta, rows, channels, eps);
+    return fz_last_launch_status();
+}

@@ -1,0 +1,258 @@
+"""Tensor-level wrappers over the C ABI (include/fatezero_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below hands raw pointers and
+sizes to libfatezero_hip.so.  Nothing in this file computes with torch ops -- if the native library is missing
+the call raises (fatezero_amd._native.NativeLibraryError).
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+FZ_ATTN_FLASH, FZ_ATTN_CAPTURE, FZ_ATTN_INJECT = N.FZ_ATTN_FLASH, N.FZ_ATTN_CAPTURE, N.FZ_ATTN_INJECT
+CROSS_P_STRIDE = N.FZ_CROSS_P_STRIDE
+CROSS_KEYS = N.FZ_CROSS_MAX_KEYS
+SUPPORTED_HEAD_DIMS = (16, 32, 40, 64, 80, 128, 160)
+
+
+def _stream(t: torch.Tensor):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if not N.is_test_backend():
+        raise RuntimeError("fatezero_amd kernels run on the GPU only (CPU tensors are accepted only by the "
+                           "emulation backend used in tests)")
+    return C.c_void_p(0)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.float16, t.dtype
+            assert t.data_ptr() % 16 == 0, "16-byte alignment required"
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sparse-causal self attention
+# ------------------------------------------------------------------------------------------------------------
+def kv_slots(index_list: Sequence, clip_len: int) -> Tuple[List[int], List[int]]:
+    """SparseCausalAttention_index -> per kv slot (is_absolute, frame or offset), attention_register.py:162-183.
+    An empty list means 'own frame' (attention.py:171-173 sets it for dim < least_sc_channel)."""
+    if len(index_list) == 0:
+        return [0], [0]
+    kabs, kval = [], []
+    for index in index_list:
+        if isinstance(index, str):
+            if index == "first":
+                fr = 0
+            elif index == "last":
+                fr = clip_len - 1
+            elif index in ("mid", "middle"):
+                fr = int((clip_len - 1) // 2)
+            else:
+                raise ValueError(f"unknown SparseCausalAttention_index entry {index!r}")
+            kabs.append(1)
+            kval.append(fr)
+        else:
+            assert isinstance(index, int), "relative index must be int"
+            kabs.append(0)
+            kval.append(int(index))
+    return kabs, kval
+
+
+def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out: torch.Tensor, *, clip_len: int,
+              heads: int, index_list: Sequence, mode: int = FZ_ATTN_FLASH, frame0: int = 0, n_frames: Optional[int] = None,
+              p: Optional[torch.Tensor] = None, p_frame_off: int = 0, row_mask: Optional[torch.Tensor] = None,
+              mask_frame_off: int = 0, scale: Optional[float] = None):
+    """q,k,out: [N, L, >=C] views with row stride (token-major); vt: [N, C, Lpad]; p: [Fp, heads, Lq, Lk] fp16.
+
+    Frames frame0 .. frame0+n_frames-1 of q/out are processed; k/vt are indexed by source frame.
+    """
+    N_, lq, c = q.shape
+    d_head = c // heads
+    assert d_head in SUPPORTED_HEAD_DIMS, d_head
+    _chk16(q, k, vt, out, p)
+    n_frames = N_ - frame0 if n_frames is None else n_frames
+    kabs, kval = kv_slots(index_list, clip_len)
+    d = N.FzAttnSelfDesc()
+    d.n_frames, d.frame0, d.clip_len, d.heads, d.head_dim = n_frames, frame0, clip_len, heads, d_head
+    d.lq, d.lkf, d.n_kv = lq, (lq if k is None else k.shape[1]), len(kabs)
+    for j in range(len(kabs)):
+        d.kv_abs[j], d.kv_val[j] = kabs[j], kval[j]
+    d.scale = float(scale if scale is not None else d_head ** -0.5)
+    d.mode = mode
+    assert q.stride(2) == 1 and out.stride(2) == 1 and vt.stride(2) == 1
+    d.q_frame_stride, d.q_row_stride = q.stride(0), q.stride(1)
+    if k is not None:
+        assert k.stride(2) == 1
+        d.k_frame_stride, d.k_row_stride = k.stride(0), k.stride(1)
+    d.vt_frame_stride, d.vt_chan_stride = vt.stride(0), vt.stride(1)
+    assert vt.shape[2] >= pad64(d.lkf), (vt.shape, d.lkf)
+    d.o_frame_stride, d.o_row_stride = out.stride(0), out.stride(1)
+    if p is not None:
+        assert p.stride(3) == 1 and p.shape[3] == d.n_kv * d.lkf, (p.shape, d.n_kv, d.lkf)
+        d.p_frame_stride, d.p_head_stride, d.p_row_stride = p.stride(0), p.stride(1), p.stride(2)
+    d.p_frame_off, d.mask_frame_off = p_frame_off, mask_frame_off
+    if row_mask is not None:
+        assert row_mask.dtype == torch.float32 and row_mask.is_contiguous() and row_mask.shape[-1] == lq
+    N.check(N.lib().fz_attn_self(C.byref(d), _ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(p), _ptr(row_mask), _stream(q)),
+            "fz_attn_self")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# cross attention
+# ------------------------------------------------------------------------------------------------------------
+def attn_cross(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, clip_len: int, heads: int,
+               lk: int, mode: int = FZ_ATTN_FLASH, frame0: int = 0, n_frames: Optional[int] = None,
+               p: Optional[torch.Tensor] = None, p_frame_off: int = 0, mapper_t: Optional[torch.Tensor] = None,
+               coef: Optional[torch.Tensor] = None, cur_out: Optional[torch.Tensor] = None, scale: Optional[float] = None):
+    """q,out: [N, L, >=C]; k: [B, >=lk, >=C]; vt: [B, C, 96]; p / cur_out: [Fp, heads, Lq, 80] fp16 (row stride 80)."""
+    N_, lq, c = q.shape
+    d_head = c // heads
+    assert d_head in SUPPORTED_HEAD_DIMS, d_head
+    _chk16(q, k, vt, out, p, mapper_t, cur_out)
+    d = N.FzAttnCrossDesc()
+    d.n_frames = N_ - frame0 if n_frames is None else n_frames
+    d.frame0, d.clip_len, d.heads, d.head_dim, d.lq, d.lk = frame0, clip_len, heads, d_head, lq, lk
+    d.scale = float(scale if scale is not None else d_head ** -0.5)
+    d.mode = mode
+    d.q_frame_stride, d.q_row_stride = q.stride(0), q.stride(1)
+    d.k_batch_stride, d.k_row_stride = k.stride(0), k.stride(1)
+    d.vt_batch_stride, d.vt_chan_stride = vt.stride(0), vt.stride(1)
+    assert vt.shape[2] >= CROSS_KEYS and vt.stride(2) == 1
+    d.o_frame_stride, d.o_row_stride = out.stride(0), out.stride(1)
+    if p is not None:
+        assert p.stride(3) == 1 and p.stride(2) >= CROSS_P_STRIDE
+        d.p_frame_stride, d.p_head_stride, d.p_row_stride = p.stride(0), p.stride(1), p.stride(2)
+        if cur_out is not None:
+            assert cur_out.stride() == p.stride()
+    d.p_frame_off = p_frame_off
+    d.store_cur = 1 if cur_out is not None else 0
+    if coef is not None:
+        assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.numel() == 2 * CROSS_KEYS
+    if mapper_t is not None:
+        assert mapper_t.is_contiguous() and tuple(mapper_t.shape) == (CROSS_KEYS, CROSS_KEYS)
+    N.check(N.lib().fz_attn_cross(C.byref(d), _ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(p), _ptr(mapper_t), _ptr(coef),
+                                  _ptr(cur_out), _stream(q)), "fz_attn_cross")
+    return out
+
+
+def attn_temporal(q, k, v, out, *, batch: int, clip_len: int, heads: int, scale: Optional[float] = None):
+    """q,k,v,out: [B*F, tokens, >=C] token-major views sharing one row stride."""
+    _, tokens, c = q.shape
+    d_head = c // heads
+    _chk16(q, k, v, out)
+    assert q.stride(1) == k.stride(1) == v.stride(1) and q.stride(0) == tokens * q.stride(1)
+    assert out.stride(0) == tokens * out.stride(1)
+    N.check(N.lib().fz_attn_temporal(_ptr(q), _ptr(k), _ptr(v), _ptr(out), batch, clip_len, tokens, heads, d_head,
+                                     q.stride(1), out.stride(1), float(scale if scale is not None else d_head ** -0.5),
+                                     _stream(q)), "fz_attn_temporal")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+def blend_mask(maps: List[torch.Tensor], alpha: torch.Tensor, th: float, out_hw: Tuple[int, int], *, or_with_first: bool,
+               out: Optional[torch.Tensor] = None):
+    """maps: list of fp16 [P, F, heads, r*r, >=80] views (row stride >= 80); alpha float [P, 80] -> float [P,F,h,w]."""
+    m0 = maps[0]
+    P_, F_, heads, npix, _ = m0.shape
+    res = int(round(npix ** 0.5))
+    assert res * res == npix, "the shape of attention map must be a square"
+    for m in maps:
+        assert m.shape[:4] == m0.shape[:4] and m.stride() == m0.stride() and m.dtype == torch.float16
+        assert m.stride(4) == 1 and m.stride(2) == npix * m.stride(3) and m.stride(1) == heads * m.stride(2)
+    h, w = out_hw
+    if out is None:
+        out = torch.empty(P_, F_, h, w, dtype=torch.float32, device=m0.device)
+    arr = (C.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
+    assert alpha.dtype == torch.float32 and alpha.is_contiguous() and tuple(alpha.shape) == (P_, 80)
+    N.check(N.lib().fz_blend_mask(arr, len(maps), P_, m0.stride(0), F_, heads, res, m0.stride(3), _ptr(alpha), float(th),
+                                  h, w, 1 if or_with_first else 0, _ptr(out), None, _stream(m0)), "fz_blend_mask")
+    return out
+
+
+_gn_scratch = {}
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span: int, groups: int, eps: float,
+              silu: bool, out: Optional[torch.Tensor] = None):
+    """x: [N, tokens, C] contiguous fp16; statistics shared by `span` consecutive frames."""
+    n, tokens, c = x.shape
+    assert x.is_contiguous()
+    _chk16(x, gamma, beta)
+    if out is None:
+        out = torch.empty_like(x)
+    chunks = N.lib().fz_groupnorm_chunks(tokens, c)
+    need = n * chunks * groups * 3 + (n // span) * groups * 2
+    key = (x.device, )
+    buf = _gn_scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=x.device)
+        _gn_scratch[key] = buf
+    N.check(N.lib().fz_groupnorm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), n, span, tokens, c, groups, float(eps),
+                                 1 if silu else 0, _ptr(buf), _stream(x)), "fz_groupnorm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):
+    c = x.shape[-1]
+    assert x.is_contiguous()
+    _chk16(x, gamma, beta)
+    if out is None:
+        out = torch.empty_like(x)
+    N.check(N.lib().fz_layernorm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), x.numel() // c, c, float(eps), _stream(x)),
+            "fz_layernorm")
+    return out
+
+
+def geglu(x: torch.Tensor, out=None):
+    inner = x.shape[-1] // 2
+    assert x.is_contiguous()
+    _chk16(x)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], inner, dtype=x.dtype, device=x.device)
+    N.check(N.lib().fz_geglu(_ptr(x), _ptr(out), x.numel() // (2 * inner), inner, _stream(x)), "fz_geglu")
+    return out
+
+
+def transpose_pad(x: torch.Tensor, lp: int, out=None):
+    """x: [N, L, >=C view] (unit channel stride) -> [N, C, lp] with zero padding."""
+    n, l, c = x.shape
+    assert x.stride(2) == 1 and x.dtype == torch.float16
+    if out is None:
+        out = torch.empty(n, c, lp, dtype=x.dtype, device=x.device)
+    N.check(N.lib().fz_transpose_pad(_ptr(x), _ptr(out), n, l, c, x.stride(0), x.stride(1), lp, _stream(x)),
+            "fz_transpose_pad")
+    return out
+
+
+def latent_update(z: torch.Tensor, eps_u: Optional[torch.Tensor], eps_c: torch.Tensor, guidance: float, cz: float,
+                  ce: float, *, inv: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                  next_in: Optional[torch.Tensor] = None):
+    """z: float [4, F, hw] (in place); eps_*: fp16 [F, hw, 4]; inv like z; mask float [F, hw]; next_in fp16 [F, hw, 4]."""
+    _, frames, hw = z.shape
+    assert z.dtype == torch.float32 and z.is_contiguous() and eps_c.is_contiguous() and eps_c.dtype == torch.float16
+    N.check(N.lib().fz_latent_update(_ptr(z), _ptr(eps_u), _ptr(eps_c), float(guidance), float(cz), float(ce), _ptr(inv),
+                                     _ptr(mask), _ptr(next_in), frames, hw, _stream(z)), "fz_latent_update")
+    return z
+
+
+def accumulate(acc: torch.Tensor, x: torch.Tensor):
+    assert acc.dtype == torch.float32 and x.dtype == torch.float16 and acc.numel() == x.numel()
+    assert acc.is_contiguous() and x.is_contiguous()
+    N.check(N.lib().fz_accumulate(_ptr(acc), _ptr(x), x.numel(), _stream(x)), "fz_accumulate")
+    return acc
+
+
+def version() -> str:
+    return N.lib().fz_version().decode()

@@ -1,0 +1,146 @@
+/* fatezero_hip.h -- C ABI of libfatezero_hip.so, the MI355X (gfx950) kernels behind the FateZero
+ * DDIM-inversion -> attention-fusion denoise loop.
+ *
+ * The reference (ChenyangQiQi/FateZero) has no native code and no FFI layer: its boundary is the Python
+ * `controller(attn, is_cross, place_in_unet)` hook called between softmax and P.V inside the patched
+ * attention forward (video_diffusion/prompt_attention/attention_register.py:23-59) plus plain torch modules.
+ * Each entry point below replaces the torch ops named in its comment; the Python host
+ * (fatezero_amd/) binds them with ctypes -- see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every tensor is caller-allocated device memory, fp16 unless noted, 16-byte aligned;
+ *   - activations are token-major: x[n][token][channel], n = b*F + f (batch-major frame index),
+ *     channels = heads*head_dim with the head as the slow sub-index (diffusers reshape_heads_to_batch_dim);
+ *   - `stream` is a hipStream_t; calls are asynchronous, never allocate, never synchronise, keep no state;
+ *   - return 0 on success, <0 on error (FZ_ERR_*); nothing is thrown.
+ */
+#ifndef FATEZERO_HIP_H
+#define FATEZERO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FZ_ATTN_FLASH 0   /* O = softmax(scale QK^T) V, no map materialised                       */
+#define FZ_ATTN_CAPTURE 1 /* same, and the fp16 probability map is written to `p` (exact softmax) */
+#define FZ_ATTN_INJECT 2  /* rows take P from `p` (inversion-time map) instead of the live softmax */
+
+#define FZ_MAX_KV_SLOTS 4
+
+/* Sparse-causal spatio-temporal self-attention: `spatial_temporal_forward` + `_attention`
+ * (attention_register.py:131-218, :23-59; SparseCausalAttention.forward attention.py:340-422), with the
+ * controller's capture (AttentionStore.forward attention_store.py:81-93) and self-attention replacement /
+ * blend-mask fusion (AttentionControlEdit.replace_self_attention attention_util.py:80-92) fused in.
+ * K/V of frame f are the concatenation over kv slots j of frame kv_src(j,f):
+ *   kv_abs[j] ? kv_val[j] : clamp(f + kv_val[j], 0, F-1)          (attention_register.py:162-188)
+ * -- the concat is never materialised. V is passed TRANSPOSED per frame: vt[n][channel][token], token
+ * stride 1, each row zero-padded to a multiple of 64 tokens. */
+typedef struct FzAttnSelfDesc {
+    int32_t n_frames;   /* frames covered by this launch                                     */
+    int32_t frame0;     /* global index n of the first one (n = b*F + f)                     */
+    int32_t clip_len;   /* F                                                                 */
+    int32_t heads;
+    int32_t head_dim;   /* 16, 32, 40, 64, 80, 128 or 160                                    */
+    int32_t lq;         /* query tokens per frame                                            */
+    int32_t lkf;        /* key tokens per kv slot (= tokens per source frame)                */
+    int32_t n_kv;       /* 1..FZ_MAX_KV_SLOTS                                                */
+    int32_t kv_abs[FZ_MAX_KV_SLOTS];
+    int32_t kv_val[FZ_MAX_KV_SLOTS];
+    float scale;        /* head_dim^-0.5                                                     */
+    int32_t mode;       /* FZ_ATTN_*                                                         */
+    int64_t q_frame_stride, q_row_stride;   /* elements */
+    int64_t k_frame_stride, k_row_stride;
+    int64_t vt_frame_stride, vt_chan_stride;
+    int64_t o_frame_stride, o_row_stride;
+    /* probability map p[frame][head][q][col], col = j*lkf + key  (reference layout [F, heads, Lq, Lk]) */
+    int64_t p_frame_stride, p_head_stride, p_row_stride;
+    int32_t p_frame_off;    /* p frame index of this launch's first frame                    */
+    int32_t mask_frame_off; /* row_mask frame index of this launch's first frame             */
+} FzAttnSelfDesc;
+
+/* row_mask (INJECT only, may be NULL): float [frames][lq]; 1 -> the row keeps the live attention,
+ * 0 -> the row takes the stored map (blend mask of spatial_blend.py:58-124 reshaped [F,1,Lq,1]).
+ * NULL -> every row takes the stored map and QK^T is skipped. */
+int fz_attn_self(const FzAttnSelfDesc* desc, const void* q, const void* k, const void* vt, void* o,
+                 void* p, const float* row_mask, void* stream);
+
+#define FZ_CROSS_MAX_KEYS 96
+#define FZ_CROSS_P_STRIDE 80 /* arena row stride of a 77-token cross map (16-byte aligned rows) */
+
+/* Cross-attention `forward` + `_attention` (attention_register.py:71-128, :23-59) with capture and the
+ * fused prompt-to-prompt edit of AttentionControlEdit.forward (attention_util.py:129-132):
+ *   new = (base @ M) * A + cur * B          per key n: A[n], B[n]
+ * which covers Replace (attention_util.py:213-223, M = mapper), Refine (:243-253, M = one-hot gather of
+ * mapper, alphas folded into A/B), Reweight (:282-286, equalizer folded) and the per-step word gate
+ * cross_replace_alpha (ptp_utils.py:179-199).  K/V are per batch element: k[b][token][channel],
+ * vt[b][channel][token] (rows zero-padded to 96 tokens). */
+typedef struct FzAttnCrossDesc {
+    int32_t n_frames, frame0, clip_len, heads, head_dim, lq, lk;
+    float scale;
+    int32_t mode; /* FZ_ATTN_FLASH (plain), FZ_ATTN_CAPTURE, FZ_ATTN_INJECT */
+    int64_t q_frame_stride, q_row_stride;
+    int64_t k_batch_stride, k_row_stride;
+    int64_t vt_batch_stride, vt_chan_stride;
+    int64_t o_frame_stride, o_row_stride;
+    int64_t p_frame_stride, p_head_stride, p_row_stride; /* fp16 map (capture dst / inject base), row stride >= 80 */
+    int32_t p_frame_off;
+    int32_t store_cur; /* INJECT: also write the un-edited live map to `cur_out` (same strides as p) */
+} FzAttnCrossDesc;
+
+/* mapper_t: fp16 [96][96], mapper_t[n][w] = M[w][n] (zero padded); coef: float [2][96] = {A, B};
+ * cur_out: fp16 map buffer or NULL. */
+int fz_attn_cross(const FzAttnCrossDesc* desc, const void* q, const void* k, const void* vt, void* o,
+                  void* p, const void* mapper_t, const float* coef, void* cur_out, void* stream);
+
+/* Temporal attention over frames (un-patched CrossAttention.forward, attention.py:327-337):
+ * q,k,v,o: [B*F][tokens][channels] (row stride given); each (b, token, head) attends over its F frames. */
+int fz_attn_temporal(const void* q, const void* k, const void* v, void* o, int batch, int clip_len,
+                     int tokens, int heads, int head_dim, int64_t qkv_row_stride, int64_t o_row_stride,
+                     float scale, void* stream);
+
+/* Blend mask (SpatialBlender.get_mask, spatial_blend.py:24-56): maps: n_maps pointers to fp16 cross maps
+ * [P][F][heads][r*r][p_row_stride] (P = n_prompts, prompt stride given), alpha: float [P][80] word weights;
+ * out: float [P][F][h][w] of 0/1 after 3x3 max-pool, nearest resize, per-(P,F) max normalisation, > th.
+ * If or_with_first != 0 (prompt_choose == 'both'): out[p] |= out[0]. */
+int fz_blend_mask(const void* const* maps, int n_maps, int n_prompts, int64_t prompt_stride, int frames,
+                  int heads, int res, int64_t p_row_stride, const float* alpha, float th, int out_h, int out_w,
+                  int or_with_first, float* out, float* scratch, void* stream);
+
+/* GroupNorm (+SiLU) on token-major activations x[n][tokens][C] (resnet.py:338-339,369,384; attention.py:110;
+ * unet_3d_condition.py:439-440).  span = number of consecutive frames sharing statistics: F for the 5-D
+ * ResNet norms (stats over C/G x F x H x W), 1 for the per-frame transformer norm.
+ * partial: float scratch, >= n_frames * fz_groupnorm_chunks(tokens, C) * G * 3. */
+int fz_groupnorm_chunks(int tokens, int channels);
+int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
+                 int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream);
+
+/* LayerNorm over channels, rows = tokens (attention.py:193-233). gamma/beta fp16. */
+int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,
+                 float eps, void* stream);
+
+/* GEGLU gate (diffusers FeedForward): y[r][c] = x[r][c] * gelu_erf(x[r][inner + c]). */
+int fz_geglu(const void* x, void* y, int64_t rows, int inner, void* stream);
+
+/* out[n][c][lp] = in[n][l][c] transposed, zero padded l -> lp (V^T operand of the attention kernels). */
+int fz_transpose_pad(const void* in, void* out, int n, int l, int c, int64_t in_frame_stride, int64_t in_row_stride,
+                     int lp, void* stream);
+
+/* Fused latent update (p2p_ddim_spatial_temporal.py:150-161 inverse step; :400-407 CFG + DDIMScheduler.step):
+ *   eps = eps_u + g (eps_c - eps_u)   (eps_c only when eps_u == NULL)
+ *   z   = cz * z + ce * eps           [+ latent blend z = inv + mask (z - inv), spatial_blend.py:121]
+ * z: float [4][F][hw] (b c f h w, b = 1) updated in place; eps: fp16 token-major [F][hw][4];
+ * next_in: fp16 token-major [F][hw][4] = the next UNet input (may be NULL). */
+int fz_latent_update(float* z, const void* eps_u, const void* eps_c, float guidance, float cz, float ce,
+                     const float* inv, const float* mask, void* next_in, int frames, int hw, void* stream);
+
+/* fp16 running-sum helper for the edit controller's accumulated cross maps (attention_store.py:95-101):
+ * acc (float) += x (fp16), n elements. */
+int fz_accumulate(float* acc, const void* x, int64_t n, void* stream);
+
+const char* fz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FATEZERO_HIP_H */

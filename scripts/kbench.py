@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on the real SD-1.x shapes (8 frames x 512^2): algorithmic TFLOP/s for the
+MFMA-bound flash levels and GB/s for the HBM-bound capture/inject/norm kernels. Timed with HIP events on
+the launch stream."""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from fatezero_amd import kernels as K
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def main():
+    dev = "cuda"
+    F_, heads = 8, 8
+    res = {}
+    for (lq, c, idx) in [(4096, 320, [-1, "first"]), (4096, 320, ["mid"]), (1024, 640, [-1, "first"]), (256, 1280, [-1, "first"])]:
+        d = c // heads
+        n_kv = len(idx)
+        g = torch.Generator().manual_seed(0)
+        qk = (torch.randn(F_, lq, 2 * c, generator=g)).half().to(dev)
+        q, k = qk[..., :c], qk[..., c:]
+        vt = torch.randn(F_, c, lq, generator=g).half().to(dev)
+        out = torch.empty(F_, lq, c, dtype=torch.float16, device=dev)
+        flops = 4.0 * lq * (n_kv * lq) * c * F_
+        ms = timeit(lambda: K.attn_self(q, k, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_FLASH))
+        res[f"flash_L{lq}_d{d}_kv{n_kv}"] = {"ms": ms, "TFLOPs": flops / ms / 1e9}
+        if lq <= 1024:
+            p = torch.empty(F_, heads, lq, n_kv * lq, dtype=torch.float16, device=dev)
+            ms = timeit(lambda: K.attn_self(q, k, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_CAPTURE, p=p))
+            res[f"capture_L{lq}_d{d}"] = {"ms": ms, "GBps_written": p.numel() * 2 / ms / 1e6, "TFLOPs": flops / ms / 1e9}
+            ms = timeit(lambda: K.attn_self(q, None, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_INJECT, p=p))
+            res[f"inject_nomask_L{lq}_d{d}"] = {"ms": ms, "GBps_read": p.numel() * 2 / ms / 1e6}
+            mask = (torch.rand(F_, lq, generator=g) > 0.5).float().to(dev)
+            ms = timeit(lambda: K.attn_self(q, k, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_INJECT, p=p, row_mask=mask))
+            res[f"inject_mask_L{lq}_d{d}"] = {"ms": ms}
+    # cross
+    for (lq, c) in [(4096, 320), (1024, 640)]:
+        g = torch.Generator().manual_seed(0)
+        q = torch.randn(F_, lq, c, generator=g).half().to(dev)
+        k = torch.randn(1, 77, c, generator=g).half().to(dev)
+        vt = K.transpose_pad(torch.randn(1, 77, c, generator=g).half().to(dev), 96)
+        out = torch.empty(F_, lq, c, dtype=torch.float16, device=dev)
+        ms = timeit(lambda: K.attn_cross(q, k, vt, out, clip_len=F_, heads=heads, lk=77, mode=K.FZ_ATTN_FLASH))
+        res[f"cross_plain_L{lq}"] = {"ms": ms}
+        p = torch.empty(F_, heads, lq, 80, dtype=torch.float16, device=dev)
+        ms = timeit(lambda: K.attn_cross(q, k, vt, out, clip_len=F_, heads=heads, lk=77, mode=K.FZ_ATTN_CAPTURE, p=p))
+        res[f"cross_capture_L{lq}"] = {"ms": ms}
+    # norms
+    for (tokens, c) in [(4096, 320), (1024, 640), (256, 1280)]:
+        x = torch.randn(F_, tokens, c).half().to(dev)
+        gm, bt = torch.ones(c).half().to(dev), torch.zeros(c).half().to(dev)
+        ms = timeit(lambda: K.groupnorm(x, gm, bt, span=F_, groups=32, eps=1e-5, silu=True))
+        res[f"groupnorm_T{tokens}_C{c}"] = {"ms": ms, "GBps": x.numel() * 2 * 3 / ms / 1e6}
+        ms = timeit(lambda: K.layernorm(x, gm, bt))
+        res[f"layernorm_T{tokens}_C{c}"] = {"ms": ms, "GBps": x.numel() * 2 * 2 / ms / 1e6}
+    x = torch.randn(F_, 4096, 320).half().to(dev)
+    ms = timeit(lambda: K.attn_temporal(x, x, x, torch.empty_like(x), batch=1, clip_len=F_, heads=8))
+    res["temporal_T4096_C320"] = {"ms": ms}
+    print(json.dumps(res, indent=1))
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,309 @@
+"""Kernel-level parity cases shared by the CPU-emulation suite (tests/test_kernels_emu.py) and the MI355X suite
+(tests/test_kernels_gpu.py).  References are plain fp32 torch on CPU.  Tolerances are stated per check."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from fatezero_amd import kernels as K
+
+
+def _frame_indices(index_list, clip):
+    out = []
+    for index in index_list:
+        if isinstance(index, str):
+            fr = {"first": 0, "last": clip - 1, "mid": (clip - 1) // 2}[index]
+            out.append([fr] * clip)
+        else:
+            out.append([min(max(f + index, 0), clip - 1) for f in range(clip)])
+    return out
+
+
+def ref_self_attention(q, k, v, heads, clip, index_list):
+    """fp32 restatement of spatial_temporal_forward + _attention (attention_register.py:131-218, :23-59).
+    q,k,v: [N, L, C] float. Returns (O [N,L,C], P [N,heads,L,Lk])."""
+    n, l, c = q.shape
+    b = n // clip
+    d = c // heads
+    idx = _frame_indices(index_list, clip)
+    if idx:
+        k5, v5 = k.reshape(b, clip, l, c), v.reshape(b, clip, l, c)
+        k = torch.cat([k5[:, fi] for fi in idx], dim=2).reshape(n, -1, c)
+        v = torch.cat([v5[:, fi] for fi in idx], dim=2).reshape(n, -1, c)
+    qh = q.reshape(n, l, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(n, -1, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(n, -1, heads, d).permute(0, 2, 1, 3)
+    p = (qh @ kh.transpose(-1, -2) * d ** -0.5).softmax(-1)
+    return p, vh
+
+
+def _mk(shape, g, device, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).half().to(device)
+
+
+def _vt(v, lp):
+    return K.transpose_pad(v, lp)
+
+
+def case_attn_self(device, *, batch, clip, heads, d, lq, index_list, mode, mask_kind=None, seed=0, qk_scale=1.5):
+    g = torch.Generator().manual_seed(seed)
+    n, c = batch * clip, heads * d
+    q = _mk((n, lq, c), g, device, qk_scale)
+    k = _mk((n, lq, c), g, device, qk_scale)
+    v = _mk((n, lq, c), g, device)
+    n_kv = max(1, len(index_list))
+    lk = n_kv * lq
+    vt = _vt(v, K.pad64(lq))
+    out = torch.full((n, lq, c), float("nan"), dtype=torch.float16, device=device)
+    p_ref, vh = ref_self_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, clip, index_list)
+    res = {}
+    if mode == K.FZ_ATTN_FLASH:
+        K.attn_self(q, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=mode)
+        o_ref = (p_ref @ vh).permute(0, 2, 1, 3).reshape(n, lq, c)
+    elif mode == K.FZ_ATTN_CAPTURE:
+        p = torch.full((n, heads, lq, lk), float("nan"), dtype=torch.float16, device=device)
+        K.attn_self(q, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=mode, p=p)
+        # the reference casts P to fp16 before P.V (attention_register.py:45,55)
+        o_ref = (p_ref.half().float() @ vh).permute(0, 2, 1, 3).reshape(n, lq, c)
+        pe = (p.float().cpu() - p_ref).abs()
+        # stored P: within 1 fp16 ulp of the fp32 softmax cast to fp16 (+ fast-exp slack)
+        ulp = torch.maximum(p_ref.abs() * 2.0 ** -10, torch.full_like(p_ref, 2.0 ** -24))
+        res["p_max_err_ulps"] = float((pe / ulp).max())
+        assert torch.isfinite(p.float()).all()
+        assert float((pe / ulp).max()) <= 1.6, float((pe / ulp).max())
+        rows = p.float().sum(-1)
+        assert float((rows - 1).abs().max()) < 3e-3
+    else:  # INJECT: frames of the second batch half take stored maps (cond half of the CFG batch)
+        fcond = clip
+        base = torch.rand(clip, heads, lq, lk, generator=g).softmax(-1).half().to(device)
+        mask = None
+        if mask_kind == "random":
+            mask = (torch.rand(clip, lq, generator=g) > 0.5).float().to(device)
+        elif mask_kind == "rows":
+            mask = torch.zeros(clip, lq)
+            mask[:, : lq // 3] = 1.0
+            mask = mask.to(device)
+        K.attn_self(q, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=K.FZ_ATTN_FLASH,
+                    frame0=0, n_frames=n - fcond)
+        K.attn_self(q, (k if mask is not None else None), vt, out, clip_len=clip, heads=heads, index_list=index_list,
+                    mode=mode, frame0=n - fcond, n_frames=fcond, p=base, row_mask=mask)
+        p_new = p_ref.clone()
+        bs = base.float().cpu()
+        if mask is None:
+            p_new[n - fcond:] = bs
+        else:
+            m = mask.cpu()[:, None, :, None]
+            p_new[n - fcond:] = m * p_ref[n - fcond:] + (1 - m) * bs  # attention_util.py:87
+        o_ref = (p_new @ vh).permute(0, 2, 1, 3).reshape(n, lq, c)
+    err = (out.float().cpu() - o_ref).abs().max().item()
+    res["o_max_err"] = err
+    assert torch.isfinite(out.float()).all(), "non-finite output"
+    assert err < 4e-3 * max(1.0, float(o_ref.abs().max())), err  # fp16 output of an fp32-accumulated product
+    return res
+
+
+def ref_cross_fuse(base, cur, mapper, coef_a, coef_b):
+    """new = (base @ M) * A + cur * B with base/cur [F,h,L,77], mapper [77,77]."""
+    return (base @ mapper) * coef_a + cur * coef_b
+
+
+def case_attn_cross(device, *, batch, clip, heads, d, lq, mode, seed=0, lk=77):
+    g = torch.Generator().manual_seed(seed)
+    n, c = batch * clip, heads * d
+    q = _mk((n, lq, c), g, device, 1.5)
+    k = _mk((batch, lk, c), g, device, 1.5)
+    v = _mk((batch, lk, c), g, device)
+    vt = K.transpose_pad(v, K.CROSS_KEYS)
+    out = torch.full((n, lq, c), float("nan"), dtype=torch.float16, device=device)
+    qf, kf, vf = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    qh = qf.reshape(n, lq, heads, d).permute(0, 2, 1, 3)
+    kh = kf.repeat_interleave(clip, 0).reshape(n, lk, heads, d).permute(0, 2, 1, 3)
+    vh = vf.repeat_interleave(clip, 0).reshape(n, lk, heads, d).permute(0, 2, 1, 3)
+    p_ref = (qh @ kh.transpose(-1, -2) * d ** -0.5).softmax(-1)
+    res = {}
+    if mode == K.FZ_ATTN_FLASH:
+        K.attn_cross(q, k, vt, out, clip_len=clip, heads=heads, lk=lk, mode=mode)
+        o_ref = (p_ref.half().float() @ vh)
+    elif mode == K.FZ_ATTN_CAPTURE:
+        p = torch.full((n, heads, lq, K.CROSS_P_STRIDE), float("nan"), dtype=torch.float16, device=device)
+        K.attn_cross(q, k, vt, out, clip_len=clip, heads=heads, lk=lk, mode=mode, p=p)
+        o_ref = (p_ref.half().float() @ vh)
+        pc = p.float().cpu()
+        assert (pc[..., lk:] == 0).all(), "pad columns must be zero"
+        ulp = torch.maximum(p_ref.abs() * 2.0 ** -10, torch.full_like(p_ref, 2.0 ** -24))
+        res["p_max_err_ulps"] = float(((pc[..., :lk] - p_ref).abs() / ulp).max())
+        assert res["p_max_err_ulps"] <= 1.6
+    else:
+        fcond = clip
+        base = torch.zeros(clip, heads, lq, K.CROSS_P_STRIDE)
+        base[..., :lk] = torch.rand(clip, heads, lq, lk, generator=g).softmax(-1)
+        base = base.half().to(device)
+        mapper = torch.zeros(lk, lk)
+        perm = torch.randperm(lk, generator=g)
+        mapper[torch.arange(lk), perm] = 1.0
+        mapper[3, :] = 0
+        mapper[3, 5] = 0.5
+        mapper[3, 6] = 0.5
+        coef = torch.zeros(2, K.CROSS_KEYS)
+        coef[0, :lk] = (torch.rand(lk, generator=g) > 0.4).float() * torch.tensor([1.0, 10.0])[torch.randint(0, 2, (lk,), generator=g)]
+        coef[1, :lk] = 1.0 - (coef[0, :lk] > 0).float() * 0.75
+        mt = torch.zeros(K.CROSS_KEYS, K.CROSS_KEYS)
+        mt[:lk, :lk] = mapper.t()
+        cur_out = torch.full((clip, heads, lq, K.CROSS_P_STRIDE), float("nan"), dtype=torch.float16, device=device)
+        K.attn_cross(q, k, vt, out, clip_len=clip, heads=heads, lk=lk, mode=K.FZ_ATTN_FLASH, frame0=0, n_frames=n - fcond)
+        K.attn_cross(q, k, vt, out, clip_len=clip, heads=heads, lk=lk, mode=mode, frame0=n - fcond, n_frames=fcond,
+                     p=base, mapper_t=mt.half().to(device), coef=coef.to(device), cur_out=cur_out)
+        p_new = p_ref.clone()
+        p_new[n - fcond:] = ref_cross_fuse(base.float().cpu()[..., :lk], p_ref[n - fcond:], mapper, coef[0, :lk], coef[1, :lk])
+        o_ref = p_new.half().float() @ vh
+        cc = cur_out.float().cpu()
+        ulp = torch.maximum(p_ref[n - fcond:].abs() * 2.0 ** -10, torch.full_like(p_ref[n - fcond:], 2.0 ** -24))
+        assert float(((cc[..., :lk] - p_ref[n - fcond:]).abs() / ulp).max()) <= 1.6
+    o_ref = o_ref.permute(0, 2, 1, 3).reshape(n, lq, c)
+    err = (out.float().cpu() - o_ref).abs().max().item()
+    res["o_max_err"] = err
+    assert torch.isfinite(out.float()).all()
+    assert err < 6e-3 * max(1.0, float(o_ref.abs().max())), err
+    return res
+
+
+def case_attn_temporal(device, *, batch, clip, heads, d, tokens, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    c = heads * d
+    qkv = _mk((batch * clip, tokens, 3 * c), g, device)
+    q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+    out = torch.full((batch * clip, tokens, c), float("nan"), dtype=torch.float16, device=device)
+    K.attn_temporal(q, k, v, out, batch=batch, clip_len=clip, heads=heads)
+
+    def r(t):  # '(b f) d c -> (b d) f c' then heads
+        t = t.float().cpu().reshape(batch, clip, tokens, heads, d).permute(0, 2, 3, 1, 4)
+        return t  # [b, tok, h, f, d]
+    qh, kh, vh = r(q), r(k), r(v)
+    p = (qh @ kh.transpose(-1, -2) * d ** -0.5).softmax(-1).half().float()
+    o = (p @ vh).permute(0, 3, 1, 2, 4).reshape(batch * clip, tokens, c)
+    err = (out.float().cpu() - o).abs().max().item()
+    assert err < 4e-3 * max(1.0, float(o.abs().max())), err
+    return {"o_max_err": err}
+
+
+def case_groupnorm(device, *, n, span, tokens, c, groups, silu, eps=1e-5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = ((torch.randn(n, tokens, c, generator=g) * 2 + torch.randn(1, 1, c, generator=g) * 3).half()).to(device)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).half().to(device)
+    beta = (0.3 * torch.randn(c, generator=g)).half().to(device)
+    y = K.groupnorm(x, gamma, beta, span=span, groups=groups, eps=eps, silu=silu)
+    xr = x.float().cpu().reshape(n // span, span * tokens, c).permute(0, 2, 1)  # [b, C, f*tok]
+    yr = F.group_norm(xr, groups, gamma.float().cpu(), beta.float().cpu(), eps)
+    if silu:
+        yr = F.silu(yr)
+    yr = yr.permute(0, 2, 1).reshape(n, tokens, c)
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert err < 2e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err}
+
+
+def case_layernorm(device, *, rows, c, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(rows, c, generator=g) * 2 + 1).half().to(device)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).half().to(device)
+    beta = (0.3 * torch.randn(c, generator=g)).half().to(device)
+    y = K.layernorm(x, gamma, beta)
+    yr = F.layer_norm(x.float().cpu(), (c,), gamma.float().cpu(), beta.float().cpu())
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert err < 2e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err}
+
+
+def case_geglu(device, *, rows, inner, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(rows, 2 * inner, generator=g) * 2).half().to(device)
+    y = K.geglu(x)
+    xf = x.float().cpu()
+    yr = xf[:, :inner] * F.gelu(xf[:, inner:])
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert err < 2e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err}
+
+
+def case_transpose_pad(device, *, n, l, c, lp, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, l, 2 * c, generator=g).half().to(device)[..., c:]  # strided view
+    y = K.transpose_pad(x, lp)
+    yr = torch.zeros(n, c, lp)
+    yr[:, :, :l] = x.float().cpu().transpose(1, 2)
+    assert torch.equal(y.float().cpu(), yr)
+    return {}
+
+
+def case_latent_update(device, *, frames, hw, blend, cfg, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(4, frames, hw, generator=g)
+    eu = torch.randn(frames, hw, 4, generator=g).half()
+    ec = torch.randn(frames, hw, 4, generator=g).half()
+    inv = torch.randn(4, frames, hw, generator=g)
+    mask = (torch.rand(frames, hw, generator=g) > 0.5).float()
+    cz, ce, gs = 1.0123, -0.0456, 7.5
+    zd = z.clone().to(device)
+    nxt = torch.empty(frames, hw, 4, dtype=torch.float16, device=device)
+    K.latent_update(zd, eu.to(device) if cfg else None, ec.to(device), gs, cz, ce,
+                    inv=inv.to(device) if blend else None, mask=mask.to(device) if blend else None, next_in=nxt)
+    e = ec.float().permute(2, 0, 1)
+    if cfg:
+        e = eu.float().permute(2, 0, 1) + gs * (ec.float().permute(2, 0, 1) - eu.float().permute(2, 0, 1))
+    zr = cz * z + ce * e
+    if blend:
+        zr = inv + mask[None] * (zr - inv)
+    assert (zd.cpu() - zr).abs().max() < 1e-5
+    assert (nxt.float().cpu().permute(2, 0, 1) - zr).abs().max() < 2e-3 * max(1.0, float(zr.abs().max()))
+    return {}
+
+
+def ref_blend_mask(maps, alpha, th, h, w, or_first):
+    """spatial_blend.py:24-56 in fp32 torch. maps: list of [P,F,heads,r*r,77] float."""
+    rr = []
+    for item in maps:
+        p, c, heads, r2, wd = item.shape
+        res = int(r2 ** 0.5)
+        rr.append(item.reshape(p, c, heads, res, res, wd).permute(0, 2, 1, 3, 4, 5))
+    m = torch.cat(rr, dim=1)
+    m = (m * alpha[:, None, None, None, None, :]).sum(-1).mean(1)
+    m = F.max_pool2d(m, (3, 3), (1, 1), padding=(1, 1))
+    mask = F.interpolate(m, size=(h, w))
+    mask = mask / mask.max(-2, keepdim=True)[0].max(-1, keepdim=True)[0]
+    mask = mask.gt(th)
+    if or_first:
+        mask = mask[:1] + mask
+    return mask
+
+
+def blob_maps(P_, F_, heads, res, g, lk=77, n_maps=5):
+    """Structured cross-attention-like maps (Gaussian blobs per token) so masks are not degenerate."""
+    out = []
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    for _ in range(n_maps):
+        cx = torch.rand(P_, F_, 1, 1, lk, generator=g) * res
+        cy = torch.rand(P_, F_, 1, 1, lk, generator=g) * res
+        d2 = (xx.reshape(1, 1, 1, res * res, 1) - cx) ** 2 + (yy.reshape(1, 1, 1, res * res, 1) - cy) ** 2
+        logits = torch.randn(P_, F_, heads, res * res, lk, generator=g) * 0.5 - d2 / (2 * (res / 4) ** 2)
+        out.append(logits.softmax(-1))
+    return out
+
+
+def case_blend_mask(device, *, prompts, frames, heads, res, out_hw, or_first, th=0.3, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    maps32 = blob_maps(prompts, frames, heads, res, g)
+    dev_maps = []
+    for m in maps32:
+        buf = torch.zeros(prompts, frames, heads, res * res, K.CROSS_P_STRIDE, dtype=torch.float16)
+        buf[..., :77] = m.half()
+        dev_maps.append(buf.to(device))
+    alpha = torch.zeros(prompts, 80)
+    alpha[:, [2, 3]] = 1.0
+    out = K.blend_mask(dev_maps, alpha.to(device), th, out_hw, or_with_first=or_first)
+    ref = ref_blend_mask([b.float().cpu()[..., :77] for b in dev_maps], alpha[:, :77], th, out_hw[0], out_hw[1], or_first)
+    diff = int((out.cpu().bool() != ref).sum())
+    frac = float(ref.float().mean())
+    assert 0.02 < frac < 0.98, f"degenerate mask ({frac})"
+    assert diff == 0, f"{diff} differing mask elements"
+    return {"ones": frac}

@@ -1,0 +1,82 @@
+"""Kernel index math / fragment layouts / masking checked WITHOUT a GPU: the kernel sources are compiled against the
+CPU emulation of csrc/fz_rt.h (libfatezero_emu.so) and run on small shapes.  This is test infrastructure -- the product
+only ever loads libfatezero_hip.so; the MI355X versions of these checks live in tests/test_kernels_gpu.py."""
+import pytest
+import torch
+
+from fatezero_amd import _native, build
+from fatezero_amd import kernels as K
+
+import kernel_cases as KC
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_backend():
+    _native.use_test_backend(build.build_emu())
+    yield
+    _native.reset_backend()
+
+
+DEV = "cpu"
+
+
+@pytest.mark.parametrize("d", [16, 40, 80, 160])
+def test_self_flash(d):
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=d, lq=64, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH)
+
+
+def test_self_flash_multi_tile_and_masking():
+    # lq=200: partial query block, key padding inside every kv slot (200 -> 256), three kv slots
+    KC.case_attn_self(DEV, batch=1, clip=3, heads=1, d=32, lq=200, index_list=[-1, "mid", 1], mode=K.FZ_ATTN_FLASH)
+
+
+def test_self_own_frame_only():
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=64, lq=64, index_list=[], mode=K.FZ_ATTN_FLASH)
+
+
+@pytest.mark.parametrize("d,lq", [(40, 64), (80, 144), (160, 36)])
+def test_self_capture(d, lq):
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=d, lq=lq, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE)
+
+
+@pytest.mark.parametrize("mask_kind", [None, "random", "rows"])
+def test_self_inject(mask_kind):
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=40, lq=64, index_list=["mid"], mode=K.FZ_ATTN_INJECT,
+                      mask_kind=mask_kind)
+
+
+def test_self_inject_unaligned():
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=1, d=32, lq=81, index_list=[-1, "first"], mode=K.FZ_ATTN_INJECT,
+                      mask_kind="random")
+
+
+@pytest.mark.parametrize("mode", [K.FZ_ATTN_FLASH, K.FZ_ATTN_CAPTURE, K.FZ_ATTN_INJECT])
+@pytest.mark.parametrize("d", [40, 160])
+def test_cross(mode, d):
+    KC.case_attn_cross(DEV, batch=2, clip=2, heads=2, d=d, lq=80, mode=mode)
+
+
+def test_temporal():
+    KC.case_attn_temporal(DEV, batch=2, clip=3, heads=2, d=40, tokens=10)
+
+
+@pytest.mark.parametrize("span,c,groups", [(2, 80, 16), (1, 64, 8), (3, 320, 32)])
+def test_groupnorm(span, c, groups):
+    KC.case_groupnorm(DEV, n=span * 2, span=span, tokens=100, c=c, groups=groups, silu=True)
+    KC.case_groupnorm(DEV, n=span, span=span, tokens=37, c=c, groups=groups, silu=False, eps=1e-6)
+
+
+def test_layernorm_geglu_transpose_latent():
+    KC.case_layernorm(DEV, rows=11, c=320)
+    KC.case_layernorm(DEV, rows=5, c=1280)
+    KC.case_geglu(DEV, rows=7, inner=128)
+    KC.case_transpose_pad(DEV, n=2, l=77, c=80, lp=96)
+    KC.case_transpose_pad(DEV, n=1, l=100, c=40, lp=128)
+    KC.case_latent_update(DEV, frames=2, hw=64, blend=False, cfg=False)
+    KC.case_latent_update(DEV, frames=3, hw=100, blend=True, cfg=True)
+
+
+@pytest.mark.parametrize("res,out_hw,prompts,or_first", [(16, (32, 32), 1, False), (16, (8, 8), 1, False),
+                                                         (16, (64, 64), 2, True), (18, (36, 36), 1, False)])
+def test_blend_mask_bit_exact(res, out_hw, prompts, or_first):
+    KC.case_blend_mask(DEV, prompts=prompts, frames=2, heads=2, res=res, out_hw=out_hw, or_first=or_first)

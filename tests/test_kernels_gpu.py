@@ -1,0 +1,87 @@
+"""MI355X parity of every HIP kernel, called through the C ABI (libfatezero_hip.so), against fp32 torch references
+(kernel_cases.py).  Shapes include the real SD-1.x levels at 512^2 (d = 40/80/160)."""
+import pytest
+import torch
+
+from fatezero_amd import _native
+from fatezero_amd import kernels as K
+
+import kernel_cases as KC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_backend():
+    _native.reset_backend()
+    assert "hip" in K.version()
+    assert _native.loaded_path().endswith("libfatezero_hip.so")
+    yield
+
+
+@pytest.mark.parametrize("d", [16, 32, 40, 64, 80, 128, 160])
+def test_self_flash_all_head_dims(d):
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=d, lq=256, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH)
+
+
+def test_self_flash_sd_level_64():
+    # the 64x64 level of SD-1.x at 512^2: Lq 4096, Lk 8192, d 40 (reduced to 2 frames x 2 heads for the CPU reference)
+    r = KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=4096, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH)
+    print("flash 64^2", r)
+
+
+def test_self_flash_masking_and_slots():
+    KC.case_attn_self(DEV, batch=1, clip=3, heads=1, d=32, lq=200, index_list=[-1, "mid", 1], mode=K.FZ_ATTN_FLASH)
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=8, d=64, lq=64, index_list=[], mode=K.FZ_ATTN_FLASH)
+    KC.case_attn_self(DEV, batch=1, clip=4, heads=8, d=40, lq=1296, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH)
+
+
+@pytest.mark.parametrize("d,lq", [(80, 1024), (160, 256), (160, 64), (40, 324), (160, 81)])
+def test_self_capture(d, lq):
+    r = KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=d, lq=lq, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE)
+    print("capture", d, lq, r)
+
+
+@pytest.mark.parametrize("mask_kind", [None, "random", "rows"])
+@pytest.mark.parametrize("d,lq", [(80, 1024), (160, 256), (32, 81)])
+def test_self_inject(mask_kind, d, lq):
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=d, lq=lq, index_list=[-1, "first"], mode=K.FZ_ATTN_INJECT,
+                      mask_kind=mask_kind)
+
+
+@pytest.mark.parametrize("mode", [K.FZ_ATTN_FLASH, K.FZ_ATTN_CAPTURE, K.FZ_ATTN_INJECT])
+@pytest.mark.parametrize("d,lq", [(40, 4096), (80, 1024), (160, 256), (160, 64), (16, 100)])
+def test_cross(mode, d, lq):
+    KC.case_attn_cross(DEV, batch=2, clip=2, heads=2, d=d, lq=lq, mode=mode)
+
+
+def test_temporal():
+    KC.case_attn_temporal(DEV, batch=2, clip=8, heads=8, d=40, tokens=300)
+    KC.case_attn_temporal(DEV, batch=1, clip=3, heads=2, d=160, tokens=17)
+
+
+@pytest.mark.parametrize("span,c,groups,tokens", [(8, 320, 32, 4096), (1, 640, 32, 1024), (4, 2560, 32, 64),
+                                                  (2, 1920, 32, 256), (2, 960, 32, 1000), (2, 80, 16, 100)])
+def test_groupnorm(span, c, groups, tokens):
+    KC.case_groupnorm(DEV, n=span * 2, span=span, tokens=tokens, c=c, groups=groups, silu=True)
+    KC.case_groupnorm(DEV, n=span, span=span, tokens=tokens, c=c, groups=groups, silu=False, eps=1e-6)
+
+
+def test_layernorm_geglu_transpose_latent():
+    KC.case_layernorm(DEV, rows=4099, c=320)
+    KC.case_layernorm(DEV, rows=513, c=1280)
+    KC.case_layernorm(DEV, rows=64, c=640)
+    KC.case_geglu(DEV, rows=1000, inner=1280)
+    KC.case_transpose_pad(DEV, n=2, l=77, c=320, lp=96)
+    KC.case_transpose_pad(DEV, n=3, l=1000, c=640, lp=1024)
+    KC.case_latent_update(DEV, frames=8, hw=4096, blend=False, cfg=False)
+    KC.case_latent_update(DEV, frames=8, hw=4096, blend=True, cfg=True)
+
+
+@pytest.mark.parametrize("res,out_hw,prompts,or_first", [(16, (32, 32), 1, False), (16, (16, 16), 1, False),
+                                                         (16, (8, 8), 1, False), (16, (64, 64), 2, True),
+                                                         (18, (36, 36), 1, False), (18, (9, 9), 1, False)])
+def test_blend_mask_bit_exact(res, out_hw, prompts, or_first):
+    for seed in range(4):
+        KC.case_blend_mask(DEV, prompts=prompts, frames=8, heads=8, res=res, out_hw=out_hw, or_first=or_first, seed=seed)
