@@ -1,0 +1,74 @@
+"""Temporal LoRA convolution (reference: video_diffusion/models/lora.py:22-54, LoRALinearLayer).
+
+x[(b h w), c, f] -> up(down(x)) + x with two bias-free Conv1d(k=3, pad=1) over the frame axis.  On token-major
+activations [B, F, HW, C] a k=3 temporal conv is three GEMMs over shifted frame views (zero padding at the clip
+ends), accumulated in place -- no '(b h w) c f' rearrange is materialised.  Parameter names/shapes are the
+reference's (`down.weight [r, C, 3]`, `up.weight [C, r, 3]`) so checkpoints load unchanged.
+"""
+import torch
+from torch import nn
+
+
+class _Conv1dParams(nn.Module):
+    def __init__(self, cin, cout, k, bias=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+
+def temporal_conv_tokens(x4, w_taps, bias=None, residual=None):
+    """x4: [B, F, T, Cin]; w_taps: [k, Cin, Cout] (tap-major, transposed for GEMM); zero padded 'same' conv over F.
+    Returns residual + conv(x) (+bias)."""
+    b, f, t, cin = x4.shape
+    k = w_taps.shape[0]
+    half = k // 2
+    cout = w_taps.shape[2]
+    x2 = x4.reshape(b, f * t, cin)
+    if residual is not None:
+        y = torch.baddbmm(residual.reshape(b, f * t, cout), x2, w_taps[half].expand(b, cin, cout))
+    else:
+        y = torch.matmul(x2, w_taps[half])
+    if bias is not None:
+        y = y + bias
+    y4 = y.view(b, f, t, cout)
+    for tap in range(k):
+        sh = tap - half  # output frame i takes input frame i + sh
+        if sh == 0 or abs(sh) >= f:
+            continue
+        if sh < 0:
+            src, dst = x4[:, : f + sh], y4[:, -sh:]
+        else:
+            src, dst = x4[:, sh:], y4[:, : f - sh]
+        n = src.shape[1] * t
+        dst2 = dst.reshape(b, n, cout)  # a view: frames are contiguous blocks
+        dst2.baddbmm_(src.reshape(b, n, cin), w_taps[tap].expand(b, cin, cout))
+    return y4
+
+
+class LoRALinearLayer(nn.Module):
+    def __init__(self, in_features, out_features, rank=4, stride=1):
+        super().__init__()
+        if rank > min(in_features, out_features):
+            rank = min(in_features, out_features) // 2  # lora.py:26-28
+        assert stride == 1, "temporal_downsample is not used by any shipped config (SURVEY §8a-12)"
+        self.down = _Conv1dParams(in_features, rank, 3)
+        self.up = _Conv1dParams(rank, out_features, 3)
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+        self._packed = None
+
+    def _pack(self, dtype, device):
+        if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
+            wd = self.down.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()  # [3, C, r]
+            wu = self.up.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()    # [3, r, C]
+            is_noop = bool((self.up.weight == 0).all())  # un-tuned SD: up == 0 -> exact identity
+            self._packed = (wd, wu, is_noop)
+        return self._packed
+
+    def forward_tokens(self, x4):
+        """x4: [B, F, T, C] -> same shape."""
+        wd, wu, is_noop = self._pack(x4.dtype, x4.device)
+        if is_noop:
+            return x4
+        d = temporal_conv_tokens(x4, wd)
+        return temporal_conv_tokens(d, wu, residual=x4)

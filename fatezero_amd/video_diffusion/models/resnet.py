@@ -1,0 +1,210 @@
+"""Pseudo-3D convolution and ResNet blocks (reference: video_diffusion/models/resnet.py).
+
+Token-major fp16 engine: x is [N = B*F, H*W, C].  GroupNorm(+SiLU) is the HIP kernel (statistics span all F
+frames of a batch element, exactly like torch.nn.GroupNorm on the reference's 5-D [b,c,f,h,w] input,
+resnet.py:338,369); the 3x3 convolution currently runs through MIOpen on a channels-last *view* of the same
+buffer (no layout copies); the temporal conv is GEMMs over shifted frame views (lora.py).
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import kernels as K
+from .lora import LoRALinearLayer, _Conv1dParams, temporal_conv_tokens
+
+
+class Tokens:
+    """A token-major activation: data [N, H*W, C] fp16 plus its frame geometry."""
+    __slots__ = ("data", "b", "f", "h", "w")
+
+    def __init__(self, data, b, f, h, w):
+        self.data, self.b, self.f, self.h, self.w = data, b, f, h, w
+
+    @property
+    def c(self):
+        return self.data.shape[-1]
+
+    def like(self, data, h=None, w=None):
+        return Tokens(data, self.b, self.f, self.h if h is None else h, self.w if w is None else w)
+
+    @staticmethod
+    def from_bcfhw(x):
+        b, c, f, h, w = x.shape
+        return Tokens(x.permute(0, 2, 3, 4, 1).reshape(b * f, h * w, c).contiguous(), b, f, h, w)
+
+    def to_bcfhw(self):
+        return self.data.view(self.b, self.f, self.h, self.w, self.c).permute(0, 4, 1, 2, 3)
+
+
+class PseudoConv3d(nn.Module):
+    """resnet.py:12-80. Parameters: weight/bias as nn.Conv2d, `conv_temporal` as in the reference."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, temporal_kernel_size=None, model_config: dict = {},
+                 temporal_downsample=False, stride=1, padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride = stride
+        self.padding = padding[0] if isinstance(padding, (tuple, list)) else padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if temporal_kernel_size is None:
+            temporal_kernel_size = kernel_size
+        assert not temporal_downsample, "temporal_downsample is not used by any shipped config"
+        if kernel_size > 1:
+            if "lora" in model_config:
+                self.conv_temporal = LoRALinearLayer(out_channels, out_channels, rank=model_config["lora"])
+            else:  # plain temporal Conv1d initialised to identity (resnet.py:42-55)
+                self.conv_temporal = _Conv1dParams(out_channels, out_channels, temporal_kernel_size, bias=True)
+                nn.init.dirac_(self.conv_temporal.weight.data)
+        else:
+            self.conv_temporal = None
+        self._packed = None
+
+    def _pack(self, dtype, device):
+        if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
+            w = self.weight.detach().to(device=device, dtype=dtype)
+            if self.kernel_size == 1:
+                w = w.reshape(self.out_channels, self.in_channels).contiguous()
+            else:
+                w = w.contiguous(memory_format=torch.channels_last)
+            bias = self.bias.detach().to(device=device, dtype=dtype)
+            wt = bt = None
+            if self.conv_temporal is not None and not isinstance(self.conv_temporal, LoRALinearLayer):
+                wt = self.conv_temporal.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
+                bt = self.conv_temporal.bias.detach().to(device=device, dtype=dtype)
+            self._packed = (w, bias, wt, bt)
+        return self._packed
+
+    def forward_tokens(self, x: Tokens, residual=None) -> Tokens:
+        w, bias, wt, bt = self._pack(x.data.dtype, x.data.device)
+        n, hw, c = x.data.shape
+        if self.kernel_size == 1:
+            y = F.linear(x.data, w, bias)
+            oh, ow = x.h, x.w
+        else:
+            xi = x.data.view(n, x.h, x.w, c).permute(0, 3, 1, 2)  # NCHW view of NHWC memory (channels_last)
+            yo = F.conv2d(xi, w, bias, stride=self.stride, padding=self.padding)
+            oh, ow = yo.shape[2], yo.shape[3]
+            y = yo.permute(0, 2, 3, 1).reshape(n, oh * ow, self.out_channels)
+        if self.conv_temporal is not None:
+            y4 = y.view(x.b, x.f, oh * ow, self.out_channels)
+            if isinstance(self.conv_temporal, LoRALinearLayer):
+                y4 = self.conv_temporal.forward_tokens(y4)
+            else:
+                y4 = temporal_conv_tokens(y4, wt, bias=bt)
+            y = y4.reshape(n, oh * ow, self.out_channels)
+        if residual is not None:
+            y = y + residual
+        return x.like(y, oh, ow)
+
+
+class _NormParams(nn.Module):
+    """Holds GroupNorm / LayerNorm affine parameters under the reference's names."""
+
+    def __init__(self, channels, groups=None, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.num_groups, self.eps = groups, eps
+        self._packed = None
+
+    def packed(self, device):
+        if self._packed is None or self._packed[0].device != device:
+            self._packed = (self.weight.detach().to(device=device, dtype=torch.float16).contiguous(),
+                            self.bias.detach().to(device=device, dtype=torch.float16).contiguous())
+        return self._packed
+
+
+def group_norm_tokens(norm: _NormParams, x: Tokens, *, span_frames: bool, silu: bool) -> Tokens:
+    g, b = norm.packed(x.data.device)
+    y = K.groupnorm(x.data, g, b, span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps, silu=silu)
+    return x.like(y)
+
+
+def upsample_nearest2x(x: Tokens) -> Tokens:
+    n, hw, c = x.data.shape
+    y = x.data.view(n, x.h, 1, x.w, 1, c).expand(n, x.h, 2, x.w, 2, c).reshape(n, 4 * hw, c)
+    return x.like(y, 2 * x.h, 2 * x.w)
+
+
+class UpsamplePseudo3D(nn.Module):
+    """resnet.py:83-175 (nearest 2x per frame, then conv3x3 + temporal)."""
+
+    def __init__(self, channels, use_conv=False, use_conv_transpose=False, out_channels=None, name="conv",
+                 model_config: dict = {}, **kwargs):
+        super().__init__()
+        assert use_conv and not use_conv_transpose
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.conv = PseudoConv3d(self.channels, self.out_channels, 3, padding=1, model_config=model_config)
+
+    def forward_tokens(self, x: Tokens) -> Tokens:
+        return self.conv.forward_tokens(upsample_nearest2x(x))
+
+
+class DownsamplePseudo3D(nn.Module):
+    """resnet.py:178-236 (stride-2 conv3x3 + temporal)."""
+
+    def __init__(self, channels, use_conv=False, out_channels=None, padding=1, model_config: dict = {}, name="conv"):
+        super().__init__()
+        assert use_conv and padding == 1
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.conv = PseudoConv3d(self.channels, self.out_channels, 3, stride=2, padding=padding, model_config=model_config)
+
+    def forward_tokens(self, x: Tokens) -> Tokens:
+        return self.conv.forward_tokens(x)
+
+
+class _LinearParams(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        self._packed = None
+
+    def packed(self, dtype, device):
+        if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
+            self._packed = (self.weight.detach().to(device=device, dtype=dtype).contiguous(),
+                            None if self.bias is None else self.bias.detach().to(device=device, dtype=dtype))
+        return self._packed
+
+    def apply(self, x):
+        w, b = self.packed(x.dtype, x.device)
+        return F.linear(x, w, b)
+
+
+class ResnetBlockPseudo3D(nn.Module):
+    """resnet.py:239-394 with time_embedding_norm='default', non_linearity swish, output_scale_factor 1."""
+
+    def __init__(self, *, in_channels, out_channels=None, temb_channels=512, groups=32, eps=1e-6,
+                 output_scale_factor=1.0, model_config: dict = {}, **unused):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.output_scale_factor = output_scale_factor
+        self.norm1 = _NormParams(in_channels, groups, eps)
+        self.conv1 = PseudoConv3d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, model_config=model_config)
+        self.time_emb_proj = _LinearParams(temb_channels, out_channels)
+        self.norm2 = _NormParams(out_channels, groups, eps)
+        self.conv2 = PseudoConv3d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, model_config=model_config)
+        self.conv_shortcut = None
+        if in_channels != out_channels:
+            self.conv_shortcut = PseudoConv3d(in_channels, out_channels, kernel_size=1, stride=1, padding=0,
+                                              model_config=model_config)
+
+    def forward_tokens(self, x: Tokens, temb_act) -> Tokens:
+        """temb_act = silu(temb) [B, temb_channels] fp16."""
+        h = group_norm_tokens(self.norm1, x, span_frames=True, silu=True)
+        h = self.conv1.forward_tokens(h)
+        t = self.time_emb_proj.apply(temb_act)  # [B, Cout]
+        hd = h.data.view(x.b, x.f * h.data.shape[1], self.out_channels)
+        hd += t[:, None, :]
+        h = group_norm_tokens(self.norm2, h, span_frames=True, silu=True)
+        skip = x if self.conv_shortcut is None else self.conv_shortcut.forward_tokens(x)
+        out = self.conv2.forward_tokens(h, residual=skip.data)
+        if self.output_scale_factor != 1.0:
+            out = out.like(out.data / self.output_scale_factor)
+        return out
