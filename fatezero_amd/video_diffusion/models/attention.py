@@ -1,0 +1,278 @@
+"""Spatio-temporal transformer (reference: video_diffusion/models/attention.py and the patched forwards of
+video_diffusion/prompt_attention/attention_register.py).
+
+Differences from the reference, by design:
+  * activations stay token-major [(b f), (h w), c] fp16 from proj_in to proj_out; the temporal attention reads
+    the same buffer with strides instead of rearranging '(b f) d c -> (b d) f c' (attention.py:327-337);
+  * the controller hook is not a tensor callback between softmax and P.V (attention_register.py:47-55) but an
+    `AttnPlan` the controller hands to the fused HIP kernels: which frames run plain flash attention, which
+    capture their probability map into the HBM arena, which take stored maps / masks / word mappers
+    (fatezero_amd/video_diffusion/prompt_attention/attention_store.py).  Foreign controllers that only implement
+    the reference's `__call__(attn, is_cross, place)` still work through a materialise-call-inject path;
+  * cross-attention K/V are projected once per batch element, not once per frame (the reference repeats the
+    text context F times before projecting, attention.py:104).
+"""
+import copy
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import kernels as K
+from .resnet import Tokens, _LinearParams, _NormParams, group_norm_tokens
+
+
+@dataclass
+class SpatioTemporalTransformerModelOutput:
+    sample: torch.Tensor
+
+
+class AttnPlan:
+    """What the attention kernels do for one controlled layer call.
+
+    Frames [0, n_plain) run plain flash attention; frames [n_plain, N) run `mode` with the given operands."""
+    __slots__ = ("n_plain", "mode", "p", "row_mask", "mapper_t", "coef", "cur_out", "capture_first")
+
+    def __init__(self, n_plain, mode=K.FZ_ATTN_FLASH, p=None, row_mask=None, mapper_t=None, coef=None, cur_out=None,
+                 capture_first=None):
+        self.n_plain, self.mode, self.p, self.row_mask = n_plain, mode, p, row_mask
+        self.mapper_t, self.coef, self.cur_out, self.capture_first = mapper_t, coef, cur_out, capture_first
+
+
+def _plan_for(controller, is_cross, place, n, clip, heads, lq, lk, device):
+    if controller is None:
+        return AttnPlan(n)
+    planner = getattr(controller, "attention_plan", None)
+    if planner is not None:
+        return planner(is_cross, place, n, clip, heads, lq, lk, device)
+    return None  # foreign controller: generic path
+
+
+class CrossAttention(nn.Module):
+    """Parameter container + executor for diffusers' CrossAttention as used by the reference (to_q/to_k/to_v without
+    bias, to_out = [Linear, Dropout]); head count = `heads`, scale = dim_head**-0.5."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False, **unused):
+        super().__init__()
+        inner = dim_head * heads
+        self.query_dim, self.inner_dim = query_dim, inner
+        self.is_cross_module = cross_attention_dim is not None
+        cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self.to_q = _LinearParams(query_dim, inner, bias=bias)
+        self.to_k = _LinearParams(cross_attention_dim, inner, bias=bias)
+        self.to_v = _LinearParams(cross_attention_dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([_LinearParams(inner, query_dim), nn.Identity()])
+        # set by register_attention_control
+        self.controller = None
+        self.place_in_unet = None
+        self._qk = None
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    def _qk_weight(self, dtype, device):
+        if self._qk is None or self._qk.dtype != dtype or self._qk.device != device:
+            self._qk = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], 0).to(device=device, dtype=dtype).contiguous()
+        return self._qk
+
+    def _generic_controller_call(self, controller, is_cross, q, k, vt, out, clip, lq, lk_total, run_capture, run_inject):
+        """Reference protocol for a controller that only has __call__: materialise P, call it, apply the result.
+        Like the reference with xformers enabled (attention_register.py:112-116,198-204) maps larger than 32x32
+        tokens bypass the controller."""
+        n = q.shape[0]
+        width = K.CROSS_P_STRIDE if is_cross else lk_total
+        p = torch.empty(n, self.heads, lq, width, dtype=torch.float16, device=q.device)
+        run_capture(p)
+        view = p[..., :lk_total] if is_cross else p
+        new = controller(view, is_cross, self.place_in_unet)
+        if new is not view:
+            view.copy_(new)
+        run_inject(p)
+
+    # -- cross attention (attention_register.py:71-128) ------------------------------------------------------
+    def forward_cross(self, x: Tokens, ctx, clip: int):
+        """x.data: LayerNorm'ed hidden states [N, L, C]; ctx: [B, 77, Dctx] fp16."""
+        n, lq, c = x.data.shape
+        q = self.to_q.apply(x.data)
+        kk = self.to_k.apply(ctx)
+        vt = K.transpose_pad(self.to_v.apply(ctx), K.CROSS_KEYS)
+        lk = ctx.shape[1]
+        out = torch.empty(n, lq, self.inner_dim, dtype=q.dtype, device=q.device)
+        kw = dict(clip_len=clip, heads=self.heads, lk=lk, scale=self.scale)
+        ctrl = self.controller
+        plan = _plan_for(ctrl, True, self.place_in_unet, n, clip, self.heads, lq, lk, q.device)
+        if plan is None:
+            if lq > 32 ** 2:
+                K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, **kw)
+            else:
+                ident = torch.eye(K.CROSS_KEYS, dtype=torch.float16, device=q.device)
+                coef = torch.zeros(2, K.CROSS_KEYS, dtype=torch.float32, device=q.device)
+                coef[0] = 1.0
+                self._generic_controller_call(
+                    ctrl, True, q, kk, vt, out, clip, lq, lk,
+                    lambda p: K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_CAPTURE, p=p, **kw),
+                    lambda p: K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_INJECT, p=p, mapper_t=ident, coef=coef, **kw))
+        else:
+            if plan.n_plain > 0:
+                K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, frame0=0, n_frames=plan.n_plain, **kw)
+            if plan.n_plain < n:
+                K.attn_cross(q, kk, vt, out, mode=plan.mode, frame0=plan.n_plain, n_frames=n - plan.n_plain, p=plan.p,
+                             mapper_t=plan.mapper_t, coef=plan.coef, cur_out=plan.cur_out, **kw)
+        return self.to_out[0].apply(out)
+
+    # -- temporal attention (attention.py:327-337; never controlled, attention_register.py:242) ---------------
+    def forward_temporal(self, x_norm, batch: int, clip: int):
+        """x_norm: [B*F, L, C] LayerNorm'ed; attention over the F frames of every (b, token)."""
+        n, l, c = x_norm.shape
+        w = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device), self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0) \
+            if getattr(self, "_qkv", None) is None else self._qkv
+        self._qkv = w
+        qkv = F.linear(x_norm, w)
+        inner = self.inner_dim
+        out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
+        K.attn_temporal(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], out, batch=batch, clip_len=clip,
+                        heads=self.heads, scale=self.scale)
+        return self.to_out[0].apply(out)
+
+    def load_state_dict(self, *a, **k):  # packed weights must follow the parameters
+        self._qk = None
+        self._qkv = None
+        return super().load_state_dict(*a, **k)
+
+
+class SparseCausalAttention(CrossAttention):
+    """attention.py:340-422 / attention_register.py:131-218: frame f attends the K/V of frames idx_j(f)."""
+
+    def forward_self(self, x: Tokens, clip: int, index_list):
+        n, lq, c = x.data.shape
+        xn = x.data
+        qk = F.linear(xn, self._qk_weight(xn.dtype, xn.device))
+        q, kk = qk[..., : self.inner_dim], qk[..., self.inner_dim:]
+        wv = self.to_v.packed(xn.dtype, xn.device)[0]
+        if lq % 64 == 0:
+            vt = torch.matmul(wv, xn.transpose(1, 2))  # V^T straight out of the projection GEMM: [N, C, L]
+        else:
+            vt = K.transpose_pad(F.linear(xn, wv), K.pad64(lq))
+        out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
+        n_kv = max(1, len(index_list))
+        kw = dict(clip_len=clip, heads=self.heads, index_list=index_list, scale=self.scale)
+        ctrl = self.controller
+        plan = _plan_for(ctrl, False, self.place_in_unet, n, clip, self.heads, lq, n_kv * lq, xn.device)
+        if plan is None:
+            if lq > 32 ** 2:
+                K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, **kw)
+            else:
+                self._generic_controller_call(
+                    ctrl, False, q, kk, vt, out, clip, lq, n_kv * lq,
+                    lambda p: K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_CAPTURE, p=p, **kw),
+                    lambda p: K.attn_self(q, None, vt, out, mode=K.FZ_ATTN_INJECT, p=p, **kw))
+        else:
+            if plan.n_plain > 0:
+                K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, frame0=0, n_frames=plan.n_plain, **kw)
+            if plan.n_plain < n:
+                rest = dict(frame0=plan.n_plain, n_frames=n - plan.n_plain)
+                if plan.capture_first is not None:  # edit pass with save_self_attention: keep the live map too
+                    K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_CAPTURE, p=plan.capture_first, **rest, **kw)
+                if plan.mode == K.FZ_ATTN_INJECT:
+                    K.attn_self(q, kk if plan.row_mask is not None else None, vt, out, mode=K.FZ_ATTN_INJECT, p=plan.p,
+                                row_mask=plan.row_mask, **rest, **kw)
+                elif not (plan.mode == K.FZ_ATTN_FLASH and plan.capture_first is not None):
+                    K.attn_self(q, kk, vt, out, mode=plan.mode, p=plan.p, **rest, **kw)
+        return self.to_out[0].apply(out)
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = _LinearParams(dim, inner * 2)
+
+
+class FeedForward(nn.Module):
+    """diffusers FeedForward(activation_fn='geglu') [3P]: net = [GEGLU(dim, 4 dim), Dropout, Linear(4 dim, dim)]."""
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([_GEGLU(dim, dim * mult), nn.Identity(), _LinearParams(dim * mult, dim)])
+
+    def apply(self, x):
+        return self.net[2].apply(K.geglu(self.net[0].proj.apply(x)))
+
+
+def layer_norm_tokens(norm: _NormParams, x):
+    g, b = norm.packed(x.device)
+    return K.layernorm(x, g, b, eps=norm.eps)
+
+
+class SpatioTemporalTransformerBlock(nn.Module):
+    """attention.py:147-337 with temporal_attention_position='after_feedforward' (the only one used)."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, cross_attention_dim=None, model_config: dict = {},
+                 **unused):
+        super().__init__()
+        self.model_config = copy.deepcopy(model_config)
+        if "least_sc_channel" in model_config and dim < model_config["least_sc_channel"]:
+            self.model_config["SparseCausalAttention_index"] = []  # attention.py:171-173
+        self.attn1 = SparseCausalAttention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim)
+        self.norm1 = _NormParams(dim)
+        self.attn2 = CrossAttention(query_dim=dim, cross_attention_dim=cross_attention_dim, heads=num_attention_heads,
+                                    dim_head=attention_head_dim)
+        self.norm2 = _NormParams(dim)
+        self.attn_temporal = CrossAttention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim)
+        nn.init.zeros_(self.attn_temporal.to_out[0].weight.data)  # attention.py:224 (the bias stays random!)
+        self.norm_temporal = _NormParams(dim)
+        self.ff = FeedForward(dim)
+        self.norm3 = _NormParams(dim)
+
+    @property
+    def sc_index(self):
+        return self.model_config.get("SparseCausalAttention_index", [-1, "first"])  # attention.py:347 default
+
+    def forward_tokens(self, x: Tokens, ctx):
+        hs = x.data
+        clip = x.f
+        hs = hs + self.attn1.forward_self(x.like(layer_norm_tokens(self.norm1, hs)), clip, self.sc_index)
+        hs = hs + self.attn2.forward_cross(x.like(layer_norm_tokens(self.norm2, hs)), ctx, clip)
+        hs = hs + self.ff.apply(layer_norm_tokens(self.norm3, hs))
+        hs = hs + self.attn_temporal.forward_temporal(layer_norm_tokens(self.norm_temporal, hs), x.b, clip)
+        return x.like(hs)
+
+
+class SpatioTemporalTransformerModel(nn.Module):
+    """attention.py:31-144: per-frame GroupNorm(eps 1e-6) -> 1x1 proj_in -> block -> 1x1 proj_out -> + residual."""
+
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, num_layers=1,
+                 norm_num_groups=32, cross_attention_dim=None, model_config: dict = {}, **unused):
+        super().__init__()
+        assert num_layers == 1
+        inner = num_attention_heads * attention_head_dim
+        self.norm = _NormParams(in_channels, norm_num_groups, 1e-6)
+        self.proj_in = _Conv1x1Params(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([SpatioTemporalTransformerBlock(
+            inner, num_attention_heads, attention_head_dim, cross_attention_dim=cross_attention_dim,
+            model_config=model_config)])
+        self.proj_out = _Conv1x1Params(inner, in_channels)
+
+    def forward_tokens(self, x: Tokens, ctx) -> Tokens:
+        h = group_norm_tokens(self.norm, x, span_frames=False, silu=False)
+        h = h.like(self.proj_in.apply(h.data))
+        h = self.transformer_blocks[0].forward_tokens(h, ctx)
+        return x.like(self.proj_out.apply(h.data) + x.data)
+
+
+class _Conv1x1Params(nn.Module):
+    """nn.Conv2d(k=1) parameters ([Cout, Cin, 1, 1]) applied as a GEMM on token-major data."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self._packed = None
+
+    def apply(self, x):
+        if self._packed is None or self._packed[0].dtype != x.dtype or self._packed[0].device != x.device:
+            self._packed = (self.weight.detach().reshape(self.weight.shape[0], -1).to(device=x.device, dtype=x.dtype).contiguous(),
+                            self.bias.detach().to(device=x.device, dtype=x.dtype))
+        return F.linear(x, *self._packed)

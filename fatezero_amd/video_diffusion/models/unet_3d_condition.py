@@ -1,0 +1,204 @@
+"""UNetPseudo3DConditionModel (reference: video_diffusion/models/unet_3d_condition.py), MI355X engine.
+
+Public surface kept: constructor kwargs, `from_2d_model`, `load_2d_state_dict`, `forward(sample, timestep,
+encoder_hidden_states).sample` on [B,4,F,H,W] latents, `.config`, state_dict key names.  Internally the forward
+runs on token-major fp16 activations (`forward_tokens`) so the DDIM loops never convert layouts.
+"""
+import glob
+import json
+import math
+import os
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .resnet import PseudoConv3d, Tokens, _LinearParams, _NormParams, group_norm_tokens
+from .unet_3d_blocks import UNetMidBlockPseudo3DCrossAttn, get_down_block, get_up_block
+
+
+@dataclass
+class UNetPseudo3DConditionOutput:
+    sample: torch.Tensor
+
+    def __getitem__(self, k):  # the reference indexes ["sample"] (p2p_ddim_spatial_temporal.py:142)
+        return getattr(self, k) if isinstance(k, str) else (self.sample,)[k]
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.linear_1 = _LinearParams(cin, cout)
+        self.linear_2 = _LinearParams(cout, cout)
+
+
+class UNetPseudo3DConditionModel(nn.Module):
+    def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
+                 center_input_sample: bool = False, flip_sin_to_cos: bool = True, freq_shift: int = 0,
+                 down_block_types: Tuple[str] = ("CrossAttnDownBlockPseudo3D", "CrossAttnDownBlockPseudo3D",
+                                                 "CrossAttnDownBlockPseudo3D", "DownBlockPseudo3D"),
+                 mid_block_type: str = "UNetMidBlockPseudo3DCrossAttn",
+                 up_block_types: Tuple[str] = ("UpBlockPseudo3D", "CrossAttnUpBlockPseudo3D", "CrossAttnUpBlockPseudo3D",
+                                               "CrossAttnUpBlockPseudo3D"),
+                 only_cross_attention=False, block_out_channels: Tuple[int] = (320, 640, 1280, 1280),
+                 layers_per_block: int = 2, downsample_padding: int = 1, mid_block_scale_factor: float = 1,
+                 act_fn: str = "silu", norm_num_groups: int = 32, norm_eps: float = 1e-5, cross_attention_dim: int = 1280,
+                 attention_head_dim: Union[int, Tuple[int]] = 8, dual_cross_attention: bool = False,
+                 use_linear_projection: bool = False, class_embed_type=None, num_class_embeds=None,
+                 upcast_attention: bool = False, resnet_time_scale_shift: str = "default", **kwargs):
+        super().__init__()
+        if (center_input_sample or not flip_sin_to_cos or freq_shift != 0 or dual_cross_attention or use_linear_projection
+                or class_embed_type is not None or num_class_embeds is not None or resnet_time_scale_shift != "default"
+                or act_fn not in ("silu", "swish") or kwargs.get("temporal_downsample") or kwargs.get("temporal_downsample_time", 0)):
+            raise NotImplementedError("only the SD-1.x configuration surface used by FateZero is implemented")
+        cfg = dict(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+                   down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+                   block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                   norm_num_groups=norm_num_groups, norm_eps=norm_eps, cross_attention_dim=cross_attention_dim,
+                   attention_head_dim=attention_head_dim, center_input_sample=False, **kwargs)
+        self.config = SimpleNamespace(**cfg)
+        self.sample_size = sample_size
+        model_config = dict(kwargs)
+        time_embed_dim = block_out_channels[0] * 4
+        self.conv_in = PseudoConv3d(in_channels, block_out_channels[0], kernel_size=3, padding=1, model_config=model_config)
+        self.time_embedding = _TimestepEmbedding(block_out_channels[0], time_embed_dim)
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * len(down_block_types)
+        self.down_blocks = nn.ModuleList()
+        out_c = block_out_channels[0]
+        for i, t in enumerate(down_block_types):
+            in_c, out_c = out_c, block_out_channels[i]
+            final = i == len(block_out_channels) - 1
+            self.down_blocks.append(get_down_block(
+                t, num_layers=layers_per_block, in_channels=in_c, out_channels=out_c, temb_channels=time_embed_dim,
+                add_downsample=not final, resnet_eps=norm_eps, resnet_groups=norm_num_groups,
+                cross_attention_dim=cross_attention_dim, attn_num_head_channels=attention_head_dim[i],
+                model_config=model_config))
+        assert mid_block_type == "UNetMidBlockPseudo3DCrossAttn"
+        self.mid_block = UNetMidBlockPseudo3DCrossAttn(
+            in_channels=block_out_channels[-1], temb_channels=time_embed_dim, resnet_eps=norm_eps,
+            output_scale_factor=mid_block_scale_factor, cross_attention_dim=cross_attention_dim,
+            attn_num_head_channels=attention_head_dim[-1], resnet_groups=norm_num_groups, model_config=model_config)
+        self.up_blocks = nn.ModuleList()
+        rev_c = list(reversed(block_out_channels))
+        rev_h = list(reversed(attention_head_dim))
+        out_c = rev_c[0]
+        self.num_upsamplers = 0
+        for i, t in enumerate(up_block_types):
+            final = i == len(block_out_channels) - 1
+            prev, out_c = out_c, rev_c[i]
+            in_c = rev_c[min(i + 1, len(block_out_channels) - 1)]
+            if not final:
+                self.num_upsamplers += 1
+            self.up_blocks.append(get_up_block(
+                t, num_layers=layers_per_block + 1, in_channels=in_c, out_channels=out_c, prev_output_channel=prev,
+                temb_channels=time_embed_dim, add_upsample=not final, resnet_eps=norm_eps, resnet_groups=norm_num_groups,
+                cross_attention_dim=cross_attention_dim, attn_num_head_channels=rev_h[i], model_config=model_config))
+        self.conv_norm_out = _NormParams(block_out_channels[0], norm_num_groups, norm_eps)
+        self.conv_out = PseudoConv3d(block_out_channels[0], out_channels, kernel_size=3, padding=1, model_config=model_config)
+
+    # ------------------------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def invalidate_packed(self):
+        for m in self.modules():
+            for a in ("_packed", "_qk", "_qkv"):
+                if hasattr(m, a):
+                    setattr(m, a, None)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_packed()
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
+    def time_embed(self, timestep, batch, device):
+        """Timesteps(C0, flip_sin_to_cos=True, shift 0) -> TimestepEmbedding [3P] (unet_3d_condition.py:338-362).
+        Returns silu(emb) in fp16: every consumer (ResnetBlock.time_emb_proj) applies the non-linearity first."""
+        c0 = self.config.block_out_channels[0]
+        half = c0 // 2
+        t = torch.as_tensor(timestep, dtype=torch.float32, device=device).reshape(-1).expand(batch)
+        freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=device) / half)
+        e = t[:, None] * freq[None]
+        e = torch.cat([torch.cos(e), torch.sin(e)], dim=-1).to(torch.float16)
+        e = self.time_embedding.linear_2.apply(F.silu(self.time_embedding.linear_1.apply(e)))
+        return F.silu(e)
+
+    def forward_tokens(self, x: Tokens, timestep, ctx) -> Tokens:
+        """x: latents as tokens [B*F, H*W, 4] fp16; ctx [B, 77, D] fp16 -> predicted noise, same layout."""
+        temb_act = self.time_embed(timestep, x.b, x.data.device)
+        ctx = ctx.to(torch.float16)
+        x = self.conv_in.forward_tokens(x)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk.forward_tokens(x, temb_act, ctx)
+            skips.extend(outs)
+        x = self.mid_block.forward_tokens(x, temb_act, ctx)
+        for blk in self.up_blocks:
+            x = blk.forward_tokens(x, skips, temb_act, ctx)
+        x = group_norm_tokens(self.conv_norm_out, x, span_frames=True, silu=True)
+        return self.conv_out.forward_tokens(x)
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                return_dict: bool = True):
+        if class_labels is not None or attention_mask is not None:
+            raise NotImplementedError
+        factor = 2 ** self.num_upsamplers
+        if any(s % factor != 0 for s in sample.shape[-2:]):
+            raise ValueError(f"latent height/width must be multiples of {factor}")
+        out_dtype = sample.dtype
+        y = self.forward_tokens(Tokens.from_bcfhw(sample.to(torch.float16)), timestep, encoder_hidden_states)
+        y = y.to_bcfhw().to(out_dtype)
+        return UNetPseudo3DConditionOutput(sample=y) if return_dict else (y,)
+
+    # ------------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_2d_model(cls, model_path, model_config):
+        """unet_3d_condition.py:449-483: read a diffusers 2-D UNet folder (config.json + first *.bin)."""
+        config_path = os.path.join(model_path, "config.json")
+        if not os.path.isfile(config_path):
+            raise RuntimeError(f"{config_path} does not exist")
+        with open(config_path, "r") as f:
+            config = json.load(f)
+        config.pop("_class_name")
+        config.pop("_diffusers_version")
+        rep = {"CrossAttnDownBlock2D": "CrossAttnDownBlockPseudo3D", "DownBlock2D": "DownBlockPseudo3D",
+               "UpBlock2D": "UpBlockPseudo3D", "CrossAttnUpBlock2D": "CrossAttnUpBlockPseudo3D"}
+        config["down_block_types"] = [rep.get(b, b) for b in config["down_block_types"]]
+        config["up_block_types"] = [rep.get(b, b) for b in config["up_block_types"]]
+        if model_config is not None:
+            config.update(model_config)
+        model = cls(**config)
+        cands = glob.glob(os.path.join(model_path, "*.bin"))
+        if cands:
+            model.load_2d_state_dict(state_dict=torch.load(cands[0], map_location="cpu"))
+        return model
+
+    def load_2d_state_dict(self, state_dict, **kwargs):
+        """unet_3d_condition.py:485-501: every 2-D key must exist with the same shape; every non-temporal 3-D key must
+        be provided."""
+        sd3 = self.state_dict()
+        for k, v in state_dict.items():
+            if k not in sd3:
+                raise KeyError(f"2d state_dict key {k} does not exist in 3d model")
+            if v.shape != sd3[k].shape:
+                raise ValueError(f"state_dict shape mismatch, 2d {v.shape}, 3d {sd3[k].shape}")
+        for k in sd3:
+            if "_temporal" in k:
+                continue
+            if k not in state_dict:
+                raise KeyError(f"3d state_dict key {k} does not exist in 2d model")
+        sd3.update(state_dict)
+        self.load_state_dict(sd3, **kwargs)
