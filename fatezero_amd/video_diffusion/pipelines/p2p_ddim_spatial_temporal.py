@@ -1,0 +1,245 @@
+"""FateZero editing pipeline (reference: video_diffusion/pipelines/p2p_ddim_spatial_temporal.py).
+
+`P2pDDIMSpatioTemporalPipeline` keeps the reference's constructor, attributes (`store_controller`,
+`empty_controller`, ...), methods and keyword arguments.  The two hot loops are re-built around the native engine:
+
+  * latents live in one fp32 buffer [4, F, h*w] plus an fp16 token-major copy [F(or 2F), h*w, 4] that is the UNet
+    input; one fused kernel per step does classifier-free guidance + the DDIM (or inverse DDIM) update + the
+    next UNet input (`fz_latent_update`), so no torch elementwise chain, no `torch.cat([latents] * 2)`, no
+    `torch.cuda.empty_cache()` (p2p_ddim_spatial_temporal.py:391-421) survives;
+  * the UNet is called through `forward_tokens` (no layout conversions inside the loop);
+  * capture / injection of attention maps happens inside the attention kernels according to the registered
+    controller's plan; maps never leave HBM.
+"""
+import os
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from ... import kernels as K
+from ..models.resnet import Tokens
+from ..prompt_attention import attention_util
+from .stable_diffusion import SpatioTemporalStableDiffusionPipeline, StableDiffusionPipelineOutput
+
+
+class _LatentState:
+    """fp32 master latents [4, F, hw] + the fp16 token-major UNet input [reps*F, hw, 4]."""
+
+    def __init__(self, latents: torch.Tensor, reps: int):
+        b, c, f, h, w = latents.shape
+        if b != 1:
+            raise ValueError("Only support single video editing")  # attention_util.py:192 of the reference
+        self.f, self.h, self.w, self.reps = f, h, w, reps
+        self.z = latents[0].float().reshape(c, f, h * w).contiguous()
+        self.tok = torch.empty(reps * f, h * w, c, dtype=torch.float16, device=latents.device)
+        self.sync_tokens()
+
+    def sync_tokens(self):
+        t = self.z.permute(1, 2, 0).to(torch.float16)
+        for r in range(self.reps):
+            self.tok[r * self.f:(r + 1) * self.f].copy_(t)
+
+    def tokens(self) -> Tokens:
+        return Tokens(self.tok, self.reps, self.f, self.h, self.w)
+
+    def as_latents(self, dtype) -> torch.Tensor:
+        return self.z.view(1, self.z.shape[0], self.f, self.h, self.w).to(dtype)
+
+    def assign(self, latents: torch.Tensor):
+        self.z.copy_(latents[0].float().reshape(self.z.shape))
+        self.sync_tokens()
+
+    def update(self, eps_u, eps_c, guidance, cz, ce):
+        K.latent_update(self.z, eps_u, eps_c, guidance, cz, ce, next_in=self.tok[: self.f])
+        for r in range(1, self.reps):
+            self.tok[r * self.f:(r + 1) * self.f].copy_(self.tok[: self.f])
+
+
+class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, disk_store: bool = False):
+        super().__init__(vae, text_encoder, tokenizer, unet, scheduler)
+        self.store_controller = attention_util.AttentionStore(disk_store=disk_store)
+        self.empty_controller = attention_util.EmptyControl()
+
+    def check_inputs(self, prompt, height, width, callback_steps, strength=None):
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if strength is not None and (strength <= 0 or strength > 1):
+            raise ValueError(f"The value of strength should in (0.0, 1.0] but is {strength}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type"
+                             f" {type(callback_steps)}.")
+
+    # ------------------------------------------------------------------------------------------------------
+    # inversion (p2p_ddim_spatial_temporal.py:69-148)
+    # ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prepare_latents_ddim_inverted(self, image, batch_size, num_images_per_prompt, text_embeddings,
+                                      store_attention=False, prompt=None, generator=None, LOW_RESOURCE=True,
+                                      save_path=None, latents=None):
+        """`latents` (extension): start from given clean latents [1,4,F,h,w] instead of VAE-encoding `image`."""
+        self.prepare_before_train_loop()
+        if store_attention:
+            attention_util.register_attention_control(self, self.store_controller)
+        resource_default_value = self.store_controller.LOW_RESOURCE
+        self.store_controller.LOW_RESOURCE = LOW_RESOURCE  # in inversion: no CFG, record every frame's attention
+        batch_size = batch_size * num_images_per_prompt
+        if latents is None:
+            if isinstance(generator, list) and len(generator) != batch_size:
+                raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                                 f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
+                                 "the generators.")
+            if isinstance(generator, list):
+                init = torch.cat([self.vae.encode(image[i:i + 1]).latent_dist.sample(generator[i]) for i in range(batch_size)], 0)
+            else:
+                init = self.vae.encode(image).latent_dist.sample(generator)
+            init = 0.18215 * init
+            if batch_size > init.shape[0] and batch_size % init.shape[0] != 0:
+                raise ValueError(f"Cannot duplicate `image` of batch size {init.shape[0]} to {batch_size} text prompts.")
+            if batch_size > init.shape[0]:
+                init = torch.cat([init] * (batch_size // init.shape[0]), dim=0)
+            bf, c, h, w = init.shape
+            latents = init.reshape(batch_size, bf // batch_size, c, h, w).permute(0, 2, 1, 3, 4)  # (b f) c h w -> b c f h w
+        self.store_controller.expected_steps = len(self.scheduler.timesteps) if store_attention else None
+        ddim_latents_all_step = self.ddim_clean2noisy_loop(latents, text_embeddings, self.store_controller)
+        if store_attention and (save_path is not None):
+            os.makedirs(save_path + "/cross_attention", exist_ok=True)
+            attention_util.show_cross_attention(self.tokenizer, prompt, self.store_controller, 16, ["up", "down"],
+                                                save_path=save_path + "/cross_attention")
+            attention_util.register_attention_control(self, self.empty_controller)  # detach the controller for safety
+        self.store_controller.LOW_RESOURCE = resource_default_value
+        return ddim_latents_all_step
+
+    @torch.no_grad()
+    def ddim_clean2noisy_loop(self, latent, text_embeddings, controller=None):
+        weight_dtype = latent.dtype
+        uncond_embeddings, cond_embeddings = text_embeddings.chunk(2)
+        all_latent = [latent]
+        state = _LatentState(latent.detach(), reps=1)
+        cond = cond_embeddings.to(torch.float16)
+        timesteps = self.scheduler.timesteps
+        for i in self.progress_bar(range(len(timesteps))):
+            t = int(timesteps[len(timesteps) - i - 1])
+            eps = self.unet.forward_tokens(state.tokens(), t, cond)
+            cz, ce = self.scheduler.inverse_step_coefficients(t)
+            state.update(None, eps.data, 0.0, cz, ce)
+            cur = state.as_latents(weight_dtype).clone()
+            if controller is not None:
+                controller.step_callback(cur)
+            all_latent.append(cur)
+        return all_latent
+
+    def next_clean2noise_step(self, model_output, timestep: int, sample):
+        """Tensor form of the inverse DDIM step (p2p_ddim_spatial_temporal.py:150-161), eta = 0."""
+        cz, ce = self.scheduler.inverse_step_coefficients(timestep)
+        return cz * sample + ce * model_output
+
+    def get_timesteps(self, num_inference_steps, strength, device):
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start:], num_inference_steps - t_start
+
+    # ------------------------------------------------------------------------------------------------------
+    # editing (p2p_ddim_spatial_temporal.py:172-259)
+    # ------------------------------------------------------------------------------------------------------
+    def p2preplace_edit(self, **kwargs):
+        len_source = len(kwargs["source_prompt"].split(" "))
+        len_target = len(kwargs["prompt"].split(" "))
+        equal_length = (len_source == len_target)
+        edit_controller = attention_util.make_controller(
+            self.tokenizer, [kwargs["source_prompt"], kwargs["prompt"]],
+            NUM_DDIM_STEPS=kwargs["num_inference_steps"],
+            is_replace_controller=kwargs.get("is_replace_controller", True) and equal_length,
+            cross_replace_steps=kwargs["cross_replace_steps"], self_replace_steps=kwargs["self_replace_steps"],
+            blend_words=kwargs.get("blend_words", None), equilizer_params=kwargs.get("eq_params", None),
+            additional_attention_store=self.store_controller, use_inversion_attention=kwargs["use_inversion_attention"],
+            blend_th=kwargs.get("blend_th", (0.3, 0.3)), blend_self_attention=kwargs.get("blend_self_attention", None),
+            blend_latents=kwargs.get("blend_latents", None), save_path=kwargs.get("save_path", None),
+            save_self_attention=kwargs.get("save_self_attention", True), disk_store=kwargs.get("disk_store", False))
+        attention_util.register_attention_control(self, edit_controller)
+        self.last_edit_controller = edit_controller
+        sdimage_output = self.sd_ddim_pipeline(controller=edit_controller, **kwargs)
+        mask_list = edit_controller.latent_blend.mask_list if hasattr(edit_controller.latent_blend, "mask_list") else None
+        attention_output = None
+        if len(edit_controller.attention_store.keys()) > 0:
+            attention_output = attention_util.show_cross_attention(self.tokenizer, kwargs["prompt"], edit_controller, 16,
+                                                                   ["up", "down"])
+        dict_output = {"sdimage_output": sdimage_output, "attention_output": attention_output, "mask_list": mask_list}
+        attention_util.register_attention_control(self, self.empty_controller)
+        return dict_output
+
+    @torch.no_grad()
+    def __call__(self, **kwargs):
+        edit_type = kwargs["edit_type"]
+        assert edit_type in ["save", "swap", None]
+        if edit_type is None:
+            return self.sd_ddim_pipeline(controller=None, **kwargs)
+        if edit_type == "save":
+            del self.store_controller
+            self.store_controller = attention_util.AttentionStore()
+            attention_util.register_attention_control(self, self.store_controller)
+            sdimage_output = self.sd_ddim_pipeline(controller=self.store_controller, **kwargs)
+            attention_output = attention_util.show_cross_attention(self.tokenizer, kwargs["prompt"], self.store_controller,
+                                                                   16, ["up", "down"])
+            dict_output = {"sdimage_output": sdimage_output, "attention_output": attention_output, "mask_list": None}
+            attention_util.register_attention_control(self, self.empty_controller)
+            return dict_output
+        return self.p2preplace_edit(**kwargs)
+
+    @torch.no_grad()
+    def sd_ddim_pipeline(self, prompt: Union[str, List[str]], image=None, height: Optional[int] = None,
+                         width: Optional[int] = None, strength: float = None, num_inference_steps: int = 50,
+                         guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: Optional[int] = 1,
+                         eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                         output_type: Optional[str] = "pil", return_dict: bool = True,
+                         callback: Optional[Callable[[int, int, torch.Tensor], None]] = None,
+                         callback_steps: Optional[int] = 1, controller=None, **args):
+        """CFG DDIM denoise loop (p2p_ddim_spatial_temporal.py:261-435). `output_type='latent'` (extension) returns the
+        final latents without a VAE."""
+        sample_size = getattr(self.unet.config, "sample_size", None) or 64
+        height = height or sample_size * self.vae_scale_factor
+        width = width or sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps, strength)
+        if eta != 0.0:
+            raise NotImplementedError("the editing path always runs eta = 0")
+        batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        device = self._execution_device
+        do_cfg = guidance_scale > 1.0
+        text_embeddings = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        if latents is None:
+            latents = self.prepare_latents_ddim_inverted(image, batch_size, num_images_per_prompt, text_embeddings,
+                                                         store_attention=False, generator=generator)[-1]
+        latents_dtype = latents.dtype
+        state = _LatentState(latents.detach(), reps=2 if do_cfg else 1)
+        emb = text_embeddings.to(torch.float16)
+        n_t = len(timesteps)
+        for i, t in enumerate(self.progress_bar(timesteps)):
+            t = int(t)
+            eps = self.unet.forward_tokens(state.tokens(), t, emb).data
+            cz, ce = self.scheduler.step_coefficients(t)
+            if do_cfg:
+                state.update(eps[: state.f], eps[state.f:], guidance_scale, cz, ce)
+            else:
+                state.update(None, eps, 0.0, cz, ce)
+            if controller is not None:
+                cur = state.as_latents(latents_dtype)
+                new = controller.step_callback(cur)
+                if new is not cur:  # latent blend (attention_util.py:47-78) changed the latents
+                    state.assign(new)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, state.as_latents(latents_dtype))
+        latents = state.as_latents(latents_dtype).clone()
+        if output_type == "latent":
+            image = latents
+        else:
+            image = self.decode_latents(latents)
+            if output_type == "pil":
+                image = self.numpy_to_pil(image)
+        if not return_dict:
+            return (image, None)
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None)

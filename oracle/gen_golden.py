@@ -33,13 +33,20 @@ from stubs import install  # noqa: E402
 
 install()
 sys.path.insert(0, REF)
-sys.path.insert(0, ROOT)
+# NOTE: the repo root must NOT be on sys.path here: the reference's `video_diffusion` is a namespace package (no
+# __init__.py) and this repo's alias package of the same name would shadow it.
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != ROOT]
 import torch  # noqa: E402
 
 torch.cuda.get_device_name = lambda *a, **k: "cpu"  # attention.py:229 calls it unconditionally
 
-from oracle.weights import procedural_state_dict  # noqa: E402
+_wspec = importlib.util.spec_from_file_location("_oracle_weights", os.path.join(HERE, "weights.py"))
+_wmod = importlib.util.module_from_spec(_wspec)
+_wspec.loader.exec_module(_wmod)
+procedural_state_dict = _wmod.procedural_state_dict
 from video_diffusion.models.unet_3d_condition import UNetPseudo3DConditionModel  # noqa: E402
+import video_diffusion as _vd  # noqa: E402
+assert list(_vd.__path__)[0].startswith(REF), "golden vectors must come from the unmodified reference"
 from video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline  # noqa: E402
 from video_diffusion.prompt_attention import attention_util, ptp_utils, seq_aligner  # noqa: E402
 from video_diffusion.prompt_attention.spatial_blend import SpatialBlender  # noqa: E402
@@ -332,8 +339,12 @@ class _FakeVAE(torch.nn.Module):
 
 def gen_pipeline(tok):
     meta = {}
-    F_, L, T = 2, 64, 4
+    F_, T = 2, 4
     scen = [
+        # small-latent scenarios (every level <= 32x32 tokens is captured; no blend words): fast enough for the CPU suite
+        ("pipe_small_replace", 0, {"lora": 16}, dict(self_replace_steps=0.5, L=32, no_blend=True)),
+        ("pipe_small_refine_reweight", 2, {"lora": 16, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 64},
+         dict(self_replace_steps=0.8, L=16, no_blend=True)),
         # name, prompt case idx, model_config, overrides
         ("pipe_replace_blend", 0, {"lora": 16}, dict(self_replace_steps=0.5, blend_self_attention=True)),
         ("pipe_refine_reweight_latentblend", 1, {"lora": 16, "SparseCausalAttention_index": ["mid"]},
@@ -343,6 +354,10 @@ def gen_pipeline(tok):
     ]
     for name, ci, mc, ov in scen:
         _, src, tgt, is_rep, crs, bw, eq, _ = PROMPT_CASES[ci]
+        ov = dict(ov)
+        L = ov.pop("L", 64)
+        if ov.pop("no_blend", False):
+            bw = None
         unet, _ = build_ref_unet("tiny16", mc)
         g = torch.Generator().manual_seed(99)
         z_raw = torch.randn(F_, 4, L, L, generator=g)

@@ -1,0 +1,22 @@
+"""Host orchestration (pipeline loops, controller plans, arena bookkeeping, step reversal) checked end to end on the CPU
+emulation backend against the unmodified reference's outputs -- small-latent scenarios only (the 64x64-latent blend
+scenarios run on the MI355X, tests/test_pipeline_gpu.py)."""
+import pytest
+
+from fatezero_amd import _native, build
+
+import pipeline_cases as PC
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_backend():
+    _native.use_test_backend(build.build_emu())
+    yield
+    _native.reset_backend()
+
+
+@pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_small_replace"])
+def test_pipeline_small(name):
+    res = PC.run_pipeline_case(name, "cpu")
+    print(name, res)
+    PC.check(res)
