@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- edited frames/s of the FateZero hot path on MI355X.
+
+A "step" is ONE FULL JOB of the hot path on one synthetic 8-frame 512x512 clip (BASELINE.json configs[1],
+config/teaser/jeep_posche.yaml shape): a 50-step DDIM inversion with attention-map capture into the HBM arena,
+followed by one 50-step classifier-free-guidance edit with attention fusion (Replace controller, cross 0.5 / self 0.5,
+blend-mask-gated self-attention, th 0.3) -- latents in, latents out (VAE / CLIP / file I/O excluded on both sides,
+SURVEY.md §8d).  value = frames edited per second over the whole job, inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ddim-steps T] [--frames F] [--no-cpu-baseline]
+
+N > 1 (launched with torch.distributed.run, one rank per GPU): every rank edits its own clip (the job is
+data-parallel over clips; weak scaling); RCCL carries only latents: the clean latents are broadcast-checked and the
+edited latents are all-gathered to rank 0 over xGMI.  No collective sits inside the UNet.
+
+Extra JSON fields: `roofline` for the dominant hand-written kernel (the 64x64-level fused spatio-temporal flash
+attention, 4096 x 8192 x d=40: algorithmic FLOPs / HIP-event time measured live on the launch stream) and
+`cpu_baseline` (the CPU oracle of the same loop on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SRC_PROMPT = "a silver jeep driving down a curvy road in the countryside,"
+TGT_PROMPT = "a Porsche car driving down a curvy road in the countryside,"
+EDIT_KW = dict(cross_replace_steps={"default_": 0.5}, self_replace_steps=0.5, use_inversion_attention=True,
+               is_replace_controller=True, blend_words=[["silver", "jeep"], ["Porsche", "car"]],
+               blend_self_attention=True, blend_th=[0.3, 0.3], save_self_attention=False, guidance_scale=7.5)
+SD15 = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+            cross_attention_dim=768, attention_head_dim=8, norm_num_groups=32)
+
+
+class KernelTimer:
+    """HIP-event timing of selected kernel launches on the launch stream (torch's current stream IS the stream every
+    fz_* kernel is launched on)."""
+
+    def __init__(self):
+        self.events = []
+        self.enabled = False
+
+    def wrap(self, module, fn_name, select):
+        orig = getattr(module, fn_name)
+        timer = self
+
+        def wrapped(*a, **k):
+            tag = select(*a, **k) if timer.enabled else None
+            if tag is None:
+                return orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            timer.events.append((tag, s, e))
+            return r
+        setattr(module, fn_name, wrapped)
+
+    def summary(self):
+        out = {}
+        for tag, s, e in self.events:
+            ms = s.elapsed_time(e)
+            d = out.setdefault(tag, [0, 0.0])
+            d[0] += 1
+            d[1] += ms
+        return {k: {"launches": v[0], "avg_ms": v[1] / v[0], "total_ms": v[1]} for k, v in out.items()}
+
+
+def build_pipeline(device, seed=0, model_config=None):
+    from fatezero_amd.synthetic import HashTextEncoder, WordTokenizer, init_like_tuned_checkpoint
+    from fatezero_amd.video_diffusion.models import UNetPseudo3DConditionModel
+    from fatezero_amd.video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline
+    from fatezero_amd.video_diffusion.schedulers import DDIMScheduler
+    torch.manual_seed(seed)
+    with torch.device(device):
+        unet = UNetPseudo3DConditionModel(**SD15, **(model_config or {"lora": 160}))
+    init_like_tuned_checkpoint(unet, seed)
+    unet = unet.half().eval()
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=HashTextEncoder(768).to(device), tokenizer=WordTokenizer(),
+                                         unet=unet, scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    return pipe
+
+
+def run_job(pipe, z0, ddim_steps, device):
+    """One full job: capture inversion + one CFG edit. Returns edited latents."""
+    pipe.scheduler.set_timesteps(ddim_steps)
+    pipe.store_controller = type(pipe.store_controller)()  # fresh arena per job
+    emb_src = pipe._encode_prompt(SRC_PROMPT, device, 1, True, None)
+    lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1, text_embeddings=emb_src,
+                                             store_attention=True, LOW_RESOURCE=True, latents=z0)
+    out = pipe(prompt=TGT_PROMPT, source_prompt=SRC_PROMPT, edit_type="swap", num_inference_steps=ddim_steps,
+               latents=lat[-1], output_type="latent", **EDIT_KW)
+    return out["sdimage_output"].images
+
+
+def cpu_baseline(pipe, ddim_steps, frames):
+    """The CPU oracle (oracle/fatezero_oracle.py, fp32 restatement of the reference loop) on the host cores.
+    Bounded sample: ONE inversion step and ONE CFG edit step of a 1-frame 512x512 clip with the same weights and
+    controller; per-frame cost is extrapolated linearly to the job (steps are homogeneous)."""
+    from oracle import fatezero_oracle as O
+    sd = {k: v.float().cpu() for k, v in pipe.unet.state_dict().items()}
+    cfg = O.UNetConfig(block_out_channels=SD15["block_out_channels"], attention_head_dim=8, cross_attention_dim=768,
+                       norm_num_groups=32, model_config={"lora": 160})
+    unet = O.OracleUNet(sd, cfg)
+    tok = pipe.tokenizer
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, 4, 1, 64, 64, generator=g)
+    emb = torch.randn(2, 77, 768, generator=g)
+    sched = O.DDIMSchedule(ddim_steps)
+    store = O.StoreController()
+    store.LOW_RESOURCE = True
+    t0 = time.time()
+    t = int(sched.timesteps[-1])
+    eps = unet(z, t, emb[1:], store)
+    zn = sched.inverse_step(eps, t, z)
+    store.step_callback(zn)
+    t_inv = time.time() - t0
+    store.LOW_RESOURCE = False
+    ctrl = O.make_edit_controller(tok, [SRC_PROMPT, TGT_PROMPT], store, 1, True, {"default_": 0.5}, 1.0,
+                                  blend_words=EDIT_KW["blend_words"], blend_th=(0.3, 0.3), blend_self_attention=True,
+                                  save_self_attention=False)
+    t0 = time.time()
+    eps2 = unet(torch.cat([zn, zn]), t, emb, ctrl)
+    eu, ec = eps2.chunk(2)
+    _ = sched.step(eu + 7.5 * (ec - eu), t, zn)
+    t_edit = time.time() - t0
+    per_frame_job = ddim_steps * (t_inv + t_edit)  # seconds of CPU work per edited frame
+    return {"value": 1.0 / per_frame_job, "unit": "edited frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 inversion step ({t_inv:.1f} s) + 1 CFG edit step ({t_edit:.1f} s) of a 1-frame 512x512 clip, "
+                      f"full-size SD-1.x pseudo-3D UNet fp32, extrapolated x{ddim_steps} steps (per frame)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1, help="timed jobs")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up jobs")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--warmup-ddim-steps", type=int, default=0, help="DDIM steps of the warm-up jobs (0 = same as timed)")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL over xGMI
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run"
+
+    from fatezero_amd import kernels as K
+    timer = KernelTimer()
+
+    def select(q, k, vt, out, **kw):
+        if kw.get("mode", K.FZ_ATTN_FLASH) == K.FZ_ATTN_FLASH and q.shape[1] == 4096 and q.shape[2] == 320:
+            nf = kw.get("n_frames") or q.shape[0]
+            return ("attn_self_flash_L4096_d40", nf, max(1, len(kw["index_list"])))
+        return None
+    timer.wrap(K, "attn_self", select)
+
+    pipe = build_pipeline(device, seed=0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    z0 = torch.randn(1, 4, args.frames, 64, 64, generator=g).to(device)
+    if dist is not None:  # every rank must have built the same model: compare a weight checksum over RCCL
+        chk = torch.stack([p.float().sum() for p in list(pipe.unet.parameters())[:8]]).sum().reshape(1)
+        ref = chk.clone()
+        dist.broadcast(ref, 0)
+        assert torch.allclose(ref, chk), "ranks built different weights"
+
+    wsteps = args.warmup_ddim_steps or args.ddim_steps
+    for _ in range(args.warmup):
+        run_job(pipe, z0, wsteps, device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    edited = None
+    for _ in range(args.steps):
+        edited = run_job(pipe, z0, args.ddim_steps, device)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    tmax = torch.tensor([dt], device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.empty_like(edited) for _ in range(world)]
+        dist.all_gather(gathered, edited.contiguous())  # edited latents -> rank 0 (and everyone) over xGMI
+        edited = torch.cat(gathered, dim=0)
+    dt = float(tmax.item())
+    finite = bool(torch.isfinite(edited.float()).all())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * args.frames * args.steps / dt
+        summ = timer.summary()
+        roof = None
+        if summ:
+            flops_total, ms_total, launches = 0.0, 0.0, 0
+            for (tag, nf, n_kv), v in summ.items():
+                flops_total += 4.0 * 4096 * (n_kv * 4096) * 320 * nf * v["launches"]  # 4*Lq*Lk*C per frame
+                ms_total += v["total_ms"]
+                launches += v["launches"]
+            achieved = flops_total / (ms_total * 1e-3) / 1e12
+            roof = {"kernel": "attn_self_kernel<40,FLASH> (64x64 level, Lq 4096, Lk 8192, d 40)", "bound": "mfma",
+                    "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+                    "launches": launches, "avg_launch_ms": ms_total / launches,
+                    "algorithmic_flops_per_launch": flops_total / launches}
+        line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)",
+                "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "fp16", "data": "synthetic",
+                "config": {"workload": "config/teaser/jeep_posche.yaml shape: 8 x 512x512 (latents 8x64x64x4), "
+                                       f"{args.ddim_steps}-step DDIM inversion with HBM map capture + {args.ddim_steps}-step "
+                                       "CFG edit (Replace, blend-masked self-attention), SD-1.x pseudo-3D UNet lora=160, "
+                                       "random-init weights",
+                           "frames": args.frames, "ddim_steps": args.ddim_steps, "n_edit": 1,
+                           "parallelism": f"dp{world} over clips" if world > 1 else "single GPU",
+                           "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite},
+                "roofline": roof, "cpu_baseline": None}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(pipe, args.ddim_steps, args.frames)
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,8 @@ class CrossAttention(nn.Module):
                     ctrl, True, q, kk, vt, out, clip, lq, lk,
                     lambda p: K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_CAPTURE, p=p, **kw),
                     lambda p: K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_INJECT, p=p, mapper_t=ident, coef=coef, **kw))
+        elif plan.mode == K.FZ_ATTN_FLASH:
+            K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, **kw)
         else:
             if plan.n_plain > 0:
                 K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, frame0=0, n_frames=plan.n_plain, **kw)
@@ -168,6 +170,8 @@ class SparseCausalAttention(CrossAttention):
                     ctrl, False, q, kk, vt, out, clip, lq, n_kv * lq,
                     lambda p: K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_CAPTURE, p=p, **kw),
                     lambda p: K.attn_self(q, None, vt, out, mode=K.FZ_ATTN_INJECT, p=p, **kw))
+        elif plan.mode == K.FZ_ATTN_FLASH and plan.capture_first is None:
+            K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, **kw)  # nothing to capture or inject: one launch
         else:
             if plan.n_plain > 0:
                 K.attn_self(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, frame0=0, n_frames=plan.n_plain, **kw)

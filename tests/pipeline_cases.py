@@ -24,7 +24,42 @@ def build_unet(kind, model_config, device):
     return unet.half().to(device).eval()
 
 
-def run_pipeline_case(name, device, return_pipe=False):
+def oracle_edit_on_native_maps(meta, consts, gz, store, tok):
+    """Run the fp32 CPU oracle's edit pass on the maps / latents captured by the NATIVE inversion.  With identical
+    (fp16) inversion maps on both sides the attention-blend masks must agree bit for bit, and the edited latents
+    isolate the edit-pass arithmetic from upstream fp16 noise."""
+    from oracle import fatezero_oracle as O
+    shapes = load_json("unet_meta.json")["unet_tiny16_default"]["state_dict_shapes"]
+    cfg = O.UNetConfig(**TINY["tiny16"], model_config=meta["model_config"])
+    unet = O.OracleUNet(procedural_state_dict([(n, tuple(s)) for n, s in shapes]), cfg)
+    ost = O.StoreController()
+    ost.attention_store_all_step = [{k: [t.float().cpu() for t in v] for k, v in d.items()}
+                                    for d in store.attention_store_all_step]
+    ost.latents_store = [t.float().cpu() for t in store.latents_store]
+    kw = meta["kwargs"]
+    ctrl = O.make_edit_controller(
+        tok, consts["prompts"], ost, meta["T"], kw["is_replace_controller"], dict(kw["cross_replace_steps"]),
+        kw["self_replace_steps"], blend_words=kw.get("blend_words"), eq_params=kw.get("eq_params"),
+        blend_th=tuple(kw["blend_th"]), blend_self_attention=kw.get("blend_self_attention", False),
+        blend_latents=kw.get("blend_latents", False), save_self_attention=kw["save_self_attention"])
+    sched = O.DDIMSchedule(meta["T"])
+    edited = O.ddim_edit(unet, sched, torch.from_numpy(gz["zT"]), torch.from_numpy(gz["emb_tgt"]), ctrl,
+                         guidance_scale=kw["guidance_scale"])
+    return edited, ctrl
+
+
+def _mask_flips(native_list, oracle_list):
+    flips = total = 0
+    assert len(native_list) == len(oracle_list), (len(native_list), len(oracle_list))
+    for a, b in zip(native_list, oracle_list):
+        a, b = a.bool().cpu(), b.bool().cpu()
+        assert a.shape == b.shape, (a.shape, b.shape)
+        flips += int((a != b).sum())
+        total += a.numel()
+    return flips, total
+
+
+def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False):
     meta = load_json("pipeline_meta.json")[name]
     consts = load_json("host_constants.json")[meta["prompt_case"]]
     gz = load_npz(name + ".npz")
@@ -81,6 +116,13 @@ def run_pipeline_case(name, device, return_pipe=False):
         want = unpack_bits(gz["latent_mask_bits"], gz["latent_mask_shape"])
         assert got.shape == want.shape, (got.shape, want.shape)
         res["latent_mask_flips"], res["latent_mask_total"] = int((got != want).sum()), got.size
+    if mixed_oracle:
+        o_edit, o_ctrl = oracle_edit_on_native_maps(meta, consts, gz, store, ReplayTokenizer())
+        res["edit_err_vs_oracle_on_native_maps"] = float((edited - o_edit).abs().max())
+        if ctrl.attention_blend is not None:
+            res["attn_mask_flips_same_maps"], _ = _mask_flips(ctrl.attention_blend.mask_list, o_ctrl.attention_blend.mask_list)
+        if ctrl.latent_blend is not None:
+            res["latent_mask_flips_same_inv_maps"], _ = _mask_flips(ctrl.latent_blend.mask_list, o_ctrl.latent_blend.mask_list)
     return (res, pipe) if return_pipe else res
 
 
@@ -88,13 +130,24 @@ def run_pipeline_case(name, device, return_pipe=False):
 LATENT_TOL = 2.5e-2      # max |latent error| / max |latent|
 MAP_TOL = 2e-2           # absolute, on probabilities in [0,1], END TO END (fp16 q/k/activations upstream of a peaky
                          # softmax); given identical q/k the kernels store P within 1.6 fp16 ulp (kernel_cases.py)
-MASK_FLIP_TOL = 2e-3     # fraction of mask elements that may differ from the fp32 reference (pixels whose normalised
-                         # score sits within fp16 rounding of the threshold); the kernel itself is bit-exact on equal inputs
+MASK_FLIP_TOL = 1.5e-2   # fraction of mask elements that may differ from the all-fp32 reference run: the mask thresholds a
+                         # normalised score, and the captured fp16 maps carry ~1e-2 of upstream fp16 noise, so pixels
+                         # sitting within ~1% of the threshold flip.  Given IDENTICAL captured maps (oracle edit run on
+                         # the native inversion maps) the attention-blend masks must be bit-exact: 0 differing elements.
+EDIT_TOL_SAME_MAPS = 2.5e-2
+EDIT_TOL_VS_REFERENCE = 6e-2   # edit pass vs the all-fp32 reference when blend masks are in play (mask flips are discrete)
 
 
 def check(res):
     assert res["inv_err"] <= LATENT_TOL * res["inv_scale"], res
-    assert res["edit_err"] <= LATENT_TOL * res["edit_scale"], res
+    has_mask = "attn_mask_flips" in res or "latent_mask_flips" in res
+    assert res["edit_err"] <= (EDIT_TOL_VS_REFERENCE if has_mask else LATENT_TOL) * res["edit_scale"], res
+    if "edit_err_vs_oracle_on_native_maps" in res:
+        assert res["edit_err_vs_oracle_on_native_maps"] <= EDIT_TOL_SAME_MAPS * res["edit_scale"], res
+    if "attn_mask_flips_same_maps" in res:
+        assert res["attn_mask_flips_same_maps"] == 0, res
+    if "latent_mask_flips_same_inv_maps" in res:
+        assert res["latent_mask_flips_same_inv_maps"] <= MASK_FLIP_TOL * res["latent_mask_total"], res
     assert res["map_err"] <= MAP_TOL and res["self_map_err"] <= MAP_TOL, res
     for k in ("attn_mask", "latent_mask"):
         if k + "_flips" in res:

@@ -17,7 +17,7 @@ def hip_backend():
 @pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_small_replace", "pipe_replace_blend",
                                   "pipe_refine_reweight_latentblend", "pipe_refine_noblend"])
 def test_pipeline(name):
-    res = PC.run_pipeline_case(name, "cuda")
+    res = PC.run_pipeline_case(name, "cuda", mixed_oracle=True)
     print(name, res)
     PC.check(res)
     assert _native.loaded_path().endswith("libfatezero_hip.so")
