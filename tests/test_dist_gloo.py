@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: world_size 2, gloo, emulation backend.  Each rank edits its own clip with the tiny model; the
+all-gathered latents must equal what a single process computes for the same clips."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _job_factory():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fatezero_amd import _native, build
+    _native.use_test_backend(build.build_emu())
+    import pipeline_cases as PC
+    from fatezero_amd.synthetic import WordTokenizer
+    from fatezero_amd.video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline
+    from fatezero_amd.video_diffusion.schedulers import DDIMScheduler
+    unet = PC.build_unet("tiny16", {"lora": 16, "SparseCausalAttention_index": ["mid"]}, "cpu")
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=WordTokenizer(), unet=unet,
+                                         scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(2, 77, 64, generator=g)
+    pipe._encode_prompt = lambda *a, **k: emb
+
+    def job(i):
+        gi = torch.Generator().manual_seed(100 + i)
+        z0 = torch.randn(1, 4, 2, 8, 8, generator=gi)
+        pipe.scheduler.set_timesteps(2)
+        pipe.store_controller = type(pipe.store_controller)()
+        lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1, text_embeddings=emb,
+                                                 store_attention=True, LOW_RESOURCE=True, latents=z0)
+        out = pipe(prompt="a red car", source_prompt="a blue car", edit_type="swap", num_inference_steps=2,
+                   latents=lat[-1], output_type="latent", cross_replace_steps={"default_": 0.5}, self_replace_steps=0.5,
+                   use_inversion_attention=True, is_replace_controller=True, save_self_attention=False, guidance_scale=3.0)
+        return out["sdimage_output"].images
+    return pipe, job
+
+
+def _worker(rank, world, port, n_clips, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), FZ_EMU_THREADS="2")
+    torch.set_num_threads(2)
+    from fatezero_amd import dist as D
+    import torch.distributed as dist
+    D.init("gloo")
+    pipe, job = _job_factory()
+    assert D.weights_agree(pipe.unet, "cpu")
+    res = D.edit_clips(job, n_clips, "cpu")
+    if rank == 0:
+        q.put([r.clone() for r in res])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [3])
+def test_two_ranks_match_single_process(n_clips):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    os.environ.pop("WORLD_SIZE", None)
+    os.environ.pop("RANK", None)
+    _, job = _job_factory()
+    from fatezero_amd import _native
+    try:
+        for i in range(n_clips):
+            ref = job(i)
+            assert torch.equal(ref, got[i]), f"clip {i} differs between the 2-rank and the single-process run"
+    finally:
+        _native.reset_backend()
+
+
+def test_clip_partition():
+    from fatezero_amd.dist import clips_for_rank
+    for n in (0, 1, 5, 8, 9):
+        for w in (1, 2, 4, 8):
+            allc = sum((clips_for_rank(n, w, r) for r in range(w)), [])
+            assert allc == list(range(n))
