@@ -29,6 +29,7 @@ class FzAttnSelfDesc(C.Structure):
         ("o_frame_stride", C.c_int64), ("o_row_stride", C.c_int64),
         ("p_frame_stride", C.c_int64), ("p_head_stride", C.c_int64), ("p_row_stride", C.c_int64),
         ("p_frame_off", C.c_int32), ("mask_frame_off", C.c_int32),
+        ("k_head_stride", C.c_int64),
     ]
 
 

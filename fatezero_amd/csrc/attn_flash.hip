@@ -1,0 +1,391 @@
+// attn_flash.hip -- the MFMA-bound member of the attention family: plain (no map) sparse-causal self-attention,
+// i.e. the 64x64-token level of SD-1.x (Lq 4096, Lk 8192, d 40: 86 % of all attention FLOPs) and the
+// unconditional CFG half of every other level.  Same transposed formulation as attn_self.hip
+// (S^T = K Q^T, O^T = V^T P^T, lane <-> query row, registers of S^T are the B operand of the PV MFMA), plus:
+//   * software pipelining: the next K/V tile is fetched global->registers before the MFMAs of the current tile
+//     and written to the OTHER LDS buffer after them: one __syncthreads per 64-key tile, HBM/L2 latency hidden
+//     under the 14 (d=40) MFMAs + softmax of the current tile;
+//   * deferred rescale: O/l are only rescaled when some row's running max grew by more than 2^6
+//     (wave-uniform branch); P stays < 2^6 in fp16, the accumulators are fp32;
+//   * the softmax denominator costs no VALU when d % 32 != 0: one padding row of the V^T tile is set to 1.0, so
+//     row D of O^T accumulates sum_k P[q,k] inside the PV MFMA (and is rescaled with O for free);
+//   * key masking only on the (wave-uniform) tail tile of a kv slot; scale folded into the exp2 argument.
+#include "fz_rt.h"
+#include "../../include/fatezero_hip.h"
+#include <stdlib.h>
+
+#define FQBLK 128
+#define FKVBLK 64
+#define FVSTR 72
+
+template <int D, int QB>
+struct FlashCfg {
+    static constexpr int QROWS = 128 * QB;  // query rows per workgroup: 4 waves x QB blocks of 32
+    static constexpr int DP16 = (D + 15) / 16 * 16;
+    static constexpr int NC = DP16 / 16;
+    static constexpr int NT = (D + 31) / 32;
+    static constexpr int KSTR = DP16 + 8;
+    static constexpr int KCH = DP16 / 8;
+    static constexpr int VROWS = NT * 32;
+    static constexpr int OSTR = NT * 32 + 8;
+    static constexpr bool ONES_ROW = (D % 32) != 0;  // a free padding row of V^T carries the softmax denominator
+    static constexpr int KS = FKVBLK * KSTR;
+    static constexpr int VS = VROWS * FVSTR;
+    static constexpr int STAGE = KS + VS;
+    static constexpr int OS = QROWS * OSTR;
+    static constexpr int LDS_HALVES = (2 * STAGE > OS) ? 2 * STAGE : OS;
+    static constexpr int KLD = (FKVBLK * KCH + 255) / 256;  // 16-byte K chunks per thread per tile
+    static constexpr int VLD = (D * 8 + 255) / 256;         // 16-byte V^T chunks per thread per tile (rows < D only)
+};
+
+FZ_DEVICE int fl_pi(int i) {
+    const int a = i >> 3, hp = (i >> 2) & 1, t = i & 3;
+    return ((a & 2) << 3) + 8 * hp + 4 * (a & 1) + t;
+}
+
+template <int D, int W, int QB, bool BRANCHY, int ABL = 0>
+FZ_KERNEL void __launch_bounds__(256, W)
+attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* __restrict__ k,
+                  const half_t* __restrict__ vt, half_t* __restrict__ o) {
+    typedef FlashCfg<D, QB> C;
+    FZ_SHARED __attribute__((aligned(16))) half_t smem[C::LDS_HALVES];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq_ = lane & 31, hi = lane >> 5;
+    const int nq = (d.lq + C::QROWS - 1) / C::QROWS;
+    const int groups = d.heads * d.n_frames;
+    int group, qt;
+    {
+        const int bid = blockIdx.x;
+        if ((groups & 7) == 0) {
+            const int xcd = bid & 7, idx = bid >> 3;
+            group = xcd * (groups >> 3) + idx / nq;
+            qt = idx % nq;
+        } else {
+            group = bid / nq;
+            qt = bid % nq;
+        }
+    }
+    const int h = group / d.n_frames, fl = group % d.n_frames;
+    const int n = d.frame0 + fl, b = n / d.clip_len, f = n % d.clip_len;
+    // each wave owns QB blocks of 32 query rows: every K / V^T fragment read from LDS feeds QB MFMAs, and the
+    // independent blocks let the MFMAs of one overlap the softmax VALU of the other inside the wave
+    half8_t qf[QB][C::NC];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        const int qrow = qt * C::QROWS + (wave * QB + u) * 32 + lq_;
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+            const int dd = 16 * c + 8 * hi;
+            qf[u][c] = (qrow < d.lq && dd < D)
+                           ? fz_ld_h8(q + (int64_t)n * d.q_frame_stride + (int64_t)qrow * d.q_row_stride + h * D + dd)
+                           : fz_zero_h8();
+        }
+    }
+    int src[FZ_MAX_KV_SLOTS];
+#pragma unroll
+    for (int j = 0; j < FZ_MAX_KV_SLOTS; ++j) {
+        int s = d.kv_abs[j] ? d.kv_val[j] : f + d.kv_val[j];
+        s = s < 0 ? 0 : (s > d.clip_len - 1 ? d.clip_len - 1 : s);
+        src[j] = b * d.clip_len + s;
+    }
+    const int lkfp = (d.lkf + FKVBLK - 1) / FKVBLK * FKVBLK;
+    const int tps = lkfp / FKVBLK;
+    const int ntiles = d.n_kv * tps;
+    const int64_t khs = d.k_head_stride ? d.k_head_stride : (int64_t)D;
+    const float cs = d.scale * 1.4426950408889634f;
+
+    // zero the padding rows of both V^T stages once (row D becomes the ones row); K padding columns are rewritten
+    // with zeros by every K store (they come from the zero-filled register chunks)
+    for (int id = tid; id < 2 * (C::VROWS - D) * 8; id += 256) {
+        const int st = id / ((C::VROWS - D) * 8), rem = id % ((C::VROWS - D) * 8);
+        const int row = D + rem / 8, ch = rem % 8;
+        half8_t v = fz_zero_h8();
+        if (C::ONES_ROW && row == D)
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)1.0f;
+        fz_st_h8(smem + st * C::STAGE + C::KS + row * FVSTR + ch * 8, v);
+    }
+
+    // Prefetch registers.  The loads are UNCONDITIONAL (addresses clamped into the tensor, invalid data replaced when it
+    // is written to LDS): a predicated load makes hipcc wrap it in control flow and then wait vmcnt(0) at the join,
+    // i.e. right before the first MFMA of the tile -- which would expose the whole global-load latency every tile.
+    half8_t kreg[C::KLD], vreg[C::VLD];
+    auto fetch = [&](int kt) {
+        const int j = kt / tps, r0 = (kt % tps) * FKVBLK;
+        const half_t* kb = k + (int64_t)src[j] * d.k_frame_stride + (int64_t)h * khs;
+#pragma unroll
+        for (int i = 0; i < C::KLD; ++i) {
+            int id = tid + 256 * i;
+            id = id < FKVBLK * C::KCH ? id : FKVBLK * C::KCH - 1;
+            const int key = id / C::KCH, ch = id % C::KCH;
+            int r = r0 + key, dd = ch * 8;
+            r = r < d.lkf ? r : d.lkf - 1;   // padded keys are masked in the softmax; any finite data will do
+            dd = dd < D ? dd : D - 8;        // padding chunk: zeroed in stash()
+            kreg[i] = fz_ld_h8(kb + (int64_t)r * d.k_row_stride + dd);
+        }
+        const half_t* vb = vt + (int64_t)src[j] * d.vt_frame_stride + (int64_t)(h * D) * d.vt_chan_stride + r0;
+#pragma unroll
+        for (int i = 0; i < C::VLD; ++i) {
+            const int id = tid + 256 * i;
+            int row = id >> 3;
+            const int ch = id & 7;
+            row = row < D ? row : D - 1;     // not stashed
+            vreg[i] = fz_ld_h8(vb + (int64_t)row * d.vt_chan_stride + ch * 8);
+        }
+    };
+    auto stash = [&](int st) {
+        half_t* Ks = smem + st * C::STAGE;
+        half_t* Vs = Ks + C::KS;
+#pragma unroll
+        for (int i = 0; i < C::KLD; ++i) {
+            const int id = tid + 256 * i;
+            if (id < FKVBLK * C::KCH) {
+                const int ch = id % C::KCH;
+                fz_st_h8(Ks + (id / C::KCH) * C::KSTR + ch * 8, (ch * 8 < D) ? kreg[i] : fz_zero_h8());
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::VLD; ++i) {
+            const int id = tid + 256 * i;
+            if ((id >> 3) < D) fz_st_h8(Vs + (id >> 3) * FVSTR + (id & 7) * 8, vreg[i]);
+        }
+    };
+
+    float m[QB], l[QB];
+    f32x16 oacc[QB][C::NT];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        m[u] = -1e30f;
+        l[u] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) oacc[u][t] = fz_zero_f16v();
+    }
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        const int r0 = (kt % tps) * FKVBLK;
+        if (!(ABL & 8) && kt + 1 < ntiles) fetch(kt + 1);  // in flight during the MFMAs below
+
+        const half_t* Ks = smem + ((ABL & 8) ? 0 : cur) * C::STAGE;
+        const half_t* Vs = Ks + C::KS;
+        f32x16 acc[QB][2];
+        half8_t kfr[2][C::NC];  // every K fragment of the tile is requested before the first MFMA
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const half_t* row = Ks + (32 * sub + fl_pi(lq_)) * C::KSTR + 8 * hi;
+#pragma unroll
+            for (int c = 0; c < C::NC; ++c) kfr[sub][c] = fz_ld_h8(row + 16 * c);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) acc[u][sub] = fz_zero_f16v();
+#pragma unroll
+            for (int c = 0; c < C::NC; ++c) {
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    if (ABL & 4) {
+                        for (int r = 0; r < 16; ++r) acc[u][sub][r] += (float)kfr[sub][c][r & 7] + (float)qf[u][c][r & 7];
+                    } else {
+                        acc[u][sub] = fz_mfma_32x32x16_f16(kfr[sub][c], qf[u][c], acc[u][sub]);
+                    }
+                }
+            }
+        }
+        half8_t pf[QB][2][2];
+        const bool tail = (r0 + FKVBLK > d.lkf);  // wave-uniform: last tile of a kv slot has padded keys
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            float s[32];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[16 * sub + r] = acc[u][sub][r];
+            if (tail) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * sub + (r < 8 ? 8 * hi + r : 8 + 8 * hi + r);
+                        if (r0 + key >= d.lkf) s[16 * sub + r] = -INFINITY;
+                    }
+            }
+            if (ABL & 1) {  // ablation: no softmax arithmetic (values kept live by the conversions)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) pf[u][i >> 4][(i >> 3) & 1][i & 7] = (half_t)s[i];
+                continue;
+            }
+            float tmax = s[0];
+#pragma unroll
+            for (int i = 1; i < 32; ++i) tmax = fmaxf(tmax, s[i]);
+            tmax = fz_pair_max32(tmax) * cs;   // log2-domain row max of this tile over both lane halves (cs > 0)
+            if (BRANCHY) {
+                if (fz_ballot(tmax > m[u] + 6.0f) != 0ull) {  // some row's max grew by more than 2^6: rescale
+                    const float mn = fmaxf(m[u], tmax);
+                    const float alpha = fz_exp2(m[u] - mn);
+                    m[u] = mn;
+                    l[u] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < C::NT; ++t) oacc[u][t] *= alpha;
+                }
+            } else {
+                // branch-free: the whole tile body stays one scheduling region, so the MFMAs of the other query block
+                // and the softmax VALU of this one interleave inside the wave
+                const float mn = fmaxf(m[u], tmax);
+                const float alpha = fz_exp2(m[u] - mn);
+                m[u] = mn;
+                l[u] *= alpha;
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) oacc[u][t] *= alpha;
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float pe = fz_exp2(s[i] * cs - m[u]);
+                if (!C::ONES_ROW) sum += pe;
+                pf[u][i >> 4][(i >> 3) & 1][i & 7] = (half_t)pe;
+            }
+            if (!C::ONES_ROW) l[u] += sum;
+        }
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            const half_t* vrow = Vs + (32 * t + lq_) * FVSTR + 8 * hi;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const half8_t vf = fz_ld_h8(vrow + 32 * sub + 16 * mm);
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) {
+                        if (ABL & 2) {
+                            for (int r = 0; r < 8; ++r) oacc[u][t][r] += (float)vf[r] * (float)pf[u][sub][mm][r];
+                        } else {
+                            oacc[u][t] = fz_mfma_32x32x16_f16(vf, pf[u][sub][mm], oacc[u][t]);
+                        }
+                    }
+                }
+        }
+        if (!(ABL & 8) && kt + 1 < ntiles) stash(cur ^ 1);
+        if (!(ABL & 16)) __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    half_t* Os = smem;
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        float denom;
+        if (C::ONES_ROW) {
+            // row D of O^T: tile D/32, row i = D%32 = (r&3) + 8(r>>2) + 4hi'
+            constexpr int i = D % 32, t = D / 32;
+            constexpr int hp = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
+            const float mine = oacc[u][t][r];
+            const float other = fz_shfl_xor(mine, 32);
+            denom = (hi == hp) ? mine : other;
+        } else {
+            denom = l[u] + fz_shfl_xor(l[u], 32);
+        }
+        const float fin = 1.0f / denom;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(oacc[u][t][4 * g + e] * fin);
+                *reinterpret_cast<half4_t*>(Os + ((wave * QB + u) * 32 + lq_) * C::OSTR + 32 * t + 8 * g + 4 * hi) = v;
+            }
+    }
+    __syncthreads();
+    constexpr int OCH = D / 8;
+    for (int id = lane; id < 32 * QB * OCH; id += 64) {
+        const int row = id / OCH, ch = id % OCH;
+        const int qg = qt * C::QROWS + wave * 32 * QB + row;
+        if (qg < d.lq)
+            fz_st_h8(o + (int64_t)n * d.o_frame_stride + (int64_t)qg * d.o_row_stride + h * D + ch * 8,
+                     fz_ld_h8(Os + (wave * 32 * QB + row) * C::OSTR + ch * 8));
+    }
+}
+
+template <int D, int W, int QB, bool BRANCHY = true, int ABL = 0>
+static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream) {
+    const int nq = (d.lq + 128 * QB - 1) / (128 * QB);
+    dim3 grid(nq * d.heads * d.n_frames), block(256);
+    FZ_LAUNCH((attn_flash_kernel<D, W, QB, BRANCHY, ABL>), grid, block, 0, stream, d, (const half_t*)q, (const half_t*)k,
+              (const half_t*)vt, (half_t*)o);
+    return fz_last_launch_status();
+}
+
+static bool flash_branchfree() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_FLASH_BRANCHFREE");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+static int flash_qb_override() {  // tuning knob: 32-row query blocks per wave (0 = default)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_FLASH_QB");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+static int flash_waves_override() {  // tuning knob: min waves/SIMD the register allocator must allow (0 = default)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_FLASH_WAVES");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+// called by fz_attn_self (attn_self.hip) for mode == FZ_ATTN_FLASH
+int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream) {
+    const int w = flash_waves_override(), qb = flash_qb_override();
+    const bool big = d.lq >= 512;  // two query blocks per wave only pay when there are enough rows to fill the chip
+    switch (d.head_dim) {
+        case 16: return launch_flash<16, 2, 1>(d, q, k, vt, o, stream);
+        case 32: return launch_flash<32, 2, 1>(d, q, k, vt, o, stream);
+        case 40:
+            if (qb == 2 || (qb == 0 && big)) {
+                if (w == 1) return launch_flash<40, 1, 2>(d, q, k, vt, o, stream);
+                if (flash_branchfree()) return launch_flash<40, 2, 2, false>(d, q, k, vt, o, stream);
+#ifndef FZ_EMU
+                {   // ablation builds for profiling only (results are wrong by construction)
+                    static int abl = -1;
+                    if (abl < 0) { const char* e = getenv("FZ_FLASH_ABLATE"); abl = e ? atoi(e) : 0; }
+                    switch (abl) {
+                        case 1: return launch_flash<40, 2, 2, true, 1>(d, q, k, vt, o, stream);
+                        case 2: return launch_flash<40, 2, 2, true, 2>(d, q, k, vt, o, stream);
+                        case 4: return launch_flash<40, 2, 2, true, 4>(d, q, k, vt, o, stream);
+                        case 6: return launch_flash<40, 2, 2, true, 6>(d, q, k, vt, o, stream);
+                        case 8: return launch_flash<40, 2, 2, true, 8>(d, q, k, vt, o, stream);
+                        case 16: return launch_flash<40, 2, 2, true, 16>(d, q, k, vt, o, stream);
+                        case 24: return launch_flash<40, 2, 2, true, 24>(d, q, k, vt, o, stream);
+                        case 25: return launch_flash<40, 2, 2, true, 25>(d, q, k, vt, o, stream);
+                        case 7: return launch_flash<40, 2, 2, true, 7>(d, q, k, vt, o, stream);
+                        default: break;
+                    }
+                }
+#endif
+                return launch_flash<40, 2, 2>(d, q, k, vt, o, stream);
+            }
+            if (w == 2) return launch_flash<40, 2, 1>(d, q, k, vt, o, stream);
+            if (w == 3) return launch_flash<40, 3, 1>(d, q, k, vt, o, stream);
+            return launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
+        case 64: return launch_flash<64, 2, 1>(d, q, k, vt, o, stream);
+        case 80:
+            if (qb == 2) return launch_flash<80, 1, 2>(d, q, k, vt, o, stream);
+            if (w == 1) return launch_flash<80, 1, 1>(d, q, k, vt, o, stream);
+            return launch_flash<80, 2, 1>(d, q, k, vt, o, stream);
+        case 128: return launch_flash<128, 1, 1>(d, q, k, vt, o, stream);
+        case 160: return launch_flash<160, 1, 1>(d, q, k, vt, o, stream);
+        default: return FZ_ERR_UNSUPPORTED;
+    }
+}

@@ -15,6 +15,7 @@
 // mapping (all query tiles of a (head, frame) pair land on one XCD so its K/V stay in that XCD's L2).
 #include "fz_rt.h"
 #include "../../include/fatezero_hip.h"
+#include <stdlib.h>
 
 #define QBLK 128
 #define KVBLK 64
@@ -99,6 +100,7 @@ attn_self_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* _
     const int lkfp = (d.lkf + KVBLK - 1) / KVBLK * KVBLK;
     const int tps = lkfp / KVBLK;
     const int ntiles = d.n_kv * tps;
+    const int64_t khs = d.k_head_stride ? d.k_head_stride : (int64_t)D;
     const float cs = d.scale * 1.4426950408889634f;  // softmax in the log2 domain
 
     bool use_cur = true;  // INJECT: does this lane's row keep the live attention?
@@ -113,7 +115,7 @@ attn_self_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* _
     // ---- tile loaders ----------------------------------------------------------------------------------
     auto load_k = [&](int kt) {
         const int j = kt / tps, r0 = (kt % tps) * KVBLK;
-        const half_t* base = k + (int64_t)src[j] * d.k_frame_stride + h * D;
+        const half_t* base = k + (int64_t)src[j] * d.k_frame_stride + (int64_t)h * khs;
         for (int id = tid; id < KVBLK * C::KCH; id += 256) {
             const int key = id / C::KCH, ch = id % C::KCH;
             const int r = r0 + key, dd = ch * 8;
@@ -349,6 +351,17 @@ static int launch_self(const FzAttnSelfDesc& d, const void* q, const void* k, co
     return fz_last_launch_status();
 }
 
+int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream);
+
+static bool use_flash_v0() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_FLASH_V0");  // A/B switch for benchmarking the first-generation kernel
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 extern "C" int fz_attn_self(const FzAttnSelfDesc* desc, const void* q, const void* k, const void* vt, void* o,
                             void* p, const float* row_mask, void* stream) {
     if (!desc || !q || !vt || !o) return FZ_ERR_BAD_ARG;
@@ -359,6 +372,7 @@ extern "C" int fz_attn_self(const FzAttnSelfDesc* desc, const void* q, const voi
     if ((d.q_row_stride | d.k_row_stride | d.vt_chan_stride | d.o_row_stride | d.q_frame_stride | d.k_frame_stride |
          d.vt_frame_stride | d.o_frame_stride) & 7)
         return FZ_ERR_BAD_ARG;  // 16-byte vector access
+    if (d.mode == FZ_ATTN_FLASH && !use_flash_v0()) return fz_attn_flash_dispatch(d, q, k, vt, o, stream);
     switch (d.head_dim) {
         case 16: return launch_self<16>(d, q, k, vt, o, p, row_mask, stream);
         case 32: return launch_self<32>(d, q, k, vt, o, p, row_mask, stream);

@@ -50,6 +50,12 @@ FZ_DEVICE float fz_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64);
 FZ_DEVICE int fz_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE float fz_shfl(float v, int lane) { return __shfl(v, lane, 64); }
 FZ_DEVICE unsigned long long fz_ballot(int pred) { return __ballot(pred); }
+// max over the lane pair (l, l^32) without touching LDS: v_permlane32_swap (gfx950) instead of ds_bpermute
+FZ_DEVICE float fz_pair_max32(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 FZ_DEVICE float fz_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 FZ_DEVICE float fz_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 FZ_DEVICE float fz_rsqrt(float x) { return rsqrtf(x); }
@@ -139,6 +145,7 @@ static inline unsigned long long fz_ballot(int pred) {
     for (int i = 0; i < 64; ++i) m |= (unsigned long long)(all[i] != 0) << i;
     return m;
 }
+static inline float fz_pair_max32(float v) { return fmaxf(v, fz_shfl_xor(v, 32)); }
 static inline float fz_exp2(float x) { return exp2f(x); }
 static inline float fz_rcp(float x) { return 1.0f / x; }
 static inline float fz_rsqrt(float x) { return 1.0f / sqrtf(x); }

@@ -91,26 +91,42 @@ FZ_KERNEL void gn_stats_kernel(GnArgs a) {
     }
 }
 
-FZ_KERNEL void gn_finalize_kernel(GnArgs a) {
-    // one thread per (span, group): Chan's parallel-variance merge in a fixed order
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nspan = a.n_frames / a.span;
-    if (idx >= nspan * a.G) return;
+FZ_DEVICE void chan_merge(float& cnt, float& mean, float& m2, float nb, float mb, float m2b) {
+    const float tot = cnt + nb;
+    if (tot > 0.0f) {
+        const float delta = mb - mean;
+        mean += delta * (nb / tot);
+        m2 += m2b + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+}
+
+FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
+    // one wave per (span, group): each lane Chan-merges a strided subset of the span's partials, then a fixed
+    // xor-butterfly merges the 64 lane results (deterministic order -> bitwise reproducible statistics)
+    const int idx = blockIdx.x, lane = threadIdx.x;
     const int sp = idx / a.G, g = idx % a.G;
+    const int total = a.span * a.chunks;
     float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
-    for (int f = 0; f < a.span; ++f)
-        for (int c = 0; c < a.chunks; ++c) {
-            const float* pp = a.partial + (((int64_t)(sp * a.span + f) * a.chunks + c) * a.G + g) * 3;
-            const float nb = pp[0], mb = pp[1], m2b = pp[2];
-            const float tot = cnt + nb;
-            const float delta = mb - mean;
-            mean += delta * (nb / tot);
-            m2 += m2b + delta * delta * (cnt * nb / tot);
-            cnt = tot;
-        }
-    const float var = m2 / cnt;  // biased, as torch.nn.GroupNorm
-    a.stats[idx * 2 + 0] = mean;
-    a.stats[idx * 2 + 1] = 1.0f / sqrtf(var + a.eps);
+    for (int e = lane; e < total; e += 64) {
+        const int f = e / a.chunks, c = e % a.chunks;
+        const float* pp = a.partial + (((int64_t)(sp * a.span + f) * a.chunks + c) * a.G + g) * 3;
+        chan_merge(cnt, mean, m2, pp[0], pp[1], pp[2]);
+    }
+#pragma unroll
+    for (int msk = 1; msk < 64; msk <<= 1) {
+        const float nb = fz_shfl_xor(cnt, msk), mb = fz_shfl_xor(mean, msk), m2b = fz_shfl_xor(m2, msk);
+        // both partners must compute the same merged value: merge (lower lane, upper lane) in that order
+        float c0 = cnt, me0 = mean, q0 = m2, c1 = nb, me1 = mb, q1 = m2b;
+        if (lane & msk) { c0 = nb; me0 = mb; q0 = m2b; c1 = cnt; me1 = mean; q1 = m2; }
+        chan_merge(c0, me0, q0, c1, me1, q1);
+        cnt = c0; mean = me0; m2 = q0;
+    }
+    if (lane == 0) {
+        const float var = m2 / cnt;  // biased, as torch.nn.GroupNorm
+        a.stats[idx * 2 + 0] = mean;
+        a.stats[idx * 2 + 1] = 1.0f / sqrtf(var + a.eps);
+    }
 }
 
 FZ_KERNEL void gn_apply_kernel(GnArgs a) {
@@ -166,7 +182,7 @@ extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const voi
     const size_t smem = ((size_t)a.R * channels + groups) * sizeof(float);
     FZ_LAUNCH(gn_stats_kernel, grid, block, smem, stream, a);
     const int nst = (n_frames / span) * groups;
-    FZ_LAUNCH(gn_finalize_kernel, dim3((nst + 63) / 64), dim3(64), 0, stream, a);
+    FZ_LAUNCH(gn_finalize_kernel, dim3(nst), dim3(64), 0, stream, a);
     FZ_LAUNCH(gn_apply_kernel, grid, block, 0, stream, a);
     return fz_last_launch_status();
 }

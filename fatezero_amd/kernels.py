@@ -72,8 +72,9 @@ def kv_slots(index_list: Sequence, clip_len: int) -> Tuple[List[int], List[int]]
 def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out: torch.Tensor, *, clip_len: int,
               heads: int, index_list: Sequence, mode: int = FZ_ATTN_FLASH, frame0: int = 0, n_frames: Optional[int] = None,
               p: Optional[torch.Tensor] = None, p_frame_off: int = 0, row_mask: Optional[torch.Tensor] = None,
-              mask_frame_off: int = 0, scale: Optional[float] = None):
+              mask_frame_off: int = 0, scale: Optional[float] = None, k_head_major: Optional[torch.Tensor] = None):
     """q,k,out: [N, L, >=C] views with row stride (token-major); vt: [N, C, Lpad]; p: [Fp, heads, Lq, Lk] fp16.
+    k_head_major (optional): K as a contiguous [N, heads, L, d] tensor (fully coalesced key tiles) instead of `k`.
 
     Frames frame0 .. frame0+n_frames-1 of q/out are processed; k/vt are indexed by source frame.
     """
@@ -92,7 +93,12 @@ def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out:
     d.mode = mode
     assert q.stride(2) == 1 and out.stride(2) == 1 and vt.stride(2) == 1
     d.q_frame_stride, d.q_row_stride = q.stride(0), q.stride(1)
-    if k is not None:
+    if k_head_major is not None:
+        assert k_head_major.is_contiguous() and k_head_major.shape[1] == heads and k_head_major.shape[3] == d_head
+        d.lkf = k_head_major.shape[2]
+        d.k_frame_stride, d.k_row_stride, d.k_head_stride = k_head_major.stride(0), d_head, k_head_major.stride(1)
+        k = k_head_major
+    elif k is not None:
         assert k.stride(2) == 1
         d.k_frame_stride, d.k_row_stride = k.stride(0), k.stride(1)
     d.vt_frame_stride, d.vt_chan_stride = vt.stride(0), vt.stride(1)

@@ -57,6 +57,8 @@ typedef struct FzAttnSelfDesc {
     int64_t p_frame_stride, p_head_stride, p_row_stride;
     int32_t p_frame_off;    /* p frame index of this launch's first frame                    */
     int32_t mask_frame_off; /* row_mask frame index of this launch's first frame             */
+    int64_t k_head_stride;  /* elements between heads of K: 0 = head_dim (heads interleaved in a row);
+                               lkf*head_dim with k_row_stride = head_dim for a head-major K [n][head][key][d] */
 } FzAttnSelfDesc;
 
 /* row_mask (INJECT only, may be NULL): float [frames][lq]; 1 -> the row keeps the live attention,

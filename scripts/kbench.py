@@ -8,7 +8,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fatezero_amd import kernels as K
 
 
@@ -29,6 +30,7 @@ def main():
     dev = "cuda"
     F_, heads = 8, 8
     res = {}
+    only_flash = "--flash" in sys.argv
     for (lq, c, idx) in [(4096, 320, [-1, "first"]), (4096, 320, ["mid"]), (1024, 640, [-1, "first"]), (256, 1280, [-1, "first"])]:
         d = c // heads
         n_kv = len(idx)
@@ -40,7 +42,10 @@ def main():
         flops = 4.0 * lq * (n_kv * lq) * c * F_
         ms = timeit(lambda: K.attn_self(q, k, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_FLASH))
         res[f"flash_L{lq}_d{d}_kv{n_kv}"] = {"ms": ms, "TFLOPs": flops / ms / 1e9}
-        if lq <= 1024:
+        khm = k.reshape(F_, lq, heads, d).permute(0, 2, 1, 3).contiguous()
+        ms = timeit(lambda: K.attn_self(q, None, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_FLASH, k_head_major=khm))
+        res[f"flash_L{lq}_d{d}_kv{n_kv}_kheadmajor"] = {"ms": ms, "TFLOPs": flops / ms / 1e9}
+        if lq <= 1024 and not only_flash:
             p = torch.empty(F_, heads, lq, n_kv * lq, dtype=torch.float16, device=dev)
             ms = timeit(lambda: K.attn_self(q, k, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_CAPTURE, p=p))
             res[f"capture_L{lq}_d{d}"] = {"ms": ms, "GBps_written": p.numel() * 2 / ms / 1e6, "TFLOPs": flops / ms / 1e9}
@@ -49,6 +54,9 @@ def main():
             mask = (torch.rand(F_, lq, generator=g) > 0.5).float().to(dev)
             ms = timeit(lambda: K.attn_self(q, k, vt, out, clip_len=F_, heads=heads, index_list=idx, mode=K.FZ_ATTN_INJECT, p=p, row_mask=mask))
             res[f"inject_mask_L{lq}_d{d}"] = {"ms": ms}
+    if only_flash:
+        print(json.dumps(res))
+        return res
     # cross
     for (lq, c) in [(4096, 320), (1024, 640)]:
         g = torch.Generator().manual_seed(0)

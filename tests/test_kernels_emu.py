@@ -30,6 +30,11 @@ def test_self_flash_multi_tile_and_masking():
     KC.case_attn_self(DEV, batch=1, clip=3, heads=1, d=32, lq=200, index_list=[-1, "mid", 1], mode=K.FZ_ATTN_FLASH)
 
 
+def test_self_flash_two_query_blocks_per_wave():
+    # lq >= 512 at d=40 selects the QB=2 variant (each wave owns two 32-row query blocks); 600 is not a multiple of 256
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=1, d=40, lq=600, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH)
+
+
 def test_self_own_frame_only():
     KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=64, lq=64, index_list=[], mode=K.FZ_ATTN_FLASH)
 
