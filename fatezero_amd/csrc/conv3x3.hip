@@ -1,0 +1,224 @@
+// conv3x3.hip -- 3x3 convolution of the pseudo-3D ResNet blocks as an MFMA implicit GEMM on token-major (NHWC)
+// fp16 activations.  Replaces the spatial part of PseudoConv3d.forward (resnet.py:57-64) inside
+// ResnetBlockPseudo3D / Up- / DownsamplePseudo3D (resnet.py:123-236, :335-394) with the elementwise tail fused:
+//   y[n][oy][ox][co] = sum_{ky,kx,ci} x[n][iy][ix][ci] * w[co][ky][kx][ci]  + bias[co] (+ temb[b][co]) (+ res[n][oy][ox][co])
+//   iy = oy*stride + ky - 1 (zero padded); with `upsample` the input is read through a nearest-2x upsampling
+//   (resnet.py:145) that is never materialised.
+// GEMM view: M = cout (A operand = packed weights wt[co][tap][ci], k contiguous), N = pixels (B operand = x rows,
+// k contiguous), K = 9*Cin; so both LDS tiles are [row][k] and are read with ds_read_b128, and the accumulator
+// layout (lane <-> pixel, 4 consecutive couts per register group) stages through LDS into full-row 16-byte stores.
+// Work decomposition: wave tile 64 couts x 64 pixels (2x2 MFMA 32x32x16 tiles), WM x WN waves per workgroup,
+// K step = one tap x BK channels; register prefetch + double-buffered LDS, one barrier per K step.
+#include "fz_rt.h"
+#include "../../include/fatezero_hip.h"
+
+struct ConvArgs {
+    const half_t* x;
+    const half_t* wt;    // [Cout][9][Cin]
+    const half_t* bias;  // [Cout] or null
+    const half_t* temb;  // [B][Cout] or null (added per batch element; frames_per_batch frames share a row)
+    const half_t* res;   // [N][Ho][Wo][Cout] or null
+    half_t* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout, stride, upsample, frames_per_batch;
+};
+
+template <int WM, int WN, int BK>
+struct ConvCfg {
+    static constexpr int T = 64 * WM * WN;
+    static constexpr int BCO = 64 * WM;  // couts per workgroup
+    static constexpr int BPX = 64 * WN;  // pixels per workgroup
+    static constexpr int KSTR = BK + 8;  // halves; (BK+8)/8 odd for BK = 32, 64
+    static constexpr int WCH = BCO * BK / 8;  // 16-byte chunks per weight tile
+    static constexpr int XCH = BPX * BK / 8;
+    static constexpr int WLD = (WCH + T - 1) / T;
+    static constexpr int XLD = (XCH + T - 1) / T;
+    static constexpr int STAGE = (BCO + BPX) * KSTR;
+    static constexpr int CSTR = BCO + 8;
+    static constexpr int CS = BPX * CSTR;
+    static constexpr int LDS_HALVES = (2 * STAGE > CS) ? 2 * STAGE : CS;
+};
+
+template <int WM, int WN, int BK>
+FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
+    typedef ConvCfg<WM, WN, BK> C;
+    FZ_SHARED __attribute__((aligned(16))) half_t smem[C::LDS_HALVES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int co0 = blockIdx.y * C::BCO;
+    const int64_t px0 = (int64_t)blockIdx.x * C::BPX;
+    const int64_t npix = (int64_t)a.N * a.Ho * a.Wo;
+    const int Hu = a.upsample ? a.Hi * 2 : a.Hi, Wu = a.upsample ? a.Wi * 2 : a.Wi;  // logical input extent
+
+    // per-thread pixel coordinates of the activation chunks it fetches (fixed over the K loop)
+    int xn[C::XLD], xoy[C::XLD], xox[C::XLD], xch[C::XLD];
+    bool xok[C::XLD];
+#pragma unroll
+    for (int i = 0; i < C::XLD; ++i) {
+        int id = tid + C::T * i;
+        xok[i] = id < C::XCH;
+        id = xok[i] ? id : C::XCH - 1;
+        const int64_t p = px0 + id / (BK / 8);
+        xch[i] = id % (BK / 8);
+        const int64_t pc = p < npix ? p : npix - 1;
+        xok[i] = xok[i] && p < npix;
+        xn[i] = (int)(pc / ((int64_t)a.Ho * a.Wo));
+        const int rem = (int)(pc % ((int64_t)a.Ho * a.Wo));
+        xoy[i] = rem / a.Wo;
+        xox[i] = rem % a.Wo;
+    }
+    const int kchunks = a.Cin / BK;
+    const int nk = 9 * kchunks;
+
+    half8_t wreg[C::WLD], xreg[C::XLD];
+    bool xz[C::XLD];
+    auto fetch = [&](int ks) {
+        const int tap = ks / kchunks, c0 = (ks % kchunks) * BK;
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int i = 0; i < C::WLD; ++i) {
+            int id = tid + C::T * i;
+            id = id < C::WCH ? id : C::WCH - 1;
+            int co = co0 + id / (BK / 8);
+            co = co < a.Cout ? co : a.Cout - 1;
+            wreg[i] = fz_ld_h8(a.wt + ((int64_t)co * 9 + tap) * a.Cin + c0 + (id % (BK / 8)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < C::XLD; ++i) {
+            int iy = xoy[i] * a.stride + ky - 1, ix = xox[i] * a.stride + kx - 1;
+            const bool inb = iy >= 0 && iy < Hu && ix >= 0 && ix < Wu;
+            xz[i] = !(inb && xok[i]);
+            iy = iy < 0 ? 0 : (iy >= Hu ? Hu - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= Wu ? Wu - 1 : ix);
+            if (a.upsample) {
+                iy >>= 1;
+                ix >>= 1;
+            }
+            xreg[i] = fz_ld_h8(a.x + (((int64_t)xn[i] * a.Hi + iy) * a.Wi + ix) * a.Cin + c0 + xch[i] * 8);
+        }
+    };
+    auto stash = [&](int st) {
+        half_t* Ws = smem + st * C::STAGE;
+        half_t* Xs = Ws + C::BCO * C::KSTR;
+#pragma unroll
+        for (int i = 0; i < C::WLD; ++i) {
+            const int id = tid + C::T * i;
+            if (id < C::WCH) {
+                const bool okc = co0 + id / (BK / 8) < a.Cout;
+                fz_st_h8(Ws + (id / (BK / 8)) * C::KSTR + (id % (BK / 8)) * 8, okc ? wreg[i] : fz_zero_h8());
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::XLD; ++i) {
+            const int id = tid + C::T * i;
+            if (id < C::XCH)
+                fz_st_h8(Xs + (id / (BK / 8)) * C::KSTR + (id % (BK / 8)) * 8, xz[i] ? fz_zero_h8() : xreg[i]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = fz_zero_f16v();
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) fetch(ks + 1);
+        const half_t* Ws = smem + cur * C::STAGE + (wm * 64 + l31) * C::KSTR + 8 * hi;
+        const half_t* Xs = smem + cur * C::STAGE + C::BCO * C::KSTR + (wn * 64 + l31) * C::KSTR + 8 * hi;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            half8_t wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = fz_ld_h8(Ws + i * 32 * C::KSTR + 16 * kk);
+                xf[i] = fz_ld_h8(Xs + i * 32 * C::KSTR + 16 * kk);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = fz_mfma_32x32x16_f16(wf[i], xf[j], acc[i][j]);
+        }
+        if (ks + 1 < nk) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C^T tile -> LDS [pixel][cout] -> bias / temb / residual -> 16-byte row stores ----------------
+    half_t* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)      // cout tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j)  // pixel tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)acc[i][j][4 * g + e];
+                *reinterpret_cast<half4_t*>(Cs + (wn * 64 + j * 32 + l31) * C::CSTR + wm * 64 + i * 32 + 8 * g + 4 * hi) = v;
+            }
+    __syncthreads();
+    constexpr int OCH = C::BCO / 8;
+    for (int id = tid; id < C::BPX * OCH; id += C::T) {
+        const int pl = id / OCH, ch = id % OCH;
+        const int64_t p = px0 + pl;
+        const int co = co0 + ch * 8;
+        if (p < npix && co < a.Cout) {
+            half8_t v = fz_ld_h8(Cs + pl * C::CSTR + ch * 8);
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+            if (a.bias != nullptr) {
+                const half8_t b = fz_ld_h8(a.bias + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += (float)b[e];
+            }
+            if (a.temb != nullptr) {
+                const int n = (int)(p / ((int64_t)a.Ho * a.Wo));
+                const half8_t t = fz_ld_h8(a.temb + (int64_t)(n / a.frames_per_batch) * a.Cout + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += (float)t[e];
+            }
+            if (a.res != nullptr) {
+                const half8_t r = fz_ld_h8(a.res + p * a.Cout + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)f[e];
+            fz_st_h8(a.y + p * a.Cout + co, v);
+        }
+    }
+}
+
+template <int WM, int WN, int BK>
+static int launch_conv(const ConvArgs& a, void* stream) {
+    typedef ConvCfg<WM, WN, BK> C;
+    const int64_t npix = (int64_t)a.N * a.Ho * a.Wo;
+    dim3 grid((unsigned)((npix + C::BPX - 1) / C::BPX), (a.Cout + C::BCO - 1) / C::BCO), block(C::T);
+    FZ_LAUNCH((conv3x3_kernel<WM, WN, BK>), grid, block, 0, stream, a);
+    return fz_last_launch_status();
+}
+
+extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, const void* res, void* y,
+                          int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
+                          void* stream) {
+    if (!x || !wt || !y || n <= 0 || hi <= 0 || wi <= 0) return FZ_ERR_BAD_ARG;
+    if (cin % 32 || cout % 8 || (stride != 1 && stride != 2) || (upsample && stride != 1)) return FZ_ERR_UNSUPPORTED;
+    ConvArgs a;
+    a.x = (const half_t*)x; a.wt = (const half_t*)wt; a.bias = (const half_t*)bias; a.temb = (const half_t*)temb;
+    a.res = (const half_t*)res; a.y = (half_t*)y;
+    a.N = n; a.Hi = hi; a.Wi = wi; a.Cin = cin; a.Cout = cout; a.stride = stride; a.upsample = upsample;
+    a.frames_per_batch = frames_per_batch > 0 ? frames_per_batch : 1;
+    const int hu = upsample ? 2 * hi : hi, wu = upsample ? 2 * wi : wi;
+    a.Ho = (hu + 2 - 3) / stride + 1;
+    a.Wo = (wu + 2 - 3) / stride + 1;
+    const int64_t npix = (int64_t)n * a.Ho * a.Wo;
+    const bool k64 = (cin % 64) == 0;
+    // 128 couts x 128 pixels per workgroup when that still yields >= ~2 workgroups per CU, else 64 x 128
+    const int64_t big_blocks = ((npix + 127) / 128) * ((cout + 127) / 128);
+    if (big_blocks >= 512 && cout % 128 == 0) return k64 ? launch_conv<2, 2, 64>(a, stream) : launch_conv<2, 2, 32>(a, stream);
+    return k64 ? launch_conv<1, 2, 64>(a, stream) : launch_conv<1, 2, 32>(a, stream);
+}

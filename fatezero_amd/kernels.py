@@ -210,6 +210,33 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span:
     return out
 
 
+def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d weight [Cout, Cin, 3, 3] -> [Cout, 9, Cin] fp16 (k = tap*Cin + ci contiguous per cout)."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).to(torch.float16).contiguous()
+
+
+def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, hw: Tuple[int, int], stride: int = 1,
+            upsample: bool = False, temb: Optional[torch.Tensor] = None, frames_per_batch: int = 1,
+            res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """x: [N, H*W, Cin] token-major fp16 -> [N, Ho*Wo, Cout]."""
+    n, _, cin = x.shape
+    h, w = hw
+    cout = wt.shape[0]
+    assert x.is_contiguous() and wt.is_contiguous() and tuple(wt.shape[1:]) == (9, cin)
+    _chk16(x, wt, bias, temb, res)
+    hu, wu = (2 * h, 2 * w) if upsample else (h, w)
+    ho, wo = (hu - 1) // stride + 1, (wu - 1) // stride + 1
+    if out is None:
+        out = torch.empty(n, ho * wo, cout, dtype=torch.float16, device=x.device)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == out.shape
+    if temb is not None:
+        assert temb.is_contiguous() and temb.shape == (n // frames_per_batch, cout)
+    N.check(N.lib().fz_conv3x3(_ptr(x), _ptr(wt), _ptr(bias), _ptr(temb), _ptr(res), _ptr(out), n, h, w, cin, cout, stride,
+                               1 if upsample else 0, frames_per_batch, _stream(x)), "fz_conv3x3")
+    return out, (ho, wo)
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):
     c = x.shape[-1]
     assert x.is_contiguous()

@@ -117,6 +117,14 @@ int fz_groupnorm_chunks(int tokens, int channels);
 int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
                  int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream);
 
+/* 3x3 convolution (pad 1) of PseudoConv3d's spatial part (resnet.py:57-64) on token-major activations, as an MFMA
+ * implicit GEMM with the elementwise tail fused: y = conv(x) + bias (+ temb[n / frames_per_batch]) (+ res).
+ * x: [n][hi][wi][cin]; wt: weights packed [cout][3*3][cin]; y / res: [n][ho][wo][cout]; temb: [n/frames_per_batch][cout].
+ * stride 1 or 2; upsample != 0 reads x through a nearest-2x upsampling (UpsamplePseudo3D, resnet.py:145) without
+ * materialising it.  cin % 32 == 0, cout % 8 == 0. */
+int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, const void* res, void* y, int n,
+               int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch, void* stream);
+
 /* LayerNorm over channels, rows = tokens (attention.py:193-233). gamma/beta fp16. */
 int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,
                  float eps, void* stream);

@@ -26,7 +26,38 @@ def timeit(fn, iters=10, warm=3):
     return st.elapsed_time(en) / iters
 
 
+def conv_bench():
+    import torch.nn.functional as F
+    dev = "cuda"
+    res = {}
+    shapes = [(8, 64, 320, 320, 1, False), (8, 64, 960, 320, 1, False), (8, 64, 640, 320, 1, False), (8, 32, 640, 640, 1, False),
+              (8, 32, 1920, 640, 1, False), (8, 16, 1280, 1280, 1, False), (8, 16, 2560, 1280, 1, False), (8, 8, 1280, 1280, 1, False),
+              (8, 64, 320, 320, 2, False), (8, 32, 640, 640, 1, True), (16, 64, 320, 320, 1, False), (16, 16, 1280, 1280, 1, False)]
+    for (n, hw, cin, cout, stride, up) in shapes:
+        x = torch.randn(n, hw * hw, cin).half().to(dev)
+        w = (torch.randn(cout, cin, 3, 3) * 0.02).half().to(dev)
+        b = torch.zeros(cout).half().to(dev)
+        wt = K.pack_conv3x3_weight(w)
+        wcl = w.contiguous(memory_format=torch.channels_last)
+        ho = (2 * hw if up else hw)
+        ho = (ho - 1) // stride + 1
+        flops = 2.0 * n * ho * ho * cout * cin * 9
+
+        def mi():
+            xi = x.view(n, hw, hw, cin).permute(0, 3, 1, 2)
+            if up:
+                xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+            return F.conv2d(xi, wcl, b, stride=stride, padding=1)
+        ms_mi = timeit(mi)
+        ms_fz = timeit(lambda: K.conv3x3(x, wt, b, hw=(hw, hw), stride=stride, upsample=up))
+        res[f"conv_n{n}_hw{hw}_{cin}to{cout}_s{stride}_u{int(up)}"] = {"miopen_ms": ms_mi, "fz_ms": ms_fz, "miopen_TF": flops / ms_mi / 1e9,
+                                                                    "fz_TF": flops / ms_fz / 1e9}
+    print(json.dumps(res, indent=1))
+
+
 def main():
+    if "--conv" in sys.argv:
+        return conv_bench()
     dev = "cuda"
     F_, heads = 8, 8
     res = {}

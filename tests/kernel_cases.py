@@ -307,3 +307,29 @@ def case_blend_mask(device, *, prompts, frames, heads, res, out_hw, or_first, th
     assert 0.02 < frac < 0.98, f"degenerate mask ({frac})"
     assert diff == 0, f"{diff} differing mask elements"
     return {"ones": frac}
+
+
+def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_temb=False, with_res=False, fpb=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, h * w, cin, generator=g).half().to(device)
+    wgt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    bias = (torch.randn(cout, generator=g) * 0.1).half().to(device)
+    temb = (torch.randn(n // fpb, cout, generator=g)).half().to(device) if with_temb else None
+    wt = K.pack_conv3x3_weight(wgt).to(device)
+    xi = x.float().cpu().reshape(n, h, w, cin).permute(0, 3, 1, 2)
+    if upsample:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    yr = F.conv2d(xi, wgt.float(), bias.float().cpu(), stride=stride, padding=1)
+    ho, wo = yr.shape[2], yr.shape[3]
+    res = torch.randn(n, ho * wo, cout, generator=g).half().to(device) if with_res else None
+    y, (ho2, wo2) = K.conv3x3(x, wt, bias, hw=(h, w), stride=stride, upsample=upsample, temb=temb, frames_per_batch=fpb, res=res)
+    assert (ho2, wo2) == (ho, wo)
+    yr = yr.permute(0, 2, 3, 1).reshape(n, ho * wo, cout)
+    if with_temb:
+        yr = yr + temb.float().cpu().repeat_interleave(fpb, 0)[:, None, :]
+    if with_res:
+        yr = yr + res.float().cpu()
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert torch.isfinite(y.float()).all()
+    assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err}

@@ -85,3 +85,10 @@ def test_layernorm_geglu_transpose_latent():
                                                          (16, (64, 64), 2, True), (18, (36, 36), 1, False)])
 def test_blend_mask_bit_exact(res, out_hw, prompts, or_first):
     KC.case_blend_mask(DEV, prompts=prompts, frames=2, heads=2, res=res, out_hw=out_hw, or_first=or_first)
+
+
+@pytest.mark.parametrize("kw", [dict(n=2, h=8, w=8, cin=32, cout=64), dict(n=2, h=6, w=10, cin=64, cout=40, with_temb=True, fpb=2),
+                                dict(n=1, h=8, w=8, cin=96, cout=128, stride=2, with_res=True),
+                                dict(n=2, h=4, w=4, cin=64, cout=64, upsample=True, with_temb=True, with_res=True)])
+def test_conv3x3(kw):
+    KC.case_conv3x3(DEV, **kw)

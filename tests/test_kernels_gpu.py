@@ -85,3 +85,14 @@ def test_layernorm_geglu_transpose_latent():
 def test_blend_mask_bit_exact(res, out_hw, prompts, or_first):
     for seed in range(4):
         KC.case_blend_mask(DEV, prompts=prompts, frames=8, heads=8, res=res, out_hw=out_hw, or_first=or_first, seed=seed)
+
+
+@pytest.mark.parametrize("kw", [dict(n=8, h=64, w=64, cin=320, cout=320, with_temb=True, fpb=8),
+                                dict(n=2, h=64, w=64, cin=960, cout=320, with_res=True),
+                                dict(n=4, h=32, w=32, cin=640, cout=640, stride=2),
+                                dict(n=4, h=16, w=16, cin=1280, cout=1280, upsample=True),
+                                dict(n=2, h=8, w=8, cin=2560, cout=1280, with_temb=True, with_res=True, fpb=2),
+                                dict(n=3, h=9, w=9, cin=96, cout=40)])
+def test_conv3x3(kw):
+    r = KC.case_conv3x3(DEV, **kw)
+    print(kw, r)
