@@ -14,12 +14,15 @@
 
 struct ConvArgs {
     const half_t* x;
-    const half_t* wt;    // [Cout][9][Cin]
+    const half_t* wt;    // [Cout][taps][Cin]
     const half_t* bias;  // [Cout] or null
     const half_t* temb;  // [B][Cout] or null (added per batch element; frames_per_batch frames share a row)
     const half_t* res;   // [N][Ho][Wo][Cout] or null
+    const half_t* res2;  // second residual, same layout, or null
     half_t* y;
+    int64_t temb_stride; // elements between the temb rows of consecutive batch elements
     int N, Hi, Wi, Cin, Ho, Wo, Cout, stride, upsample, frames_per_batch;
+    int temporal;  // != 0: 3 taps along the FRAME axis (k=3, zero padded inside each clip of frames_per_batch frames)
 };
 
 template <int WM, int WN, int BK>
@@ -67,7 +70,8 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
         xox[i] = rem % a.Wo;
     }
     const int kchunks = a.Cin / BK;
-    const int nk = 9 * kchunks;
+    const int ntaps = a.temporal ? 3 : 9;
+    const int nk = ntaps * kchunks;
 
     half8_t wreg[C::WLD], xreg[C::XLD];
     bool xz[C::XLD];
@@ -80,7 +84,19 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
             id = id < C::WCH ? id : C::WCH - 1;
             int co = co0 + id / (BK / 8);
             co = co < a.Cout ? co : a.Cout - 1;
-            wreg[i] = fz_ld_h8(a.wt + ((int64_t)co * 9 + tap) * a.Cin + c0 + (id % (BK / 8)) * 8);
+            wreg[i] = fz_ld_h8(a.wt + ((int64_t)co * ntaps + tap) * a.Cin + c0 + (id % (BK / 8)) * 8);
+        }
+        if (a.temporal) {
+#pragma unroll
+            for (int i = 0; i < C::XLD; ++i) {
+                const int f = xn[i] % a.frames_per_batch;
+                int fs = f + tap - 1;
+                xz[i] = !(fs >= 0 && fs < a.frames_per_batch && xok[i]);
+                fs = fs < 0 ? 0 : (fs >= a.frames_per_batch ? a.frames_per_batch - 1 : fs);
+                const int ns = xn[i] - f + fs;
+                xreg[i] = fz_ld_h8(a.x + (((int64_t)ns * a.Hi + xoy[i]) * a.Wi + xox[i]) * a.Cin + c0 + xch[i] * 8);
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < C::XLD; ++i) {
@@ -177,12 +193,17 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
             }
             if (a.temb != nullptr) {
                 const int n = (int)(p / ((int64_t)a.Ho * a.Wo));
-                const half8_t t = fz_ld_h8(a.temb + (int64_t)(n / a.frames_per_batch) * a.Cout + co);
+                const half8_t t = fz_ld_h8(a.temb + (int64_t)(n / a.frames_per_batch) * a.temb_stride + co);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += (float)t[e];
             }
             if (a.res != nullptr) {
                 const half8_t r = fz_ld_h8(a.res + p * a.Cout + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+            }
+            if (a.res2 != nullptr) {
+                const half8_t r = fz_ld_h8(a.res2 + p * a.Cout + co);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
             }
@@ -202,23 +223,65 @@ static int launch_conv(const ConvArgs& a, void* stream) {
     return fz_last_launch_status();
 }
 
-extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, const void* res, void* y,
-                          int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
-                          void* stream) {
+#include <stdlib.h>
+#include <stdio.h>
+static int conv_cfg_override() {  // tuning knob FZ_CONV_CFG=<wm><wn><bk/32> e.g. 122 = (1,2,64); 0 = heuristic
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_CONV_CFG");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+static int dispatch_conv(const ConvArgs& a, void* stream) {
+    const bool k64 = (a.Cin % 64) == 0;
+    const int64_t npix = (int64_t)a.N * a.Ho * a.Wo;
+    int cfg = conv_cfg_override();
+    if (cfg == 0) {
+        cfg = npix >= 16384 ? 221 : 222;  // measured on MI355X (scripts/kbench.py --conv)
+    }
+    if (!k64 && (cfg % 10) == 2) cfg -= 1;
+    switch (cfg) {
+        case 121: return launch_conv<1, 2, 32>(a, stream);
+        case 122: return launch_conv<1, 2, 64>(a, stream);
+        case 141: return launch_conv<1, 4, 32>(a, stream);
+        case 142: return launch_conv<1, 4, 64>(a, stream);
+        case 221: return launch_conv<2, 2, 32>(a, stream);
+        case 222: return launch_conv<2, 2, 64>(a, stream);
+        case 241: return launch_conv<2, 4, 32>(a, stream);
+        default: return FZ_ERR_BAD_ARG;
+    }
+}
+
+extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
+                                int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len,
+                                void* stream) {
+    if (!x || !wt || !y || n <= 0 || tokens <= 0 || clip_len <= 0 || n % clip_len) return FZ_ERR_BAD_ARG;
+    if (cin % 32 || cout % 8) return FZ_ERR_UNSUPPORTED;
+    ConvArgs a;
+    a.x = (const half_t*)x; a.wt = (const half_t*)wt; a.bias = nullptr; a.temb = (const half_t*)temb;
+    a.temb_stride = temb_stride ? temb_stride : cout;
+    a.res = (const half_t*)res; a.res2 = (const half_t*)res2; a.y = (half_t*)y;
+    a.N = n; a.Hi = 1; a.Wi = tokens; a.Cin = cin; a.Cout = cout; a.stride = 1; a.upsample = 0;
+    a.frames_per_batch = clip_len; a.temporal = 1; a.Ho = 1; a.Wo = tokens;
+    return dispatch_conv(a, stream);
+}
+
+extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride,
+                          const void* res, void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample,
+                          int frames_per_batch, void* stream) {
     if (!x || !wt || !y || n <= 0 || hi <= 0 || wi <= 0) return FZ_ERR_BAD_ARG;
     if (cin % 32 || cout % 8 || (stride != 1 && stride != 2) || (upsample && stride != 1)) return FZ_ERR_UNSUPPORTED;
     ConvArgs a;
     a.x = (const half_t*)x; a.wt = (const half_t*)wt; a.bias = (const half_t*)bias; a.temb = (const half_t*)temb;
-    a.res = (const half_t*)res; a.y = (half_t*)y;
+    a.res = (const half_t*)res; a.res2 = nullptr; a.y = (half_t*)y;
+    a.temb_stride = temb_stride ? temb_stride : cout;
     a.N = n; a.Hi = hi; a.Wi = wi; a.Cin = cin; a.Cout = cout; a.stride = stride; a.upsample = upsample;
     a.frames_per_batch = frames_per_batch > 0 ? frames_per_batch : 1;
+    a.temporal = 0;
     const int hu = upsample ? 2 * hi : hi, wu = upsample ? 2 * wi : wi;
     a.Ho = (hu + 2 - 3) / stride + 1;
     a.Wo = (wu + 2 - 3) / stride + 1;
-    const int64_t npix = (int64_t)n * a.Ho * a.Wo;
-    const bool k64 = (cin % 64) == 0;
-    // 128 couts x 128 pixels per workgroup when that still yields >= ~2 workgroups per CU, else 64 x 128
-    const int64_t big_blocks = ((npix + 127) / 128) * ((cout + 127) / 128);
-    if (big_blocks >= 512 && cout % 128 == 0) return k64 ? launch_conv<2, 2, 64>(a, stream) : launch_conv<2, 2, 32>(a, stream);
-    return k64 ? launch_conv<1, 2, 64>(a, stream) : launch_conv<1, 2, 32>(a, stream);
+    return dispatch_conv(a, stream);
 }

@@ -17,9 +17,19 @@ CROSS_KEYS = N.FZ_CROSS_MAX_KEYS
 SUPPORTED_HEAD_DIMS = (16, 32, 40, 64, 80, 128, 160)
 
 
+_stream_cache = {"handle": None}
+
+
+def refresh_stream():
+    """Re-read PyTorch's current HIP stream (call when the caller switches streams; the pipelines do it per forward)."""
+    _stream_cache["handle"] = C.c_void_p(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else None
+
+
 def _stream(t: torch.Tensor):
     if t.is_cuda:
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        if _stream_cache["handle"] is None:
+            refresh_stream()
+        return _stream_cache["handle"]
     if not N.is_test_backend():
         raise RuntimeError("fatezero_amd kernels run on the GPU only (CPU tensors are accepted only by the "
                            "emulation backend used in tests)")
@@ -230,11 +240,34 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, 
         out = torch.empty(n, ho * wo, cout, dtype=torch.float16, device=x.device)
     if res is not None:
         assert res.is_contiguous() and res.shape == out.shape
+    ts = 0
     if temb is not None:
-        assert temb.is_contiguous() and temb.shape == (n // frames_per_batch, cout)
-    N.check(N.lib().fz_conv3x3(_ptr(x), _ptr(wt), _ptr(bias), _ptr(temb), _ptr(res), _ptr(out), n, h, w, cin, cout, stride,
+        assert temb.shape == (n // frames_per_batch, cout) and temb.stride(1) == 1
+        ts = temb.stride(0)
+    N.check(N.lib().fz_conv3x3(_ptr(x), _ptr(wt), _ptr(bias), _ptr(temb), ts, _ptr(res), _ptr(out), n, h, w, cin, cout, stride,
                                1 if upsample else 0, frames_per_batch, _stream(x)), "fz_conv3x3")
     return out, (ho, wo)
+
+
+def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Optional[torch.Tensor] = None,
+                   res2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, out=None):
+    """x: [N, tokens, Cin]; wt: [Cout, 3, Cin] (nn.Conv1d weight [Cout, Cin, 3] permuted); -> [N, tokens, Cout] (+res)."""
+    n, tokens, cin = x.shape
+    cout = wt.shape[0]
+    assert x.is_contiguous() and wt.is_contiguous() and tuple(wt.shape[1:]) == (3, cin)
+    _chk16(x, wt, res)
+    if out is None:
+        out = torch.empty(n, tokens, cout, dtype=torch.float16, device=x.device)
+    for r in (res, res2):
+        if r is not None:
+            assert r.is_contiguous() and r.shape == out.shape and r.dtype == torch.float16
+    ts = 0
+    if temb is not None:
+        assert temb.shape == (n // clip_len, cout) and temb.stride(1) == 1 and temb.dtype == torch.float16
+        ts = temb.stride(0)
+    N.check(N.lib().fz_temporal_conv3(_ptr(x), _ptr(wt), _ptr(res), _ptr(res2), _ptr(temb), ts, _ptr(out), n, tokens, cin, cout,
+                                      clip_len, _stream(x)), "fz_temporal_conv3")
+    return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):

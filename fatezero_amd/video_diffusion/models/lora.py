@@ -8,6 +8,8 @@ reference's (`down.weight [r, C, 3]`, `up.weight [C, r, 3]`) so checkpoints load
 import torch
 from torch import nn
 
+from ... import kernels as K
+
 
 class _Conv1dParams(nn.Module):
     def __init__(self, cin, cout, k, bias=False):
@@ -59,16 +61,43 @@ class LoRALinearLayer(nn.Module):
 
     def _pack(self, dtype, device):
         if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
-            wd = self.down.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()  # [3, C, r]
-            wu = self.up.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()    # [3, r, C]
+            dw, uw = self.down.weight.detach(), self.up.weight.detach()
+            rank, cin = dw.shape[0], dw.shape[1]
+            cout = uw.shape[0]
             is_noop = bool((self.up.weight == 0).all())  # un-tuned SD: up == 0 -> exact identity
-            self._packed = (wd, wu, is_noop)
+            native = (rank % 32 == 0 and cin % 32 == 0 and cout % 8 == 0 and dtype == torch.float16)
+            if native:  # [Cout][3][Cin] packing of the implicit-GEMM kernel (fz_temporal_conv3)
+                wd = dw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous()
+                wu = uw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous()
+            else:       # tiny ranks (e.g. conv_out's rank 2): three small library GEMMs over shifted frame views
+                wd = dw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()  # [3, C, r]
+                wu = uw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()  # [3, r, C]
+            self._packed = (wd, wu, is_noop, native)
         return self._packed
 
-    def forward_tokens(self, x4):
-        """x4: [B, F, T, C] -> same shape."""
-        wd, wu, is_noop = self._pack(x4.dtype, x4.device)
+    def is_noop(self, dtype, device):
+        return self._pack(dtype, device)[2]
+
+    def forward_tokens(self, x4, temb=None, residual=None):
+        """x4: [B, F, T, C] -> up(down(x)) + x (+ temb[b] broadcast) (+ residual), same shape."""
+        wd, wu, is_noop, native = self._pack(x4.dtype, x4.device)
+        b, f, t, c = x4.shape
         if is_noop:
-            return x4
+            y = x4
+            if temb is not None:
+                y = y + temb[:, None, None, :]
+            if residual is not None:
+                y = y + residual.view(b, f, t, c)
+            return y
+        if native:
+            x3 = x4.reshape(b * f, t, c)
+            d = K.temporal_conv3(x3, wd, clip_len=f)
+            y = K.temporal_conv3(d, wu, clip_len=f, res=x3, res2=residual, temb=temb)
+            return y.view(b, f, t, c)
         d = temporal_conv_tokens(x4, wd)
-        return temporal_conv_tokens(d, wu, residual=x4)
+        y = temporal_conv_tokens(d, wu, residual=x4)
+        if temb is not None:
+            y = y + temb[:, None, None, :]
+        if residual is not None:
+            y = y + residual.view(b, f, t, c)
+        return y

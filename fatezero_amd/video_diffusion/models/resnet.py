@@ -63,41 +63,67 @@ class PseudoConv3d(nn.Module):
             self.conv_temporal = None
         self._packed = None
 
+    # The hand-written implicit-GEMM kernel (fz_conv3x3) is used where it beats MIOpen's NHWC igemm on MI355X
+    # (scripts/kbench.py --conv): the 64x64-latent level (>= 4096 tokens per frame) and every upsample conv (the nearest
+    # 2x is folded into its addressing).  Elsewhere the conv runs through MIOpen on a channels-last view.
+    NATIVE_MIN_TOKENS = 4096
+
     def _pack(self, dtype, device):
         if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
             w = self.weight.detach().to(device=device, dtype=dtype)
+            wt = None
             if self.kernel_size == 1:
                 w = w.reshape(self.out_channels, self.in_channels).contiguous()
             else:
+                if self.in_channels % 32 == 0 and self.out_channels % 8 == 0 and dtype == torch.float16:
+                    wt = K.pack_conv3x3_weight(w)
                 w = w.contiguous(memory_format=torch.channels_last)
             bias = self.bias.detach().to(device=device, dtype=dtype)
-            wt = bt = None
+            wtt = btt = None
             if self.conv_temporal is not None and not isinstance(self.conv_temporal, LoRALinearLayer):
-                wt = self.conv_temporal.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
-                bt = self.conv_temporal.bias.detach().to(device=device, dtype=dtype)
-            self._packed = (w, bias, wt, bt)
+                wtt = self.conv_temporal.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
+                btt = self.conv_temporal.bias.detach().to(device=device, dtype=dtype)
+            self._packed = (w, bias, wtt, btt, wt)
         return self._packed
 
-    def forward_tokens(self, x: Tokens, residual=None) -> Tokens:
-        w, bias, wt, bt = self._pack(x.data.dtype, x.data.device)
+    def forward_tokens(self, x: Tokens, residual=None, temb=None, upsample=False) -> Tokens:
+        """conv (+ temporal conv) (+ temb[b] per batch element) (+ residual). temb: [B, Cout] view, residual: [N, T, Cout]."""
+        w, bias, wtt, btt, wt = self._pack(x.data.dtype, x.data.device)
         n, hw, c = x.data.shape
+        lora = self.conv_temporal if isinstance(self.conv_temporal, LoRALinearLayer) else None
+        plain_t = self.conv_temporal is not None and lora is None
+        temporal_active = plain_t or (lora is not None and not lora.is_noop(x.data.dtype, x.data.device))
         if self.kernel_size == 1:
             y = F.linear(x.data, w, bias)
             oh, ow = x.h, x.w
+            fused = False
         else:
-            xi = x.data.view(n, x.h, x.w, c).permute(0, 3, 1, 2)  # NCHW view of NHWC memory (channels_last)
-            yo = F.conv2d(xi, w, bias, stride=self.stride, padding=self.padding)
-            oh, ow = yo.shape[2], yo.shape[3]
-            y = yo.permute(0, 2, 3, 1).reshape(n, oh * ow, self.out_channels)
-        if self.conv_temporal is not None:
-            y4 = y.view(x.b, x.f, oh * ow, self.out_channels)
-            if isinstance(self.conv_temporal, LoRALinearLayer):
-                y4 = self.conv_temporal.forward_tokens(y4)
+            native = wt is not None and (upsample or hw >= self.NATIVE_MIN_TOKENS) and x.data.is_contiguous()
+            if native:
+                fuse_tail = not temporal_active  # the elementwise tail commutes with nothing but the last linear op
+                y, (oh, ow) = K.conv3x3(x.data, wt, bias, hw=(x.h, x.w), stride=self.stride, upsample=upsample,
+                                        temb=temb if fuse_tail else None, frames_per_batch=x.f,
+                                        res=residual if fuse_tail else None)
+                fused = fuse_tail
             else:
-                y4 = temporal_conv_tokens(y4, wt, bias=bt)
+                xin = upsample_nearest2x(x) if upsample else x
+                xi = xin.data.view(n, xin.h, xin.w, c).permute(0, 3, 1, 2)  # NCHW view of NHWC memory (channels_last)
+                yo = F.conv2d(xi, w, bias, stride=self.stride, padding=self.padding)
+                oh, ow = yo.shape[2], yo.shape[3]
+                y = yo.permute(0, 2, 3, 1).reshape(n, oh * ow, self.out_channels)
+                fused = False
+        if lora is not None and temporal_active:
+            y4 = lora.forward_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), temb=temb, residual=residual)
             y = y4.reshape(n, oh * ow, self.out_channels)
-        if residual is not None:
-            y = y + residual
+            fused = True
+        elif plain_t:
+            y4 = temporal_conv_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), wtt, bias=btt)
+            y = y4.reshape(n, oh * ow, self.out_channels)
+        if not fused:
+            if temb is not None:
+                y = (y.view(x.b, x.f * oh * ow, self.out_channels) + temb[:, None, :]).view(n, oh * ow, self.out_channels)
+            if residual is not None:
+                y = y + residual
         return x.like(y, oh, ow)
 
 
@@ -141,7 +167,7 @@ class UpsamplePseudo3D(nn.Module):
         self.conv = PseudoConv3d(self.channels, self.out_channels, 3, padding=1, model_config=model_config)
 
     def forward_tokens(self, x: Tokens) -> Tokens:
-        return self.conv.forward_tokens(upsample_nearest2x(x))
+        return self.conv.forward_tokens(x, upsample=True)
 
 
 class DownsamplePseudo3D(nn.Module):
@@ -195,13 +221,15 @@ class ResnetBlockPseudo3D(nn.Module):
             self.conv_shortcut = PseudoConv3d(in_channels, out_channels, kernel_size=1, stride=1, padding=0,
                                               model_config=model_config)
 
-    def forward_tokens(self, x: Tokens, temb_act) -> Tokens:
-        """temb_act = silu(temb) [B, temb_channels] fp16."""
+    def forward_tokens(self, x: Tokens, temb_act, temb_proj=None) -> Tokens:
+        """temb_act = silu(temb) [B, temb_channels] fp16; temb_proj (optional) = this block's time_emb_proj output
+        [B, Cout] precomputed by the UNet in one batched GEMM."""
         h = group_norm_tokens(self.norm1, x, span_frames=True, silu=True)
-        h = self.conv1.forward_tokens(h)
-        t = self.time_emb_proj.apply(temb_act)  # [B, Cout]
-        hd = h.data.view(x.b, x.f * h.data.shape[1], self.out_channels)
-        hd += t[:, None, :]
+        if temb_proj is None:
+            temb_proj = getattr(self, "_temb_cached", None)  # set by the UNet: all blocks' projections in one GEMM
+            self._temb_cached = None
+        t = temb_proj if temb_proj is not None else self.time_emb_proj.apply(temb_act)  # [B, Cout]
+        h = self.conv1.forward_tokens(h, temb=t)
         h = group_norm_tokens(self.norm2, h, span_frames=True, silu=True)
         skip = x if self.conv_shortcut is None else self.conv_shortcut.forward_tokens(x)
         out = self.conv2.forward_tokens(h, residual=skip.data)

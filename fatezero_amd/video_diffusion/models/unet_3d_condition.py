@@ -110,6 +110,7 @@ class UNetPseudo3DConditionModel(nn.Module):
         return next(self.parameters()).dtype
 
     def invalidate_packed(self):
+        self._temb_pack = None
         for m in self.modules():
             for a in ("_packed", "_qk", "_qkv"):
                 if hasattr(m, a):
@@ -135,9 +136,31 @@ class UNetPseudo3DConditionModel(nn.Module):
         e = self.time_embedding.linear_2.apply(F.silu(self.time_embedding.linear_1.apply(e)))
         return F.silu(e)
 
+    def _project_time_embeddings(self, temb_act):
+        """All 22 `time_emb_proj` Linear layers of the ResNet blocks as ONE GEMM (they only depend on the timestep)."""
+        pk = getattr(self, "_temb_pack", None)
+        if pk is None or pk[0].device != temb_act.device:
+            from .resnet import ResnetBlockPseudo3D
+            blocks = [m for m in self.modules() if isinstance(m, ResnetBlockPseudo3D)]
+            w = torch.cat([b.time_emb_proj.weight.detach() for b in blocks], 0).to(device=temb_act.device, dtype=torch.float16)
+            bias = torch.cat([b.time_emb_proj.bias.detach() for b in blocks], 0).to(device=temb_act.device, dtype=torch.float16)
+            offs, o = [], 0
+            for b in blocks:
+                offs.append((o, b.out_channels))
+                o += b.out_channels
+            pk = (w.contiguous(), bias, blocks, offs)
+            self._temb_pack = pk
+        w, bias, blocks, offs = pk
+        t_all = F.linear(temb_act, w, bias)  # [B, sum Cout]
+        for b, (o, c) in zip(blocks, offs):
+            b._temb_cached = t_all[:, o:o + c]
+
     def forward_tokens(self, x: Tokens, timestep, ctx) -> Tokens:
         """x: latents as tokens [B*F, H*W, 4] fp16; ctx [B, 77, D] fp16 -> predicted noise, same layout."""
+        from ... import kernels as K
+        K.refresh_stream()
         temb_act = self.time_embed(timestep, x.b, x.data.device)
+        self._project_time_embeddings(temb_act)
         ctx = ctx.to(torch.float16)
         x = self.conv_in.forward_tokens(x)
         skips = [x]

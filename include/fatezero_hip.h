@@ -119,11 +119,21 @@ int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, in
 
 /* 3x3 convolution (pad 1) of PseudoConv3d's spatial part (resnet.py:57-64) on token-major activations, as an MFMA
  * implicit GEMM with the elementwise tail fused: y = conv(x) + bias (+ temb[n / frames_per_batch]) (+ res).
- * x: [n][hi][wi][cin]; wt: weights packed [cout][3*3][cin]; y / res: [n][ho][wo][cout]; temb: [n/frames_per_batch][cout].
+ * x: [n][hi][wi][cin]; wt: weights packed [cout][3*3][cin]; y / res: [n][ho][wo][cout]; temb: n/frames_per_batch rows of
+ * cout values, temb_stride elements apart.
  * stride 1 or 2; upsample != 0 reads x through a nearest-2x upsampling (UpsamplePseudo3D, resnet.py:145) without
  * materialising it.  cin % 32 == 0, cout % 8 == 0. */
-int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, const void* res, void* y, int n,
-               int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch, void* stream);
+int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
+               void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
+               void* stream);
+
+/* Temporal k=3 convolution over the frame axis (the two Conv1d of LoRALinearLayer, lora.py:31-54, applied on
+ * '(b h w) c f'): y[n][tok][co] = sum_{t=0..2, ci} x[n - f + (f+t-1)][tok][ci] * wt[co][t][ci] (+ res), zero padded at the
+ * clip ends (f = n % clip_len).  x: [n][tokens][cin]; wt: [cout][3][cin]; y/res/res2: [n][tokens][cout];
+ * temb (optional): [n/clip_len] rows of cout values, temb_stride elements apart (ResnetBlock's time embedding add,
+ * resnet.py:366-376, fused behind the temporal conv). */
+int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
+                      int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len, void* stream);
 
 /* LayerNorm over channels, rows = tokens (attention.py:193-233). gamma/beta fp16. */
 int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,

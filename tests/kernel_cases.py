@@ -333,3 +333,19 @@ def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_t
     assert torch.isfinite(y.float()).all()
     assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
     return {"max_err": err}
+
+
+def case_temporal_conv3(device, *, batch, clip, tokens, cin, cout, with_res, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    n = batch * clip
+    x = torch.randn(n, tokens, cin, generator=g).half().to(device)
+    w = (torch.randn(cout, cin, 3, generator=g) * (3 * cin) ** -0.5).half()
+    res = torch.randn(n, tokens, cout, generator=g).half().to(device) if with_res else None
+    y = K.temporal_conv3(x, w.permute(0, 2, 1).contiguous().to(device), clip_len=clip, res=res)
+    xr = x.float().cpu().reshape(batch, clip, tokens, cin).permute(0, 2, 3, 1).reshape(batch * tokens, cin, clip)
+    yr = F.conv1d(xr, w.float(), None, padding=1).reshape(batch, tokens, cout, clip).permute(0, 3, 1, 2).reshape(n, tokens, cout)
+    if with_res:
+        yr = yr + res.float().cpu()
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err}

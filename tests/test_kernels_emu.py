@@ -92,3 +92,9 @@ def test_blend_mask_bit_exact(res, out_hw, prompts, or_first):
                                 dict(n=2, h=4, w=4, cin=64, cout=64, upsample=True, with_temb=True, with_res=True)])
 def test_conv3x3(kw):
     KC.case_conv3x3(DEV, **kw)
+
+
+def test_temporal_conv3():
+    KC.case_temporal_conv3(DEV, batch=2, clip=3, tokens=20, cin=64, cout=32, with_res=False)
+    KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
+    KC.case_temporal_conv3(DEV, batch=1, clip=1, tokens=16, cin=32, cout=40, with_res=True)

@@ -96,3 +96,10 @@ def test_blend_mask_bit_exact(res, out_hw, prompts, or_first):
 def test_conv3x3(kw):
     r = KC.case_conv3x3(DEV, **kw)
     print(kw, r)
+
+
+def test_temporal_conv3():
+    KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=320, cout=160, with_res=False)
+    KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=160, cout=320, with_res=True)
+    KC.case_temporal_conv3(DEV, batch=1, clip=8, tokens=64, cin=160, cout=1280, with_res=True)
+    KC.case_temporal_conv3(DEV, batch=1, clip=3, tokens=100, cin=1280, cout=160, with_res=False)
