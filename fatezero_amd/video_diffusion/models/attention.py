@@ -70,6 +70,8 @@ class CrossAttention(nn.Module):
         self.controller = None
         self.place_in_unet = None
         self._qk = None
+        self._qkv = None
+        self._ctx_kv = None
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _qk_weight(self, dtype, device):
@@ -96,8 +98,15 @@ class CrossAttention(nn.Module):
         """x.data: LayerNorm'ed hidden states [N, L, C]; ctx: [B, 77, Dctx] fp16."""
         n, lq, c = x.data.shape
         q = self.to_q.apply(x.data)
-        kk = self.to_k.apply(ctx)
-        vt = K.transpose_pad(self.to_v.apply(ctx), K.CROSS_KEYS)
+        # K / V^T of the text context depend only on (ctx, weights): the DDIM loops pass the same embedding tensor at
+        # every step, so they are projected once per job instead of once per layer call (16 x 100 times per job)
+        kvc = self._ctx_kv
+        if kvc is not None and kvc[0] is ctx and kvc[1] == ctx._version:
+            kk, vt = kvc[2], kvc[3]
+        else:
+            kk = self.to_k.apply(ctx)
+            vt = K.transpose_pad(self.to_v.apply(ctx), K.CROSS_KEYS)
+            self._ctx_kv = (ctx, ctx._version, kk, vt)
         lk = ctx.shape[1]
         out = torch.empty(n, lq, self.inner_dim, dtype=q.dtype, device=q.device)
         kw = dict(clip_len=clip, heads=self.heads, lk=lk, scale=self.scale)
@@ -128,10 +137,10 @@ class CrossAttention(nn.Module):
     def forward_temporal(self, x_norm, batch: int, clip: int):
         """x_norm: [B*F, L, C] LayerNorm'ed; attention over the F frames of every (b, token)."""
         n, l, c = x_norm.shape
-        w = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device), self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0) \
-            if getattr(self, "_qkv", None) is None else self._qkv
-        self._qkv = w
-        qkv = F.linear(x_norm, w)
+        if self._qkv is None or self._qkv.device != x_norm.device:
+            self._qkv = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device),
+                                   self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0).contiguous()
+        qkv = F.linear(x_norm, self._qkv)
         inner = self.inner_dim
         out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
         K.attn_temporal(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], out, batch=batch, clip_len=clip,

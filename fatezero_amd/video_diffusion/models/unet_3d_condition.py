@@ -112,7 +112,7 @@ class UNetPseudo3DConditionModel(nn.Module):
     def invalidate_packed(self):
         self._temb_pack = None
         for m in self.modules():
-            for a in ("_packed", "_qk", "_qkv"):
+            for a in ("_packed", "_qk", "_qkv", "_ctx_kv"):
                 if hasattr(m, a):
                     setattr(m, a, None)
 

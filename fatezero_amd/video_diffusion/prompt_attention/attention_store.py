@@ -80,7 +80,25 @@ class AttentionControl(abc.ABC):
 
 class MapArena:
     """HBM slabs for captured maps. The first step sizes the slab; later steps take one allocation each (or a
-    single pre-reserved block when the number of steps is known)."""
+    single pre-reserved block when the number of steps is known).  Reserved blocks (tens of GB) are recycled
+    through a process-wide pool when their store dies, so a second job never pays hipMalloc/hipFree for them."""
+    _pool = []  # released reserved blocks (uint8 tensors), largest reuse wins
+
+    @classmethod
+    def _take(cls, nbytes, device):
+        best = None
+        for i, t in enumerate(cls._pool):
+            if t.device == torch.device(device) and t.numel() >= nbytes and (best is None or t.numel() < cls._pool[best].numel()):
+                best = i
+        if best is not None:
+            return cls._pool.pop(best)
+        cls._pool.clear()  # nothing fits: let the allocator have the old blocks back before asking for a bigger one
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def release(self):
+        if self.reserved is not None:
+            MapArena._pool.append(self.reserved)
+            self.reserved = None
 
     def __init__(self):
         self.step_bytes = 0
@@ -93,9 +111,9 @@ class MapArena:
 
     def reserve(self, n_steps, device):
         if self.first_step_done and self.step_bytes and n_steps > 0 and self.reserved is None:
-            self.reserved = torch.empty(self.step_bytes * n_steps, dtype=torch.uint8, device=device)
+            self.reserved = MapArena._take(self.step_bytes * n_steps, device)
             self.reserved_off = 0
-            self.total_bytes += self.reserved.numel()
+            self.total_bytes += self.step_bytes * n_steps
 
     def alloc(self, shape, device):
         nbytes = 2
@@ -241,7 +259,25 @@ class AttentionStore(AttentionControl):
 
     def reset(self):
         super().reset()
+        self.release_arena()
         self._init_state()
+
+    def release_arena(self):
+        """Drop every captured map and hand the reserved HBM block back to the pool."""
+        arena = getattr(self, "arena", None)
+        if arena is not None:
+            self.step_store = self.get_empty_store()
+            self.attention_store_all_step = []
+            self._all_step_maps = []
+            self._step_maps = {k: [] for k in KEYS}
+            arena.cur = None
+            arena.release()
+
+    def __del__(self):
+        try:
+            self.release_arena()
+        except Exception:
+            pass
 
     @property
     def arena_bytes(self):
