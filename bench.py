@@ -90,7 +90,8 @@ def build_pipeline(device, seed=0, model_config=None):
 def run_job(pipe, z0, ddim_steps, device):
     """One full job: capture inversion + one CFG edit. Returns edited latents."""
     pipe.scheduler.set_timesteps(ddim_steps)
-    pipe.store_controller = type(pipe.store_controller)()  # fresh arena per job
+    pipe.release_attention_maps()                          # previous job's 75 GB arena block goes back to the pool
+    pipe.store_controller = type(pipe.store_controller)()  # fresh store per job
     emb_src = pipe._encode_prompt(SRC_PROMPT, device, 1, True, None)
     lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1, text_embeddings=emb_src,
                                              store_attention=True, LOW_RESOURCE=True, latents=z0)

@@ -62,6 +62,13 @@ class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
         self.store_controller = attention_util.AttentionStore(disk_store=disk_store)
         self.empty_controller = attention_util.EmptyControl()
 
+    def release_attention_maps(self):
+        """Free the HBM map arena of the last inversion (and the edit controller that references it) so that the next
+        job recycles the block instead of allocating a second one."""
+        self.last_edit_controller = None
+        if self.store_controller is not None:
+            self.store_controller.release_arena()
+
     def check_inputs(self, prompt, height, width, callback_steps, strength=None):
         if not isinstance(prompt, str) and not isinstance(prompt, list):
             raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")

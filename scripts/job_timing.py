@@ -9,6 +9,7 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 z0 = torch.randn(1, 4, 8, 64, 64, device=dev)
 for job in range(3):
     pipe.scheduler.set_timesteps(T)
+    pipe.release_attention_maps()
     pipe.store_controller = type(pipe.store_controller)()
     emb_src = pipe._encode_prompt(bench.SRC_PROMPT, dev, 1, True, None)
     torch.cuda.synchronize(); t0 = time.perf_counter()
