@@ -48,6 +48,8 @@ def temporal_conv_tokens(x4, w_taps, bias=None, residual=None):
 
 
 class LoRALinearLayer(nn.Module):
+    NATIVE_MIN_ROWS = 8192  # (frames x tokens) from which the hand-written temporal conv beats three library GEMMs
+
     def __init__(self, in_features, out_features, rank=4, stride=1):
         super().__init__()
         if rank > min(in_features, out_features):
@@ -66,13 +68,14 @@ class LoRALinearLayer(nn.Module):
             cout = uw.shape[0]
             is_noop = bool((self.up.weight == 0).all())  # un-tuned SD: up == 0 -> exact identity
             native = (rank % 32 == 0 and cin % 32 == 0 and cout % 8 == 0 and dtype == torch.float16)
-            if native:  # [Cout][3][Cin] packing of the implicit-GEMM kernel (fz_temporal_conv3)
-                wd = dw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous()
-                wu = uw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous()
-            else:       # tiny ranks (e.g. conv_out's rank 2): three small library GEMMs over shifted frame views
-                wd = dw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()  # [3, C, r]
-                wu = uw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()  # [3, r, C]
-            self._packed = (wd, wu, is_noop, native)
+            # [Cout][3][Cin] packing of the implicit-GEMM kernel (fz_temporal_conv3) ...
+            wdn = dw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous() if native else None
+            wun = uw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous() if native else None
+            # ... and tap-major [3, Cin, Cout] for the library-GEMM form used for tiny ranks (conv_out's rank 2) and for
+            # the small pyramid levels, where a few workgroups cannot fill the chip (scripts/kbench.py --tconv)
+            wd = dw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
+            wu = uw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
+            self._packed = (wd, wu, is_noop, native, wdn, wun)
         return self._packed
 
     def is_noop(self, dtype, device):
@@ -80,7 +83,7 @@ class LoRALinearLayer(nn.Module):
 
     def forward_tokens(self, x4, temb=None, residual=None):
         """x4: [B, F, T, C] -> up(down(x)) + x (+ temb[b] broadcast) (+ residual), same shape."""
-        wd, wu, is_noop, native = self._pack(x4.dtype, x4.device)
+        wd, wu, is_noop, native, wdn, wun = self._pack(x4.dtype, x4.device)
         b, f, t, c = x4.shape
         if is_noop:
             y = x4
@@ -89,10 +92,10 @@ class LoRALinearLayer(nn.Module):
             if residual is not None:
                 y = y + residual.view(b, f, t, c)
             return y
-        if native:
+        if native and b * f * t >= self.NATIVE_MIN_ROWS:
             x3 = x4.reshape(b * f, t, c)
-            d = K.temporal_conv3(x3, wd, clip_len=f)
-            y = K.temporal_conv3(d, wu, clip_len=f, res=x3, res2=residual, temb=temb)
+            d = K.temporal_conv3(x3, wdn, clip_len=f)
+            y = K.temporal_conv3(d, wun, clip_len=f, res=x3, res2=residual, temb=temb)
             return y.view(b, f, t, c)
         d = temporal_conv_tokens(x4, wd)
         y = temporal_conv_tokens(d, wu, residual=x4)

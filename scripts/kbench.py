@@ -55,9 +55,27 @@ def conv_bench():
     print(json.dumps(res, indent=1))
 
 
+def tconv_bench():
+    dev = "cuda"
+    res = {}
+    for (n, tokens, c) in [(8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (16, 4096, 320), (16, 1024, 640), (8, 64, 1280)]:
+        r = 160
+        x = torch.randn(n, tokens, c).half().to(dev)
+        wd = (torch.randn(r, 3, c) * 0.02).half().to(dev)
+        wu = (torch.randn(c, 3, r) * 0.02).half().to(dev)
+        d = K.temporal_conv3(x, wd, clip_len=8)
+        ms_d = timeit(lambda: K.temporal_conv3(x, wd, clip_len=8))
+        ms_u = timeit(lambda: K.temporal_conv3(d, wu, clip_len=8, res=x))
+        fl = 2.0 * n * tokens * 3 * c * r
+        res[f"tconv_n{n}_t{tokens}_c{c}"] = {"down_ms": ms_d, "up_ms": ms_u, "down_TF": fl / ms_d / 1e9, "up_TF": fl / ms_u / 1e9}
+    print(json.dumps(res))
+
+
 def main():
     if "--conv" in sys.argv:
         return conv_bench()
+    if "--tconv" in sys.argv:
+        return tconv_bench()
     dev = "cuda"
     F_, heads = 8, 8
     res = {}
