@@ -87,6 +87,21 @@ def build_pipeline(device, seed=0, model_config=None):
     return pipe
 
 
+def pmc_traffic_per_launch(frames_per_launch):
+    """HBM bytes of the judged kernel per launch.  PMC counters cannot be read from inside this process; they come
+    from the separate rocprofv3 --pmc passes of scripts/pmc_flash.sh (same kernel, 8 frames per launch), whose
+    summary is committed under profiles/.  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request,
+    MI355X_MICROARCH.md, HBM section); both counters are KiB.  Scaled linearly to this run's frames per launch."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_flash_d40_final.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        per8 = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        return per8 * frames_per_launch / 8.0, "profiles/r01_pmc_flash_d40_final.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def run_job(pipe, z0, ddim_steps, device):
     """One full job: capture inversion + one CFG edit. Returns edited latents."""
     pipe.scheduler.set_timesteps(ddim_steps)
@@ -212,14 +227,17 @@ def main():
         summ = timer.summary()
         roof = None
         if summ:
-            flops_total, ms_total, launches = 0.0, 0.0, 0
+            flops_total, ms_total, launches, frames_total = 0.0, 0.0, 0, 0
             for (tag, nf, n_kv), v in summ.items():
+                frames_total += nf * v["launches"]
                 flops_total += 4.0 * 4096 * (n_kv * 4096) * 320 * nf * v["launches"]  # 4*Lq*Lk*C per frame
                 ms_total += v["total_ms"]
                 launches += v["launches"]
             achieved = flops_total / (ms_total * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic_per_launch(frames_total / launches)
             roof = {"kernel": "attn_self_kernel<40,FLASH> (64x64 level, Lq 4096, Lk 8192, d 40)", "bound": "mfma",
-                    "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+                    "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src,
                     "launches": launches, "avg_launch_ms": ms_total / launches,
                     "algorithmic_flops_per_launch": flops_total / launches}
         line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)",

@@ -30,6 +30,7 @@ class FzAttnSelfDesc(C.Structure):
         ("p_frame_stride", C.c_int64), ("p_head_stride", C.c_int64), ("p_row_stride", C.c_int64),
         ("p_frame_off", C.c_int32), ("mask_frame_off", C.c_int32),
         ("k_head_stride", C.c_int64),
+        ("q_log2_scaled", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -9,7 +9,11 @@
 //     (wave-uniform branch); P stays < 2^6 in fp16, the accumulators are fp32;
 //   * the softmax denominator costs no VALU when d % 32 != 0: one padding row of the V^T tile is set to 1.0, so
 //     row D of O^T accumulates sum_k P[q,k] inside the PV MFMA (and is rescaled with O for free);
-//   * key masking only on the (wave-uniform) tail tile of a kv slot; scale folded into the exp2 argument.
+//   * key masking only on the (wave-uniform) tail tile of a kv slot;
+//   * when d % 16 != 0 (d = 40) and q arrives in the log2 domain (desc.q_log2_scaled: scale*log2e folded into Wq by
+//     the host) the running max costs no VALU either: the free contraction slot D holds 1.0 on the K side and -m
+//     (kept fp16-representable, so the product is exact) on the Q side, and the QK^T MFMA delivers s - m directly:
+//     per score the VALU work is exp2 + 1/2 max3 + 1/2 cvt_pk.
 #include "fz_rt.h"
 #include "../../include/fatezero_hip.h"
 #include <stdlib.h>
@@ -29,6 +33,8 @@ struct FlashCfg {
     static constexpr int VROWS = NT * 32;
     static constexpr int OSTR = NT * 32 + 8;
     static constexpr bool ONES_ROW = (D % 32) != 0;  // a free padding row of V^T carries the softmax denominator
+    static constexpr bool BIAS_SLOT = (D % 16) != 0 && (D % 8) == 0;  // a free contraction slot can carry -max
+    static constexpr int BC = D / 16, BHI = (D % 16) / 8, BE = D % 8;  // Q fragment chunk / lane half / element of slot D
     static constexpr int KS = FKVBLK * KSTR;
     static constexpr int VS = VROWS * FVSTR;
     static constexpr int STAGE = KS + VS;
@@ -67,6 +73,8 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     }
     const int h = group / d.n_frames, fl = group % d.n_frames;
     const int n = d.frame0 + fl, b = n / d.clip_len, f = n % d.clip_len;
+    constexpr bool BIAS = C::BIAS_SLOT && BRANCHY && !(ABL & 32);
+    const float cs = d.q_log2_scaled ? 1.0f : d.scale * 1.4426950408889634f;
     // each wave owns QB blocks of 32 query rows: every K / V^T fragment read from LDS feeds QB MFMAs, and the
     // independent blocks let the MFMAs of one overlap the softmax VALU of the other inside the wave
     half8_t qf[QB][C::NC];
@@ -92,7 +100,6 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     const int tps = lkfp / FKVBLK;
     const int ntiles = d.n_kv * tps;
     const int64_t khs = d.k_head_stride ? d.k_head_stride : (int64_t)D;
-    const float cs = d.scale * 1.4426950408889634f;
 
     // zero the padding rows of both V^T stages once (row D becomes the ones row); K padding columns are rewritten
     // with zeros by every K store (they come from the zero-filled register chunks)
@@ -132,6 +139,8 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
             vreg[i] = fz_ld_h8(vb + (int64_t)row * d.vt_chan_stride + ch * 8);
         }
     };
+    half8_t kpad = fz_zero_h8();  // what the padding chunk of a K row holds: zeros, or 1.0 in slot D
+    if (BIAS) kpad[C::BE] = (half_t)1.0f;
     auto stash = [&](int st) {
         half_t* Ks = smem + st * C::STAGE;
         half_t* Vs = Ks + C::KS;
@@ -140,7 +149,8 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
             const int id = tid + 256 * i;
             if (id < FKVBLK * C::KCH) {
                 const int ch = id % C::KCH;
-                fz_st_h8(Ks + (id / C::KCH) * C::KSTR + ch * 8, (ch * 8 < D) ? kreg[i] : fz_zero_h8());
+                fz_st_h8(Ks + (id / C::KCH) * C::KSTR + ch * 8,
+                         (ch * 8 < D) ? kreg[i] : (ch * 8 == D / 8 * 8 ? kpad : fz_zero_h8()));
             }
         }
 #pragma unroll
@@ -154,7 +164,7 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     f32x16 oacc[QB][C::NT];
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
-        m[u] = -1e30f;
+        m[u] = BIAS ? 0.0f : -1e30f;
         l[u] = 0.0f;
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) oacc[u][t] = fz_zero_f16v();
@@ -221,6 +231,35 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
             float tmax = s[0];
 #pragma unroll
             for (int i = 1; i < 32; ++i) tmax = fmaxf(tmax, s[i]);
+            if (BIAS) {
+                // s already is (log2-domain score) - m[u]; m[u] only moves when a row grew by more than 2^6, and on
+                // the first tile (where it starts at 0 and must come DOWN to the row max as well)
+                tmax = fz_pair_max32(tmax);
+                const bool first = (kt == 0);
+                if (first || fz_ballot(tmax > 6.0f) != 0ull) {
+                    float mn = first ? tmax : m[u] + fmaxf(tmax, 0.0f);
+                    mn = fminf(fmaxf(mn, -60000.0f), 60000.0f);
+                    mn = (float)(half_t)mn;  // fp16-representable: (1.0 * -mn) is exact inside the MFMA
+                    const float delta = mn - m[u];
+                    const float alpha = first ? 1.0f : fz_exp2(-delta);
+                    m[u] = mn;
+                    l[u] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < C::NT; ++t) oacc[u][t] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) s[i] -= delta;
+                    if (hi == C::BHI) qf[u][C::BC][C::BE] = (half_t)(-mn);
+                }
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const float pe = fz_exp2(s[i]);
+                    if (!C::ONES_ROW) sum += pe;
+                    pf[u][i >> 4][(i >> 3) & 1][i & 7] = (half_t)pe;
+                }
+                if (!C::ONES_ROW) l[u] += sum;
+                continue;
+            }
             tmax = fz_pair_max32(tmax) * cs;   // log2-domain row max of this tile over both lane halves (cs > 0)
             if (BRANCHY) {
                 if (fz_ballot(tmax > m[u] + 6.0f) != 0ull) {  // some row's max grew by more than 2^6: rescale
@@ -318,10 +357,10 @@ static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, c
     return fz_last_launch_status();
 }
 
-static bool flash_branchfree() {
+static bool flash_nobias() {  // A/B knob: running max through the fma (the d % 16 == 0 formulation) also for d = 40
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("FZ_FLASH_BRANCHFREE");
+        const char* e = getenv("FZ_FLASH_NOBIAS");
         v = (e && e[0] == '1') ? 1 : 0;
     }
     return v == 1;
@@ -352,10 +391,13 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
     switch (d.head_dim) {
         case 16: return launch_flash<16, 2, 1>(d, q, k, vt, o, stream);
         case 32: return launch_flash<32, 2, 1>(d, q, k, vt, o, stream);
-        case 40:
-            if (qb == 2 || (qb == 0 && big)) {
+        case 40: {
+            const bool two = (qb == 2 || (qb == 0 && big));
+            if (!d.q_log2_scaled || flash_nobias())  // q as to_q produces it: running max through the fma
+                return two ? launch_flash<40, 2, 2, true, 32>(d, q, k, vt, o, stream)
+                           : launch_flash<40, 4, 1, true, 32>(d, q, k, vt, o, stream);
+            if (two) {
                 if (w == 1) return launch_flash<40, 1, 2>(d, q, k, vt, o, stream);
-                if (flash_branchfree()) return launch_flash<40, 2, 2, false>(d, q, k, vt, o, stream);
 #ifndef FZ_EMU
                 {   // ablation builds for profiling only (results are wrong by construction)
                     static int abl = -1;
@@ -365,11 +407,8 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
                         case 2: return launch_flash<40, 2, 2, true, 2>(d, q, k, vt, o, stream);
                         case 4: return launch_flash<40, 2, 2, true, 4>(d, q, k, vt, o, stream);
                         case 6: return launch_flash<40, 2, 2, true, 6>(d, q, k, vt, o, stream);
-                        case 8: return launch_flash<40, 2, 2, true, 8>(d, q, k, vt, o, stream);
-                        case 16: return launch_flash<40, 2, 2, true, 16>(d, q, k, vt, o, stream);
-                        case 24: return launch_flash<40, 2, 2, true, 24>(d, q, k, vt, o, stream);
-                        case 25: return launch_flash<40, 2, 2, true, 25>(d, q, k, vt, o, stream);
                         case 7: return launch_flash<40, 2, 2, true, 7>(d, q, k, vt, o, stream);
+                        case 8: return launch_flash<40, 2, 2, true, 8>(d, q, k, vt, o, stream);
                         default: break;
                     }
                 }
@@ -377,8 +416,8 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
                 return launch_flash<40, 2, 2>(d, q, k, vt, o, stream);
             }
             if (w == 2) return launch_flash<40, 2, 1>(d, q, k, vt, o, stream);
-            if (w == 3) return launch_flash<40, 3, 1>(d, q, k, vt, o, stream);
             return launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
+        }
         case 64: return launch_flash<64, 2, 1>(d, q, k, vt, o, stream);
         case 80:
             if (qb == 2) return launch_flash<80, 1, 2>(d, q, k, vt, o, stream);

@@ -101,7 +101,7 @@ attn_self_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* _
     const int tps = lkfp / KVBLK;
     const int ntiles = d.n_kv * tps;
     const int64_t khs = d.k_head_stride ? d.k_head_stride : (int64_t)D;
-    const float cs = d.scale * 1.4426950408889634f;  // softmax in the log2 domain
+    const float cs = d.q_log2_scaled ? 1.0f : d.scale * 1.4426950408889634f;  // softmax in the log2 domain
 
     bool use_cur = true;  // INJECT: does this lane's row keep the live attention?
     bool any_cur = true;  // wave-uniform: is QK^T needed at all?

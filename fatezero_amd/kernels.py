@@ -82,9 +82,12 @@ def kv_slots(index_list: Sequence, clip_len: int) -> Tuple[List[int], List[int]]
 def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out: torch.Tensor, *, clip_len: int,
               heads: int, index_list: Sequence, mode: int = FZ_ATTN_FLASH, frame0: int = 0, n_frames: Optional[int] = None,
               p: Optional[torch.Tensor] = None, p_frame_off: int = 0, row_mask: Optional[torch.Tensor] = None,
-              mask_frame_off: int = 0, scale: Optional[float] = None, k_head_major: Optional[torch.Tensor] = None):
+              mask_frame_off: int = 0, scale: Optional[float] = None, k_head_major: Optional[torch.Tensor] = None,
+              q_log2_scaled: bool = False):
     """q,k,out: [N, L, >=C] views with row stride (token-major); vt: [N, C, Lpad]; p: [Fp, heads, Lq, Lk] fp16.
     k_head_major (optional): K as a contiguous [N, heads, L, d] tensor (fully coalesced key tiles) instead of `k`.
+
+    q_log2_scaled: q already carries scale*log2(e) (folded into the projection weight), see include/fatezero_hip.h.
 
     Frames frame0 .. frame0+n_frames-1 of q/out are processed; k/vt are indexed by source frame.
     """
@@ -101,6 +104,7 @@ def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out:
         d.kv_abs[j], d.kv_val[j] = kabs[j], kval[j]
     d.scale = float(scale if scale is not None else d_head ** -0.5)
     d.mode = mode
+    d.q_log2_scaled = 1 if q_log2_scaled else 0
     assert q.stride(2) == 1 and out.stride(2) == 1 and vt.stride(2) == 1
     d.q_frame_stride, d.q_row_stride = q.stride(0), q.stride(1)
     if k_head_major is not None:

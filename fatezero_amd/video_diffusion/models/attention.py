@@ -23,6 +23,8 @@ from torch import nn
 from ... import kernels as K
 from .resnet import Tokens, _LinearParams, _NormParams, group_norm_tokens
 
+_LOG2E = 1.4426950408889634
+
 
 @dataclass
 class SpatioTemporalTransformerModelOutput:
@@ -70,13 +72,17 @@ class CrossAttention(nn.Module):
         self.controller = None
         self.place_in_unet = None
         self._qk = None
+        self._qk_fold = 1.0
         self._qkv = None
         self._ctx_kv = None
 
     # -- helpers -----------------------------------------------------------------------------------------
-    def _qk_weight(self, dtype, device):
-        if self._qk is None or self._qk.dtype != dtype or self._qk.device != device:
-            self._qk = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], 0).to(device=device, dtype=dtype).contiguous()
+    def _qk_weight(self, dtype, device, q_fold=1.0):
+        """Fused [Wq; Wk] projection weight; `q_fold` is multiplied into the Wq rows in fp32 before the cast."""
+        if self._qk is None or self._qk.dtype != dtype or self._qk.device != device or self._qk_fold != q_fold:
+            wq = self.to_q.weight.detach().float() * q_fold
+            self._qk = torch.cat([wq, self.to_k.weight.detach().float()], 0).to(device=device, dtype=dtype).contiguous()
+            self._qk_fold = q_fold
         return self._qk
 
     def _generic_controller_call(self, controller, is_cross, q, k, vt, out, clip, lq, lk_total, run_capture, run_inject):
@@ -159,7 +165,11 @@ class SparseCausalAttention(CrossAttention):
     def forward_self(self, x: Tokens, clip: int, index_list):
         n, lq, c = x.data.shape
         xn = x.data
-        qk = F.linear(xn, self._qk_weight(xn.dtype, xn.device))
+        # head dims with a free MFMA contraction slot (SD-1.x: 40): the softmax scale and log2(e) go into Wq, q comes out of
+        # the projection GEMM in the log2 domain and the flash kernel gets its running max for free (csrc/attn_flash.hip)
+        d_head = self.inner_dim // self.heads
+        folded = d_head % 16 != 0 and d_head % 8 == 0
+        qk = F.linear(xn, self._qk_weight(xn.dtype, xn.device, self.scale * _LOG2E if folded else 1.0))
         q, kk = qk[..., : self.inner_dim], qk[..., self.inner_dim:]
         wv = self.to_v.packed(xn.dtype, xn.device)[0]
         if lq % 64 == 0:
@@ -168,7 +178,7 @@ class SparseCausalAttention(CrossAttention):
             vt = K.transpose_pad(F.linear(xn, wv), K.pad64(lq))
         out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
         n_kv = max(1, len(index_list))
-        kw = dict(clip_len=clip, heads=self.heads, index_list=index_list, scale=self.scale)
+        kw = dict(clip_len=clip, heads=self.heads, index_list=index_list, scale=self.scale, q_log2_scaled=folded)
         ctrl = self.controller
         plan = _plan_for(ctrl, False, self.place_in_unet, n, clip, self.heads, lq, n_kv * lq, xn.device)
         if plan is None:

@@ -59,6 +59,11 @@ typedef struct FzAttnSelfDesc {
     int32_t mask_frame_off; /* row_mask frame index of this launch's first frame             */
     int64_t k_head_stride;  /* elements between heads of K: 0 = head_dim (heads interleaved in a row);
                                lkf*head_dim with k_row_stride = head_dim for a head-major K [n][head][key][d] */
+    int32_t q_log2_scaled;  /* 1: the producer of q already folded scale*log2(e) into it (e.g. into the rows of
+                               Wq), so q.k IS the log2-domain logit and `scale` is not applied again.  For
+                               head_dim % 16 != 0 this lets the running max ride in a free contraction slot of
+                               the QK^T MFMA (csrc/attn_flash.hip).  0: q as the reference's to_q produces it. */
+    int32_t reserved0;
 } FzAttnSelfDesc;
 
 /* row_mask (INJECT only, may be NULL): float [frames][lq]; 1 -> the row keeps the live attention,

@@ -46,11 +46,24 @@ def _vt(v, lp):
     return K.transpose_pad(v, lp)
 
 
-def case_attn_self(device, *, batch, clip, heads, d, lq, index_list, mode, mask_kind=None, seed=0, qk_scale=1.5):
+def case_attn_self(device, *, batch, clip, heads, d, lq, index_list, mode, mask_kind=None, seed=0, qk_scale=1.5,
+                   fold=False, shape=None):
+    """fold=True: q is handed over in the log2 domain (desc.q_log2_scaled), as the host does for d % 16 != 0; the
+    reference then sees exactly the same fp16 numbers divided by the folded factor."""
     g = torch.Generator().manual_seed(seed)
     n, c = batch * clip, heads * d
     q = _mk((n, lq, c), g, device, qk_scale)
     k = _mk((n, lq, c), g, device, qk_scale)
+    if shape == "ramp":      # logits grow along the key axis: the running max moves in (almost) every tile
+        k = (k.float() * torch.linspace(0.05, 3.0, lq, device=k.device)[None, :, None]).half()
+    elif shape == "negative":  # every logit far below zero: the running max has to come DOWN on the first tile
+        q, k = q.abs(), -k.abs()
+    q_in, fkw = q, {}
+    if fold:
+        cs = d ** -0.5 * 1.4426950408889634
+        q_in = (q.float() * cs).half()
+        q = q_in.float() / cs
+        fkw = dict(q_log2_scaled=True)
     v = _mk((n, lq, c), g, device)
     n_kv = max(1, len(index_list))
     lk = n_kv * lq
@@ -59,11 +72,11 @@ def case_attn_self(device, *, batch, clip, heads, d, lq, index_list, mode, mask_
     p_ref, vh = ref_self_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, clip, index_list)
     res = {}
     if mode == K.FZ_ATTN_FLASH:
-        K.attn_self(q, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=mode)
+        K.attn_self(q_in, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=mode, **fkw)
         o_ref = (p_ref @ vh).permute(0, 2, 1, 3).reshape(n, lq, c)
     elif mode == K.FZ_ATTN_CAPTURE:
         p = torch.full((n, heads, lq, lk), float("nan"), dtype=torch.float16, device=device)
-        K.attn_self(q, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=mode, p=p)
+        K.attn_self(q_in, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=mode, p=p, **fkw)
         # the reference casts P to fp16 before P.V (attention_register.py:45,55)
         o_ref = (p_ref.half().float() @ vh).permute(0, 2, 1, 3).reshape(n, lq, c)
         pe = (p.float().cpu() - p_ref).abs()
@@ -84,10 +97,10 @@ def case_attn_self(device, *, batch, clip, heads, d, lq, index_list, mode, mask_
             mask = torch.zeros(clip, lq)
             mask[:, : lq // 3] = 1.0
             mask = mask.to(device)
-        K.attn_self(q, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=K.FZ_ATTN_FLASH,
-                    frame0=0, n_frames=n - fcond)
-        K.attn_self(q, (k if mask is not None else None), vt, out, clip_len=clip, heads=heads, index_list=index_list,
-                    mode=mode, frame0=n - fcond, n_frames=fcond, p=base, row_mask=mask)
+        K.attn_self(q_in, k, vt, out, clip_len=clip, heads=heads, index_list=index_list, mode=K.FZ_ATTN_FLASH,
+                    frame0=0, n_frames=n - fcond, **fkw)
+        K.attn_self(q_in, (k if mask is not None else None), vt, out, clip_len=clip, heads=heads, index_list=index_list,
+                    mode=mode, frame0=n - fcond, n_frames=fcond, p=base, row_mask=mask, **fkw)
         p_new = p_ref.clone()
         bs = base.float().cpu()
         if mask is None:

@@ -35,6 +35,21 @@ def test_self_flash_two_query_blocks_per_wave():
     KC.case_attn_self(DEV, batch=1, clip=2, heads=1, d=40, lq=600, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH)
 
 
+@pytest.mark.parametrize("lq,qk_scale,shape", [(64, 1.5, None), (600, 1.5, None), (600, 6.0, None), (576, 3.0, "ramp"),
+                                               (320, 3.0, "negative")])
+def test_self_flash_log2_folded_q(lq, qk_scale, shape):
+    # d=40 with q delivered in the log2 domain: the running max rides in contraction slot 40 of the QK^T MFMA
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=lq, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH,
+                      qk_scale=qk_scale, shape=shape, fold=True)
+
+
+def test_self_capture_and_inject_log2_folded_q():
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=64, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE,
+                      fold=True)
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=40, lq=64, index_list=["mid"], mode=K.FZ_ATTN_INJECT,
+                      mask_kind="random", fold=True)
+
+
 def test_self_own_frame_only():
     KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=64, lq=64, index_list=[], mode=K.FZ_ATTN_FLASH)
 

@@ -31,6 +31,22 @@ def test_self_flash_sd_level_64():
     print("flash 64^2", r)
 
 
+@pytest.mark.parametrize("lq,qk_scale,shape", [(64, 1.5, None), (600, 1.5, None), (1024, 6.0, None), (576, 3.0, "ramp"),
+                                               (320, 3.0, "negative"), (4096, 1.5, None)])
+def test_self_flash_log2_folded_q(lq, qk_scale, shape):
+    # d=40 with q delivered in the log2 domain: the running max rides in contraction slot 40 of the QK^T MFMA
+    r = KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=lq, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH,
+                          qk_scale=qk_scale, shape=shape, fold=True)
+    print("flash folded", lq, qk_scale, shape, r)
+
+
+def test_self_capture_and_inject_log2_folded_q():
+    KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=324, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE,
+                      fold=True)
+    KC.case_attn_self(DEV, batch=2, clip=2, heads=2, d=40, lq=256, index_list=["mid"], mode=K.FZ_ATTN_INJECT,
+                      mask_kind="random", fold=True)
+
+
 def test_self_flash_masking_and_slots():
     KC.case_attn_self(DEV, batch=1, clip=3, heads=1, d=32, lq=200, index_list=[-1, "mid", 1], mode=K.FZ_ATTN_FLASH)
     KC.case_attn_self(DEV, batch=2, clip=2, heads=8, d=64, lq=64, index_list=[], mode=K.FZ_ATTN_FLASH)
