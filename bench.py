@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--warmup-ddim-steps", type=int, default=0, help="DDIM steps of the warm-up jobs (0 = same as timed)")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["clips", "frames"], default="clips",
+                    help="N > 1: 'clips' = one clip per GPU (weak scaling, latents only on the wire; the default); 'frames' = "
+                         "ONE clip's frames split over the GPUs (strong scaling; GroupNorm / K-V / temporal exchanges over RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,7 +189,8 @@ def main():
     timer.wrap(K, "attn_self", select)
 
     pipe = build_pipeline(device, seed=0)
-    g = torch.Generator().manual_seed(1234 + rank)
+    by_frames = args.shard == "frames" and world > 1
+    g = torch.Generator().manual_seed(1234 + (0 if by_frames else rank))  # frame-sharded: every rank holds the same clip
     z0 = torch.randn(1, 4, args.frames, 64, 64, generator=g).to(device)
     if dist is not None:  # every rank must have built the same model: compare a weight checksum over RCCL
         chk = torch.stack([p.float().sum() for p in list(pipe.unet.parameters())[:8]]).sum().reshape(1)
@@ -194,6 +198,9 @@ def main():
         dist.broadcast(ref, 0)
         assert torch.allclose(ref, chk), "ranks built different weights"
 
+    if by_frames:
+        from fatezero_amd import dist as fz_dist
+        pipe.frame_shard = fz_dist.FrameShard(args.frames)
     wsteps = args.warmup_ddim_steps or args.ddim_steps
     for _ in range(args.warmup):
         run_job(pipe, z0, wsteps, device)
@@ -215,15 +222,16 @@ def main():
     tmax = torch.tensor([dt], device=device)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.empty_like(edited) for _ in range(world)]
-        dist.all_gather(gathered, edited.contiguous())  # edited latents -> rank 0 (and everyone) over xGMI
-        edited = torch.cat(gathered, dim=0)
+        if not by_frames:  # (a frame-sharded job already returned the all-gathered latents of its one clip)
+            gathered = [torch.empty_like(edited) for _ in range(world)]
+            dist.all_gather(gathered, edited.contiguous())  # edited latents -> rank 0 (and everyone) over xGMI
+            edited = torch.cat(gathered, dim=0)
     dt = float(tmax.item())
     finite = bool(torch.isfinite(edited.float()).all())
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * args.frames * args.steps / dt
+        value = (1 if by_frames else world) * args.frames * args.steps / dt
         summ = timer.summary()
         roof = None
         if summ:
@@ -242,14 +250,16 @@ def main():
                     "algorithmic_flops_per_launch": flops_total / launches}
         line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)",
                 "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if by_frames else "weak",
+                "vs_baseline": None,
                 "dtype": "fp16", "data": "synthetic",
                 "config": {"workload": "config/teaser/jeep_posche.yaml shape: 8 x 512x512 (latents 8x64x64x4), "
                                        f"{args.ddim_steps}-step DDIM inversion with HBM map capture + {args.ddim_steps}-step "
                                        "CFG edit (Replace, blend-masked self-attention), SD-1.x pseudo-3D UNet lora=160, "
                                        "random-init weights",
                            "frames": args.frames, "ddim_steps": args.ddim_steps, "n_edit": 1,
-                           "parallelism": f"dp{world} over clips" if world > 1 else "single GPU",
+                           "parallelism": ("single GPU" if world == 1 else
+                                           f"{world}-way frame-sharded clip" if by_frames else f"dp{world} over clips"),
                            "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite},
                 "roofline": roof, "cpu_baseline": None}
         if not args.no_cpu_baseline and world == 1:

@@ -30,7 +30,7 @@ class FzAttnSelfDesc(C.Structure):
         ("p_frame_stride", C.c_int64), ("p_head_stride", C.c_int64), ("p_row_stride", C.c_int64),
         ("p_frame_off", C.c_int32), ("mask_frame_off", C.c_int32),
         ("k_head_stride", C.c_int64),
-        ("q_log2_scaled", C.c_int32), ("reserved0", C.c_int32),
+        ("q_log2_scaled", C.c_int32), ("kv_clip_len", C.c_int32), ("kv_frame_off", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -54,11 +54,16 @@ _SIGS = {
     "fz_attn_cross": (C.c_int, [C.POINTER(FzAttnCrossDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_attn_temporal": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                    C.c_int64, C.c_float, _P]),
+    "fz_attn_temporal_ex": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      C.c_int64, C.c_int64, C.c_float, _P]),
     "fz_blend_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, _P,
                                 C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "fz_groupnorm_chunks": (C.c_int, [C.c_int, C.c_int]),
     "fz_groupnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                _P, _P]),
+    "fz_groupnorm_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "fz_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
+                                     C.c_int, C.c_int, _P, _P]),
     "fz_conv3x3": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, _P]),
     "fz_temporal_conv3": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

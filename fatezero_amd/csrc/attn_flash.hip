@@ -44,6 +44,18 @@ struct FlashCfg {
     static constexpr int VLD = (D * 8 + 255) / 256;         // 16-byte V^T chunks per thread per tile (rows < D only)
 };
 
+#ifdef FZ_FLASH_TIMING  // scripts/flash_timing.hip: per-segment s_memtime totals of wave 0 of block 0 (never in the product)
+__device__ long long fz_flash_timing[8];
+#define FZ_TICK(slot)                                         \
+    do {                                                      \
+        const long long now_ = clock64();                     \
+        if (blockIdx.x == 0 && tid == 0) fz_flash_timing[slot] += now_ - tick_; \
+        tick_ = now_;                                         \
+    } while (0)
+#else
+#define FZ_TICK(slot)
+#endif
+
 FZ_DEVICE int fl_pi(int i) {
     const int a = i >> 3, hp = (i >> 2) & 1, t = i & 3;
     return ((a & 2) << 3) + 8 * hp + 4 * (a & 1) + t;
@@ -92,9 +104,10 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     int src[FZ_MAX_KV_SLOTS];
 #pragma unroll
     for (int j = 0; j < FZ_MAX_KV_SLOTS; ++j) {
-        int s = d.kv_abs[j] ? d.kv_val[j] : f + d.kv_val[j];
-        s = s < 0 ? 0 : (s > d.clip_len - 1 ? d.clip_len - 1 : s);
-        src[j] = b * d.clip_len + s;
+        const int kvl = d.kv_clip_len ? d.kv_clip_len : d.clip_len;  // frames per batch element of k / vt
+        int s = d.kv_abs[j] ? d.kv_val[j] : f + (d.kv_clip_len ? d.kv_frame_off : 0) + d.kv_val[j];
+        s = s < 0 ? 0 : (s > kvl - 1 ? kvl - 1 : s);
+        src[j] = b * kvl + s;
     }
     const int lkfp = (d.lkf + FKVBLK - 1) / FKVBLK * FKVBLK;
     const int tps = lkfp / FKVBLK;
@@ -115,28 +128,47 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     // Prefetch registers.  The loads are UNCONDITIONAL (addresses clamped into the tensor, invalid data replaced when it
     // is written to LDS): a predicated load makes hipcc wrap it in control flow and then wait vmcnt(0) at the join,
     // i.e. right before the first MFMA of the tile -- which would expose the whole global-load latency every tile.
+    // Addresses are strength-reduced: a wave-uniform 64-bit base that walks along the keys of the current kv slot, plus a
+    // 32-bit per-lane byte offset whose only per-tile work is the clamp of the key row on a slot's ragged last tile
+    // (one v_min + one v_mad_u32_u24 per K chunk; the V^T offsets never change).
     half8_t kreg[C::KLD], vreg[C::VLD];
-    auto fetch = [&](int kt) {
-        const int j = kt / tps, r0 = (kt % tps) * FKVBLK;
-        const half_t* kb = k + (int64_t)src[j] * d.k_frame_stride + (int64_t)h * khs;
+    uint32_t kkey[C::KLD], kdd[C::KLD], voff[C::VLD];
+    const uint32_t krs_bytes = (uint32_t)d.k_row_stride * 2u;
+#pragma unroll
+    for (int i = 0; i < C::KLD; ++i) {
+        int id = tid + 256 * i;
+        id = id < FKVBLK * C::KCH ? id : FKVBLK * C::KCH - 1;
+        const int ch = id % C::KCH;
+        kkey[i] = id / C::KCH;
+        kdd[i] = 2u * (ch * 8 < D ? ch * 8 : D - 8);  // padding chunk: any valid data, replaced in stash()
+    }
+#pragma unroll
+    for (int i = 0; i < C::VLD; ++i) {
+        const int id = tid + 256 * i;
+        const int row = (id >> 3) < D ? (id >> 3) : D - 1;  // rows >= D are not stashed
+        voff[i] = (uint32_t)row * (uint32_t)d.vt_chan_stride * 2u + (id & 7) * 16u;
+    }
+    int fj = 0, fr0 = 0;  // kv slot and first key row of the next tile to fetch
+    const char *kcur = nullptr, *vcur = nullptr;
+    auto fetch = [&]() {
+        if (fr0 == 0) {  // wave-uniform: first tile of a kv slot
+            kcur = reinterpret_cast<const char*>(k + (int64_t)src[fj] * d.k_frame_stride + (int64_t)h * khs);
+            vcur = reinterpret_cast<const char*>(vt + (int64_t)src[fj] * d.vt_frame_stride + (int64_t)(h * D) * d.vt_chan_stride);
+        }
+        const uint32_t kmax = (uint32_t)(d.lkf - 1 - fr0);  // padded keys are masked in the softmax; any finite data will do
 #pragma unroll
         for (int i = 0; i < C::KLD; ++i) {
-            int id = tid + 256 * i;
-            id = id < FKVBLK * C::KCH ? id : FKVBLK * C::KCH - 1;
-            const int key = id / C::KCH, ch = id % C::KCH;
-            int r = r0 + key, dd = ch * 8;
-            r = r < d.lkf ? r : d.lkf - 1;   // padded keys are masked in the softmax; any finite data will do
-            dd = dd < D ? dd : D - 8;        // padding chunk: zeroed in stash()
-            kreg[i] = fz_ld_h8(kb + (int64_t)r * d.k_row_stride + dd);
+            const uint32_t key = kkey[i] < kmax ? kkey[i] : kmax;
+            kreg[i] = fz_ld_h8_off(kcur, fz_mad24(key, krs_bytes, kdd[i]));
         }
-        const half_t* vb = vt + (int64_t)src[j] * d.vt_frame_stride + (int64_t)(h * D) * d.vt_chan_stride + r0;
 #pragma unroll
-        for (int i = 0; i < C::VLD; ++i) {
-            const int id = tid + 256 * i;
-            int row = id >> 3;
-            const int ch = id & 7;
-            row = row < D ? row : D - 1;     // not stashed
-            vreg[i] = fz_ld_h8(vb + (int64_t)row * d.vt_chan_stride + ch * 8);
+        for (int i = 0; i < C::VLD; ++i) vreg[i] = fz_ld_h8_off(vcur, voff[i]);
+        kcur += (int64_t)FKVBLK * krs_bytes;
+        vcur += FKVBLK * 2;
+        fr0 += FKVBLK;
+        if (fr0 >= lkfp) {
+            fr0 = 0;
+            ++fj;
         }
     };
     half8_t kpad = fz_zero_h8();  // what the padding chunk of a K row holds: zeros, or 1.0 in slot D
@@ -170,14 +202,18 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
         for (int t = 0; t < C::NT; ++t) oacc[u][t] = fz_zero_f16v();
     }
 
-    fetch(0);
+    fetch();
     stash(0);
     __syncthreads();
 
+#ifdef FZ_FLASH_TIMING
+    long long tick_ = clock64();
+#endif
+    int r0 = 0;  // first key row (within its kv slot) of the tile being consumed
     for (int kt = 0; kt < ntiles; ++kt) {
         const int cur = kt & 1;
-        const int r0 = (kt % tps) * FKVBLK;
-        if (!(ABL & 8) && kt + 1 < ntiles) fetch(kt + 1);  // in flight during the MFMAs below
+        if (!(ABL & 8) && kt + 1 < ntiles) fetch();  // in flight during the MFMAs below
+        FZ_TICK(0);
 
         const half_t* Ks = smem + ((ABL & 8) ? 0 : cur) * C::STAGE;
         const half_t* Vs = Ks + C::KS;
@@ -189,6 +225,7 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
 #pragma unroll
             for (int c = 0; c < C::NC; ++c) kfr[sub][c] = fz_ld_h8(row + 16 * c);
         }
+        if (ABL & 64) fz_setprio_hi();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -205,6 +242,8 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
                 }
             }
         }
+        if (ABL & 64) fz_setprio_lo();
+        FZ_TICK(1);
         half8_t pf[QB][2][2];
         const bool tail = (r0 + FKVBLK > d.lkf);  // wave-uniform: last tile of a kv slot has padded keys
 #pragma unroll
@@ -289,6 +328,8 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
             }
             if (!C::ONES_ROW) l[u] += sum;
         }
+        FZ_TICK(2);
+        if (ABL & 64) fz_setprio_hi();
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             const half_t* vrow = Vs + (32 * t + lq_) * FVSTR + 8 * hi;
@@ -307,8 +348,14 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
                     }
                 }
         }
+        if (ABL & 64) fz_setprio_lo();
+        FZ_TICK(3);
         if (!(ABL & 8) && kt + 1 < ntiles) stash(cur ^ 1);
+        FZ_TICK(4);
         if (!(ABL & 16)) __syncthreads();
+        FZ_TICK(5);
+        r0 += FKVBLK;
+        if (r0 >= lkfp) r0 = 0;
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------
@@ -350,6 +397,8 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
 
 template <int D, int W, int QB, bool BRANCHY = true, int ABL = 0>
 static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream) {
+    // 32-bit per-lane byte offsets inside one (frame, head) K / V^T panel
+    if (d.k_row_stride >= (1 << 22) || (int64_t)D * d.vt_chan_stride >= (1ll << 30)) return FZ_ERR_UNSUPPORTED;
     const int nq = (d.lq + 128 * QB - 1) / (128 * QB);
     dim3 grid(nq * d.heads * d.n_frames), block(256);
     FZ_LAUNCH((attn_flash_kernel<D, W, QB, BRANCHY, ABL>), grid, block, 0, stream, d, (const half_t*)q, (const half_t*)k,
@@ -409,6 +458,7 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
                         case 6: return launch_flash<40, 2, 2, true, 6>(d, q, k, vt, o, stream);
                         case 7: return launch_flash<40, 2, 2, true, 7>(d, q, k, vt, o, stream);
                         case 8: return launch_flash<40, 2, 2, true, 8>(d, q, k, vt, o, stream);
+                        case 64: return launch_flash<40, 2, 2, true, 64>(d, q, k, vt, o, stream);  // s_setprio around MFMA clusters (correct)
                         default: break;
                     }
                 }
@@ -416,6 +466,7 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
                 return launch_flash<40, 2, 2>(d, q, k, vt, o, stream);
             }
             if (w == 2) return launch_flash<40, 2, 1>(d, q, k, vt, o, stream);
+            if (w == 3) return launch_flash<40, 3, 1>(d, q, k, vt, o, stream);
             return launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
         }
         case 64: return launch_flash<64, 2, 1>(d, q, k, vt, o, stream);

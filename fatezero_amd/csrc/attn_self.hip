@@ -92,9 +92,10 @@ attn_self_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* _
     int src[FZ_MAX_KV_SLOTS];
 #pragma unroll
     for (int j = 0; j < FZ_MAX_KV_SLOTS; ++j) {
-        int s = d.kv_abs[j] ? d.kv_val[j] : f + d.kv_val[j];
-        s = s < 0 ? 0 : (s > d.clip_len - 1 ? d.clip_len - 1 : s);
-        src[j] = b * d.clip_len + s;
+        const int kvl = d.kv_clip_len ? d.kv_clip_len : d.clip_len;  // frames per batch element of k / vt
+        int s = d.kv_abs[j] ? d.kv_val[j] : f + (d.kv_clip_len ? d.kv_frame_off : 0) + d.kv_val[j];
+        s = s < 0 ? 0 : (s > kvl - 1 ? kvl - 1 : s);
+        src[j] = b * kvl + s;
     }
 
     const int lkfp = (d.lkf + KVBLK - 1) / KVBLK * KVBLK;

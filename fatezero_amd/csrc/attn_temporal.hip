@@ -14,8 +14,8 @@
 struct TemporalArgs {
     const half_t *q, *k, *v;
     half_t* o;
-    int batch, F, tokens, heads, dh;
-    int64_t in_stride, out_stride;
+    int batch, F, Fq, tokens, heads, dh;  // F key/value frames, Fq query frames per batch element
+    int64_t in_stride, q_stride, out_stride;
     float scale;
     int tok_per_block;
 };
@@ -26,7 +26,7 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int tok0 = blockIdx.x * a.tok_per_block;
-    const int items = a.tok_per_block * a.heads * a.F;
+    const int items = a.tok_per_block * a.heads * a.Fq;
     const int nvec = a.dh >> 3;
     float* myS = S + tid * a.F;
     for (int w = tid; w < items; w += TTHREADS) {
@@ -36,7 +36,7 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) 
         const int tok = tok0 + tl;
         if (tok >= a.tokens) continue;
         const int64_t col = (int64_t)h * a.dh;
-        const half_t* qrow = a.q + ((int64_t)(b * a.F + i) * a.tokens + tok) * a.in_stride + col;
+        const half_t* qrow = a.q + ((int64_t)(b * a.Fq + i) * a.tokens + tok) * a.q_stride + col;
         // pass 1: scores
         float mx = -1e30f;
         for (int j = 0; j < a.F; ++j) {
@@ -60,7 +60,7 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) 
         const float inv = 1.0f / sum;
         for (int j = 0; j < a.F; ++j) myS[j] = (float)(half_t)(myS[j] * inv);  // P is cast to fp16 before P.V
         // pass 2: O = P V
-        half_t* orow = a.o + ((int64_t)(b * a.F + i) * a.tokens + tok) * a.out_stride + col;
+        half_t* orow = a.o + ((int64_t)(b * a.Fq + i) * a.tokens + tok) * a.out_stride + col;
         for (int c = 0; c < nvec; ++c) {
             float acc[8];
 #pragma unroll
@@ -79,20 +79,29 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) 
     }
 }
 
-extern "C" int fz_attn_temporal(const void* q, const void* k, const void* v, void* o, int batch, int clip_len,
-                                int tokens, int heads, int head_dim, int64_t qkv_row_stride, int64_t o_row_stride,
-                                float scale, void* stream) {
-    if (!q || !k || !v || !o || batch <= 0 || clip_len <= 0 || clip_len > TMAXF || tokens <= 0) return FZ_ERR_BAD_ARG;
-    if ((head_dim & 7) || (qkv_row_stride & 7) || (o_row_stride & 7)) return FZ_ERR_BAD_ARG;
+extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, void* o, int batch, int q_frames,
+                                   int kv_frames, int tokens, int heads, int head_dim, int64_t q_row_stride,
+                                   int64_t kv_row_stride, int64_t o_row_stride, float scale, void* stream) {
+    if (!q || !k || !v || !o || batch <= 0 || q_frames <= 0 || kv_frames <= 0 || kv_frames > TMAXF || q_frames > TMAXF ||
+        tokens <= 0)
+        return FZ_ERR_BAD_ARG;
+    if ((head_dim & 7) || (q_row_stride & 7) || (kv_row_stride & 7) || (o_row_stride & 7)) return FZ_ERR_BAD_ARG;
     TemporalArgs a;
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.o = (half_t*)o;
-    a.batch = batch; a.F = clip_len; a.tokens = tokens; a.heads = heads; a.dh = head_dim;
-    a.in_stride = qkv_row_stride; a.out_stride = o_row_stride; a.scale = scale;
-    int tpb = TTHREADS / (heads * clip_len);
+    a.batch = batch; a.F = kv_frames; a.Fq = q_frames; a.tokens = tokens; a.heads = heads; a.dh = head_dim;
+    a.in_stride = kv_row_stride; a.q_stride = q_row_stride; a.out_stride = o_row_stride; a.scale = scale;
+    int tpb = TTHREADS / (heads * q_frames);
     if (tpb < 1) tpb = 1;
     a.tok_per_block = tpb;
     dim3 grid((tokens + tpb - 1) / tpb, batch), block(TTHREADS);
-    const size_t smem = (size_t)TTHREADS * clip_len * sizeof(float);
+    const size_t smem = (size_t)TTHREADS * kv_frames * sizeof(float);
     FZ_LAUNCH(attn_temporal_kernel, grid, block, smem, stream, a);
     return fz_last_launch_status();
+}
+
+extern "C" int fz_attn_temporal(const void* q, const void* k, const void* v, void* o, int batch, int clip_len,
+                                int tokens, int heads, int head_dim, int64_t qkv_row_stride, int64_t o_row_stride,
+                                float scale, void* stream) {
+    return fz_attn_temporal_ex(q, k, v, o, batch, clip_len, clip_len, tokens, heads, head_dim, qkv_row_stride,
+                               qkv_row_stride, o_row_stride, scale, stream);
 }

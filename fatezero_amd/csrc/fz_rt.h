@@ -167,6 +167,29 @@ FZ_DEVICE f32x16 fz_zero_f16v() {
     return z;
 }
 FZ_DEVICE half8_t fz_ld_h8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
+// 16-byte load from a wave-uniform base plus a 32-bit per-lane byte offset (the SGPR-base + VGPR-offset global_load form)
+FZ_DEVICE half8_t fz_ld_h8_off(const char* base, uint32_t byte_off) {
+    return *reinterpret_cast<const half8_t*>(base + byte_off);
+}
+// wave issue priority hint (0..3); no-op on the emulator
+FZ_DEVICE void fz_setprio_hi() {
+#ifndef FZ_EMU
+    __builtin_amdgcn_s_setprio(1);
+#endif
+}
+FZ_DEVICE void fz_setprio_lo() {
+#ifndef FZ_EMU
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+// a * b + c with a, b < 2^24: one full-rate v_mad_u32_u24 instead of a quarter-rate 32-bit multiply
+FZ_DEVICE uint32_t fz_mad24(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef FZ_EMU
+    return a * b + c;
+#else
+    return __umul24(a, b) + c;
+#endif
+}
 FZ_DEVICE void fz_st_h8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
 
 static inline int fz_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -27,6 +27,7 @@ struct GnArgs {
     float* partial;  // [n_frames][chunks][G][3]
     float* stats;    // [n_frames/span][G][2]
     int n_frames, span, tokens, C, G, chunks, V, R;
+    int fin_span;    // frames merged per stat set by gn_finalize (= span unless the partials were gathered from other ranks)
     float eps;
     int silu;
 };
@@ -106,11 +107,11 @@ FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
     // xor-butterfly merges the 64 lane results (deterministic order -> bitwise reproducible statistics)
     const int idx = blockIdx.x, lane = threadIdx.x;
     const int sp = idx / a.G, g = idx % a.G;
-    const int total = a.span * a.chunks;
+    const int total = a.fin_span * a.chunks;
     float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
     for (int e = lane; e < total; e += 64) {
         const int f = e / a.chunks, c = e % a.chunks;
-        const float* pp = a.partial + (((int64_t)(sp * a.span + f) * a.chunks + c) * a.G + g) * 3;
+        const float* pp = a.partial + (((int64_t)(sp * a.fin_span + f) * a.chunks + c) * a.G + g) * 3;
         chan_merge(cnt, mean, m2, pp[0], pp[1], pp[2]);
     }
 #pragma unroll
@@ -160,30 +161,72 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
     }
 }
 
-extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
-                            int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream) {
-    if (!x || !y || !gamma || !beta || !partial) return FZ_ERR_BAD_ARG;
+static int gn_setup(GnArgs& a, int n_frames, int span, int tokens, int channels, int groups, int& threads, size_t& smem) {
     if (n_frames <= 0 || span <= 0 || n_frames % span || channels % 8 || channels % groups || groups > 64)
         return FZ_ERR_BAD_ARG;
-    GnArgs a;
-    a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
-    a.n_frames = n_frames; a.span = span; a.tokens = tokens; a.C = channels; a.G = groups;
+    a.n_frames = n_frames; a.span = span; a.fin_span = span; a.tokens = tokens; a.C = channels; a.G = groups;
     a.chunks = fz_groupnorm_chunks(tokens, channels);
     a.V = channels / 8;
     if (a.V > 1024) return FZ_ERR_UNSUPPORTED;
     a.R = a.V >= 256 ? 1 : 256 / a.V;
+    // >= G threads are needed for the per-group reduction; threads beyond V*R would alias rows, so V*R >= 64 is required
+    if (a.V * a.R < 64) return FZ_ERR_UNSUPPORTED;
+    threads = a.V * a.R;
+    smem = ((size_t)a.R * channels + groups) * sizeof(float);
+    return FZ_OK;
+}
+
+extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
+                            int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream) {
+    if (!x || !y || !gamma || !beta || !partial) return FZ_ERR_BAD_ARG;
+    GnArgs a;
+    int threads;
+    size_t smem;
+    const int rc = gn_setup(a, n_frames, span, tokens, channels, groups, threads, smem);
+    if (rc != FZ_OK) return rc;
+    a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
     a.eps = eps; a.silu = silu;
     a.partial = partial;
     a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
-    const int threads = a.V * a.R < 64 ? 64 : a.V * a.R;  // >= G threads are needed for the per-group reduction
-    // threads beyond V*R would alias rows: keep r < R by construction (threads == V*R unless tiny C)
-    if (a.V * a.R < 64) return FZ_ERR_UNSUPPORTED;
     dim3 grid(a.chunks, n_frames), block(threads);
-    const size_t smem = ((size_t)a.R * channels + groups) * sizeof(float);
     FZ_LAUNCH(gn_stats_kernel, grid, block, smem, stream, a);
     const int nst = (n_frames / span) * groups;
     FZ_LAUNCH(gn_finalize_kernel, dim3(nst), dim3(64), 0, stream, a);
     FZ_LAUNCH(gn_apply_kernel, grid, block, 0, stream, a);
+    return fz_last_launch_status();
+}
+
+extern "C" int fz_groupnorm_stats(const void* x, int n_frames, int tokens, int channels, int groups, float* partial,
+                                  void* stream) {
+    if (!x || !partial) return FZ_ERR_BAD_ARG;
+    GnArgs a;
+    int threads;
+    size_t smem;
+    const int rc = gn_setup(a, n_frames, 1, tokens, channels, groups, threads, smem);
+    if (rc != FZ_OK) return rc;
+    a.x = (const half_t*)x; a.y = nullptr; a.gamma = nullptr; a.beta = nullptr; a.eps = 0.0f; a.silu = 0;
+    a.partial = partial; a.stats = nullptr;
+    FZ_LAUNCH(gn_stats_kernel, dim3(a.chunks, n_frames), dim3(threads), smem, stream, a);
+    return fz_last_launch_status();
+}
+
+extern "C" int fz_groupnorm_apply(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
+                                  int tokens, int channels, int groups, float eps, int silu, const float* partial_all,
+                                  int stat_sets, int frames_per_set, float* stats, void* stream) {
+    if (!x || !y || !gamma || !beta || !partial_all || !stats || stat_sets <= 0 || frames_per_set <= 0) return FZ_ERR_BAD_ARG;
+    GnArgs a;
+    int threads;
+    size_t smem;
+    const int rc = gn_setup(a, n_frames, span, tokens, channels, groups, threads, smem);
+    if (rc != FZ_OK) return rc;
+    if (n_frames / span != stat_sets) return FZ_ERR_BAD_ARG;
+    a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
+    a.eps = eps; a.silu = silu;
+    a.partial = const_cast<float*>(partial_all);
+    a.stats = stats;
+    a.fin_span = frames_per_set;
+    FZ_LAUNCH(gn_finalize_kernel, dim3(stat_sets * groups), dim3(64), 0, stream, a);
+    FZ_LAUNCH(gn_apply_kernel, dim3(a.chunks, n_frames), dim3(threads), 0, stream, a);
     return fz_last_launch_status();
 }
 

@@ -1,14 +1,23 @@
 """Multi-GPU layer: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / gloo in CPU tests.
 
-Round-1 sharding: the job is data-parallel over CLIPS -- every rank runs the whole inversion -> edit job on its own
-clip, with no collective inside the UNet.  RCCL only ever carries latents (SURVEY.md §8e "start / end"): rank 0's
-weights checksum / prompts are broadcast-checked, and the edited latents are all-gathered.  Frame-sharding ONE clip
-across ranks needs the exchanges listed in SURVEY.md §8e (GroupNorm partial sums, anchor/neighbour K/V, temporal
-halo); the GroupNorm kernels are already split into stats / finalize / apply for that purpose, the exchanges
-themselves are future work.
+Two ways to use N GPUs:
+
+* clips (default of bench.py --gpus N): the job is data-parallel over CLIPS -- every rank runs the whole inversion ->
+  edit job on its own clip, with no collective inside the UNet.  RCCL only ever carries latents: rank 0's weights
+  checksum is broadcast-checked and the edited latents are all-gathered.
+* frames (`FrameShard`): ONE clip's frames are partitioned over the ranks (each keeps its slice of the HBM map arena
+  and of the blend masks).  Frames are coupled in four places, and those are the only collectives on the data path:
+    - 5-D GroupNorm statistics span all frames  -> all-gather of the Welford partials, merged identically everywhere
+      (fz_groupnorm_stats / fz_groupnorm_apply);
+    - sparse-causal K/V of neighbour / anchor frames -> point-to-point fetch of those frames' K and V^T from their owners
+      into an extended K/V frame axis the attention kernels index directly (FzAttnSelfDesc.kv_clip_len);
+    - the k=3 temporal LoRA convolution           -> one-frame halo exchange with the neighbours (twice: x, then down(x));
+    - temporal attention over all F frames per pixel -> all-gather of that layer's K and V.
+  CFG, the DDIM update, blend masks (normalised per frame) and the latent blend are per-frame and need nothing.
 """
+import contextlib
 import os
-from typing import Callable, List, Optional
+from typing import Callable, List, Optional, Sequence
 
 import torch
 
@@ -71,3 +80,127 @@ def edit_clips(job: Callable[[int], torch.Tensor], n_clips: int, device) -> Opti
         for j in range(len(clips_for_rank(n_clips, world, r))):
             result.append(bufs[r][j])
     return result
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# frame-sharding one clip
+# ---------------------------------------------------------------------------------------------------------------
+class FrameShard:
+    """Contiguous block partition of the F frames of one clip over the ranks of a process group."""
+
+    def __init__(self, clip_len: int, group=None, rank: Optional[int] = None, world: Optional[int] = None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = world if world is not None else dist.get_world_size(group)
+        self.rank = rank if rank is not None else dist.get_rank(group)
+        if clip_len < self.world:
+            raise ValueError(f"cannot shard {clip_len} frames over {self.world} ranks: every rank needs a frame")
+        self.clip_len = clip_len
+        base, rem = divmod(clip_len, self.world)
+        self.bounds = [r * base + min(r, rem) for r in range(self.world + 1)]
+        self.f0, self.f1 = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.n_local = self.f1 - self.f0
+        self.max_local = base + (1 if rem else 0)
+
+    # -- bookkeeping ---------------------------------------------------------------------------------------------
+    def frames_of(self, rank: int) -> range:
+        return range(self.bounds[rank], self.bounds[rank + 1])
+
+    def owner(self, frame: int) -> int:
+        for r in range(self.world):
+            if frame < self.bounds[r + 1]:
+                return r
+        raise IndexError(frame)
+
+    def _peer(self, rank: int) -> int:
+        import torch.distributed as dist
+        return rank if self.group is None else dist.get_global_rank(self.group, rank)
+
+    def local(self, x: torch.Tensor, dim: int) -> torch.Tensor:
+        """This rank's frames of a tensor that holds all F frames along `dim`."""
+        return x.narrow(dim, self.f0, self.n_local)
+
+    # -- collectives ---------------------------------------------------------------------------------------------
+    def all_gather_frames(self, x_local: torch.Tensor) -> torch.Tensor:
+        """x_local [B, F_local, ...] -> [B, F, ...] on every rank (frames in clip order)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return x_local
+        b = x_local.shape[0]
+        rest = tuple(x_local.shape[2:])
+        if self.n_local == self.max_local:
+            mine = x_local.contiguous()
+        else:  # ragged partition: pad to the largest block
+            mine = x_local.new_zeros((b, self.max_local) + rest)
+            mine[:, : self.n_local] = x_local
+        bufs = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(bufs, mine, group=self.group)
+        return torch.cat([bufs[r][:, : len(self.frames_of(r))] for r in range(self.world)], dim=1)
+
+    def fetch_frames(self, x_local: torch.Tensor, wanted: Callable[[int], Sequence[int]], *,
+                     zero_outside: bool = False) -> torch.Tensor:
+        """Point-to-point gather of whole frames.  `wanted(rank)` lists the GLOBAL frame indices rank `rank` needs (the
+        same pure function on every rank, so each one also knows what to send).  Indices outside [0, F) are clamped
+        into the clip (sparse-causal attention, attention.py:383-386) or, with zero_outside, return zeros (the zero
+        padding of the temporal convolution).  x_local: [B, F_local, ...] -> [B, len(wanted(my rank)), ...]."""
+        import torch.distributed as dist
+
+        def resolve(g):
+            if 0 <= g < self.clip_len:
+                return g
+            return None if zero_outside else min(max(g, 0), self.clip_len - 1)
+
+        mine = [resolve(g) for g in wanted(self.rank)]
+        b, rest = x_local.shape[0], tuple(x_local.shape[2:])
+        out = x_local.new_zeros((b, len(mine)) + rest)
+        ops, recvs, keep = [], [], []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            theirs = [resolve(g) for g in wanted(r)]
+            send = [g for g in theirs if g is not None and self.f0 <= g < self.f1]
+            if send:  # one message per (sender, receiver): the frames in the receiver's slot order
+                buf = torch.stack([x_local[:, g - self.f0] for g in send], dim=1).contiguous()
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, self._peer(r), group=self.group))
+            slots = [i for i, g in enumerate(mine) if g is not None and self.owner(g) == r]
+            if slots:
+                buf = x_local.new_empty((b, len(slots)) + rest)
+                recvs.append((slots, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, self._peer(r), group=self.group))
+        for i, g in enumerate(mine):
+            if g is not None and self.f0 <= g < self.f1:
+                out[:, i] = x_local[:, g - self.f0]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for slots, buf in recvs:
+            out[:, slots] = buf
+        return out
+
+    def with_halo(self, x_local: torch.Tensor, left: int, right: int, *, zero_outside: bool) -> torch.Tensor:
+        """[B, F_local, ...] -> [B, left + F_local + right, ...]: the neighbours' boundary frames on both sides."""
+        def wanted(r):
+            fr = self.frames_of(r)
+            return list(range(fr.start - left, fr.start)) + list(range(fr.stop, fr.stop + right))
+        halo = self.fetch_frames(x_local, wanted, zero_outside=zero_outside)
+        return torch.cat([halo[:, :left], x_local, halo[:, left:]], dim=1)
+
+
+_active_shard: Optional[FrameShard] = None
+
+
+def active_shard() -> Optional[FrameShard]:
+    """The FrameShard the model code must honour right now (None: all frames of the clip are local)."""
+    return _active_shard
+
+
+@contextlib.contextmanager
+def frame_sharded(shard: Optional[FrameShard]):
+    global _active_shard
+    prev = _active_shard
+    _active_shard = shard if (shard is not None and shard.world > 1) else None
+    try:
+        yield shard
+    finally:
+        _active_shard = prev

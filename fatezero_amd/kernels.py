@@ -83,11 +83,14 @@ def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out:
               heads: int, index_list: Sequence, mode: int = FZ_ATTN_FLASH, frame0: int = 0, n_frames: Optional[int] = None,
               p: Optional[torch.Tensor] = None, p_frame_off: int = 0, row_mask: Optional[torch.Tensor] = None,
               mask_frame_off: int = 0, scale: Optional[float] = None, k_head_major: Optional[torch.Tensor] = None,
-              q_log2_scaled: bool = False):
+              q_log2_scaled: bool = False, kv_slots_override: Optional[Tuple[List[int], List[int]]] = None,
+              kv_clip_len: int = 0, kv_frame_off: int = 0):
     """q,k,out: [N, L, >=C] views with row stride (token-major); vt: [N, C, Lpad]; p: [Fp, heads, Lq, Lk] fp16.
     k_head_major (optional): K as a contiguous [N, heads, L, d] tensor (fully coalesced key tiles) instead of `k`.
 
     q_log2_scaled: q already carries scale*log2(e) (folded into the projection weight), see include/fatezero_hip.h.
+    kv_clip_len / kv_frame_off / kv_slots_override: frame-sharded clips -- k / vt carry kv_clip_len frames per batch
+    element (halos + own frames + anchors, fatezero_amd/dist.py) and the slots are given on that extended axis.
 
     Frames frame0 .. frame0+n_frames-1 of q/out are processed; k/vt are indexed by source frame.
     """
@@ -96,8 +99,9 @@ def attn_self(q: torch.Tensor, k: Optional[torch.Tensor], vt: torch.Tensor, out:
     assert d_head in SUPPORTED_HEAD_DIMS, d_head
     _chk16(q, k, vt, out, p)
     n_frames = N_ - frame0 if n_frames is None else n_frames
-    kabs, kval = kv_slots(index_list, clip_len)
+    kabs, kval = kv_slots(index_list, clip_len) if kv_slots_override is None else kv_slots_override
     d = N.FzAttnSelfDesc()
+    d.kv_clip_len, d.kv_frame_off = kv_clip_len, kv_frame_off
     d.n_frames, d.frame0, d.clip_len, d.heads, d.head_dim = n_frames, frame0, clip_len, heads, d_head
     d.lq, d.lkf, d.n_kv = lq, (lq if k is None else k.shape[1]), len(kabs)
     for j in range(len(kabs)):
@@ -167,16 +171,21 @@ def attn_cross(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
     return out
 
 
-def attn_temporal(q, k, v, out, *, batch: int, clip_len: int, heads: int, scale: Optional[float] = None):
-    """q,k,v,out: [B*F, tokens, >=C] token-major views sharing one row stride."""
+def attn_temporal(q, k, v, out, *, batch: int, clip_len: int, heads: int, scale: Optional[float] = None,
+                  kv_frames: Optional[int] = None):
+    """q,out: [B*clip_len, tokens, >=C]; k,v: [B*kv_frames, tokens, >=C] token-major views (kv_frames defaults to clip_len;
+    it is larger when the clip is frame-sharded and k / v were all-gathered)."""
     _, tokens, c = q.shape
     d_head = c // heads
+    kv_frames = clip_len if kv_frames is None else kv_frames
     _chk16(q, k, v, out)
-    assert q.stride(1) == k.stride(1) == v.stride(1) and q.stride(0) == tokens * q.stride(1)
-    assert out.stride(0) == tokens * out.stride(1)
-    N.check(N.lib().fz_attn_temporal(_ptr(q), _ptr(k), _ptr(v), _ptr(out), batch, clip_len, tokens, heads, d_head,
-                                     q.stride(1), out.stride(1), float(scale if scale is not None else d_head ** -0.5),
-                                     _stream(q)), "fz_attn_temporal")
+    assert k.stride(1) == v.stride(1) and q.stride(0) == tokens * q.stride(1) and k.stride(0) == tokens * k.stride(1)
+    assert v.stride(0) == tokens * v.stride(1) and out.stride(0) == tokens * out.stride(1)
+    assert q.shape[0] == batch * clip_len and k.shape[0] == batch * kv_frames
+    N.check(N.lib().fz_attn_temporal_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), batch, clip_len, kv_frames, tokens, heads,
+                                        d_head, q.stride(1), k.stride(1), out.stride(1),
+                                        float(scale if scale is not None else d_head ** -0.5), _stream(q)),
+            "fz_attn_temporal_ex")
     return out
 
 
@@ -221,6 +230,35 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span:
         _gn_scratch[key] = buf
     N.check(N.lib().fz_groupnorm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), n, span, tokens, c, groups, float(eps),
                                  1 if silu else 0, _ptr(buf), _stream(x)), "fz_groupnorm")
+    return out
+
+
+def groupnorm_stats(x: torch.Tensor, *, groups: int) -> torch.Tensor:
+    """Welford partials (count, mean, M2) of this rank's frames: float [N, chunks, G, 3] (fz_groupnorm_stats)."""
+    n, tokens, c = x.shape
+    assert x.is_contiguous()
+    _chk16(x)
+    chunks = N.lib().fz_groupnorm_chunks(tokens, c)
+    partial = torch.empty(n, chunks, groups, 3, dtype=torch.float32, device=x.device)
+    N.check(N.lib().fz_groupnorm_stats(_ptr(x), n, tokens, c, groups, _ptr(partial), _stream(x)), "fz_groupnorm_stats")
+    return partial
+
+
+def groupnorm_apply(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, partial_all: torch.Tensor, *, span: int,
+                    groups: int, eps: float, silu: bool, out: Optional[torch.Tensor] = None):
+    """Normalise the local frames x [N, tokens, C] with statistics merged from partial_all
+    [stat_sets, frames_per_set, chunks, G, 3] (the partials of ALL ranks' frames); frame n uses stat set n // span."""
+    n, tokens, c = x.shape
+    assert x.is_contiguous() and partial_all.is_contiguous() and partial_all.dtype == torch.float32
+    sets, per_set = partial_all.shape[0], partial_all.shape[1]
+    assert n // span == sets and partial_all.shape[2] == N.lib().fz_groupnorm_chunks(tokens, c)
+    _chk16(x, gamma, beta)
+    if out is None:
+        out = torch.empty_like(x)
+    stats = torch.empty(sets, groups, 2, dtype=torch.float32, device=x.device)
+    N.check(N.lib().fz_groupnorm_apply(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), n, span, tokens, c, groups, float(eps),
+                                       1 if silu else 0, _ptr(partial_all), sets, per_set, _ptr(stats), _stream(x)),
+            "fz_groupnorm_apply")
     return out
 
 

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ... import dist as D
 from ... import kernels as K
 from .resnet import Tokens, _LinearParams, _NormParams, group_norm_tokens
 
@@ -149,6 +150,13 @@ class CrossAttention(nn.Module):
         qkv = F.linear(x_norm, self._qkv)
         inner = self.inner_dim
         out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
+        shard = D.active_shard()
+        if shard is not None:  # every pixel attends over ALL frames of the clip: gather this layer's K and V
+            kv = shard.all_gather_frames(qkv[..., inner:].reshape(batch, clip, l, 2 * inner))
+            kv = kv.reshape(batch * shard.clip_len, l, 2 * inner)
+            K.attn_temporal(qkv[..., :inner], kv[..., :inner], kv[..., inner:], out, batch=batch, clip_len=clip,
+                            kv_frames=shard.clip_len, heads=self.heads, scale=self.scale)
+            return self.to_out[0].apply(out)
         K.attn_temporal(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], out, batch=batch, clip_len=clip,
                         heads=self.heads, scale=self.scale)
         return self.to_out[0].apply(out)
@@ -157,6 +165,36 @@ class CrossAttention(nn.Module):
         self._qk = None
         self._qkv = None
         return super().load_state_dict(*a, **k)
+
+
+def _sharded_kv(shard, kk, vt, batch, clip, index_list):
+    """K / V^T of a frame-sharded clip on an extended frame axis [left halo | own frames | right halo | anchors]: the
+    neighbour frames a relative index reaches and the 'first' / 'mid' / 'last' anchors are fetched from their owners
+    (attention.py:376-386 semantics: relative indices clamp to the CLIP ends, anchors are global frame numbers)."""
+    rel = [i for i in index_list if not isinstance(i, str)]
+    left, right = max([0] + [-i for i in rel]), max([0] + [i for i in rel])
+    anchors = [a for a in dict.fromkeys(K.kv_slots([i], shard.clip_len)[1][0] for i in index_list if isinstance(i, str))]
+
+    def wanted(r):
+        fr = shard.frames_of(r)
+        return list(range(fr.start - left, fr.start)) + list(range(fr.stop, fr.stop + right)) + anchors
+
+    def extend(t):  # [B*clip, ...] -> [B*(left+clip+right+len(anchors)), ...]
+        t4 = t.reshape(batch, clip, *t.shape[1:])
+        got = shard.fetch_frames(t4, wanted)
+        e = torch.cat([got[:, :left], t4, got[:, left:]], dim=1)
+        return e.reshape(batch * e.shape[1], *t.shape[1:])
+
+    kabs, kval = [], []
+    for i in index_list:
+        if isinstance(i, str):
+            kabs.append(1)
+            kval.append(left + clip + right + anchors.index(K.kv_slots([i], shard.clip_len)[1][0]))
+        else:
+            kabs.append(0)
+            kval.append(int(i))
+    ext = dict(kv_slots_override=(kabs, kval), kv_clip_len=left + clip + right + len(anchors), kv_frame_off=left)
+    return extend(kk), extend(vt), ext
 
 
 class SparseCausalAttention(CrossAttention):
@@ -179,6 +217,10 @@ class SparseCausalAttention(CrossAttention):
         out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
         n_kv = max(1, len(index_list))
         kw = dict(clip_len=clip, heads=self.heads, index_list=index_list, scale=self.scale, q_log2_scaled=folded)
+        shard = D.active_shard()
+        if shard is not None and len(index_list) > 0:
+            kk, vt, ext = _sharded_kv(shard, kk, vt, n // clip, clip, index_list)
+            kw.update(ext)
         ctrl = self.controller
         plan = _plan_for(ctrl, False, self.place_in_unet, n, clip, self.heads, lq, n_kv * lq, xn.device)
         if plan is None:

@@ -8,6 +8,7 @@ reference's (`down.weight [r, C, 3]`, `up.weight [C, r, 3]`) so checkpoints load
 import torch
 from torch import nn
 
+from ... import dist as D
 from ... import kernels as K
 
 
@@ -87,6 +88,19 @@ class LoRALinearLayer(nn.Module):
         b, f, t, c = x4.shape
         if is_noop:
             y = x4
+            if temb is not None:
+                y = y + temb[:, None, None, :]
+            if residual is not None:
+                y = y + residual.view(b, f, t, c)
+            return y
+        shard = D.active_shard()
+        if shard is not None:
+            # the clip's frames are split over ranks: one-frame halos from the neighbours (zeros beyond the clip ends, the
+            # conv's own padding), first of x, then of down(x); the halo frames' outputs are dropped
+            x_ext = shard.with_halo(x4, 1, 1, zero_outside=True)
+            d = temporal_conv_tokens(x_ext, wd)[:, 1:-1].contiguous()
+            d_ext = shard.with_halo(d, 1, 1, zero_outside=True)
+            y = temporal_conv_tokens(d_ext, wu)[:, 1:-1] + x4
             if temb is not None:
                 y = y + temb[:, None, None, :]
             if residual is not None:

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ... import dist as D
 from ... import kernels as K
 from .lora import LoRALinearLayer, _Conv1dParams, temporal_conv_tokens
 
@@ -146,6 +147,15 @@ class _NormParams(nn.Module):
 
 def group_norm_tokens(norm: _NormParams, x: Tokens, *, span_frames: bool, silu: bool) -> Tokens:
     g, b = norm.packed(x.data.device)
+    shard = D.active_shard()
+    if shard is not None and span_frames:
+        # statistics span ALL frames of the clip, this rank holds x.f of them: exchange the Welford partials (a few KB)
+        # and merge them in the same fixed order on every rank
+        n, _, _ = x.data.shape
+        part = K.groupnorm_stats(x.data, groups=norm.num_groups)
+        allp = shard.all_gather_frames(part.view(n // x.f, x.f, *part.shape[1:])).contiguous()
+        y = K.groupnorm_apply(x.data, g, b, allp, span=x.f, groups=norm.num_groups, eps=norm.eps, silu=silu)
+        return x.like(y)
     y = K.groupnorm(x.data, g, b, span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps, silu=silu)
     return x.like(y)
 

@@ -63,6 +63,13 @@ typedef struct FzAttnSelfDesc {
                                Wq), so q.k IS the log2-domain logit and `scale` is not applied again.  For
                                head_dim % 16 != 0 this lets the running max ride in a free contraction slot of
                                the QK^T MFMA (csrc/attn_flash.hip).  0: q as the reference's to_q produces it. */
+    /* Frame-sharded clips (one clip's frames split over GPUs): k / vt then hold, per batch element, kv_clip_len
+     * frames [left halo | the rank's own frames | right halo | anchor frames] gathered from their owners, while q / o
+     * keep clip_len (= local) frames.  A relative slot reads frame clamp(f + kv_frame_off + kv_val, 0, kv_clip_len-1),
+     * an absolute slot reads frame kv_val of that extended axis.  kv_clip_len == 0: k / vt have clip_len frames and
+     * kv_frame_off is ignored (the single-GPU layout). */
+    int32_t kv_clip_len;
+    int32_t kv_frame_off;
     int32_t reserved0;
 } FzAttnSelfDesc;
 
@@ -106,6 +113,12 @@ int fz_attn_temporal(const void* q, const void* k, const void* v, void* o, int b
                      int tokens, int heads, int head_dim, int64_t qkv_row_stride, int64_t o_row_stride,
                      float scale, void* stream);
 
+/* Same with q/o holding q_frames frames per batch element and k/v holding kv_frames (a frame-sharded clip: the rank's
+ * own query frames against the all-gathered keys/values); q/o rows are [B*q_frames][tokens], k/v rows [B*kv_frames][tokens]. */
+int fz_attn_temporal_ex(const void* q, const void* k, const void* v, void* o, int batch, int q_frames, int kv_frames,
+                        int tokens, int heads, int head_dim, int64_t q_row_stride, int64_t kv_row_stride,
+                        int64_t o_row_stride, float scale, void* stream);
+
 /* Blend mask (SpatialBlender.get_mask, spatial_blend.py:24-56): maps: n_maps pointers to fp16 cross maps
  * [P][F][heads][r*r][p_row_stride] (P = n_prompts, prompt stride given), alpha: float [P][80] word weights;
  * out: float [P][F][h][w] of 0/1 after 3x3 max-pool, nearest resize, per-(P,F) max normalisation, > th.
@@ -121,6 +134,17 @@ int fz_blend_mask(const void* const* maps, int n_maps, int n_prompts, int64_t pr
 int fz_groupnorm_chunks(int tokens, int channels);
 int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
                  int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream);
+
+/* The two halves of fz_groupnorm for statistics that span frames living on several GPUs:
+ *   fz_groupnorm_stats  writes this rank's Welford partials  partial[n_frames][chunks][G][3] = (count, mean, M2);
+ *   (the caller all-gathers them over the ranks and orders them [stat_sets][frames_per_set][chunks][G][3])
+ *   fz_groupnorm_apply  Chan-merges partial_all per (stat set, group) in a fixed order -- bitwise identical on every
+ *                       rank -- into stats[stat_sets][G][2] (scratch) and normalises the local frames:
+ *                       frame n uses stat set n / span, so n_frames / span must equal stat_sets. */
+int fz_groupnorm_stats(const void* x, int n_frames, int tokens, int channels, int groups, float* partial, void* stream);
+int fz_groupnorm_apply(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span, int tokens,
+                       int channels, int groups, float eps, int silu, const float* partial_all, int stat_sets,
+                       int frames_per_set, float* stats, void* stream);
 
 /* 3x3 convolution (pad 1) of PseudoConv3d's spatial part (resnet.py:57-64) on token-major activations, as an MFMA
  * implicit GEMM with the elementwise tail fused: y = conv(x) + bias (+ temb[n / frames_per_batch]) (+ res).

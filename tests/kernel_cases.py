@@ -216,6 +216,59 @@ def case_groupnorm(device, *, n, span, tokens, c, groups, silu, eps=1e-5, seed=0
     return {"max_err": err}
 
 
+def case_sharded_pieces(device, *, batch, clip, lo, hi, heads, d, tokens, groups, seed=0):
+    """The kernel forms a frame-sharded clip uses, driven the way a rank owning frames [lo, hi) of the clip would drive them
+    (fatezero_amd/dist.py), checked against the single-GPU kernels on the whole clip: split GroupNorm, sparse-causal
+    attention on the extended K/V frame axis [left halo | own | right halo | anchors], temporal attention with gathered K/V."""
+    g = torch.Generator().manual_seed(seed)
+    c, fl, res = heads * d, hi - lo, {}
+
+    def own(t):  # frames [lo, hi) of every batch element of a [(b f), ...] tensor
+        return t.reshape(batch, clip, *t.shape[1:])[:, lo:hi].reshape(batch * fl, *t.shape[1:]).contiguous()
+
+    # -- GroupNorm: partials of all frames (here computed locally, in clip order) + apply on the own frames ------
+    x = ((torch.randn(batch * clip, tokens, c, generator=g) * 2 + 1).half()).to(device)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).half().to(device)
+    beta = (0.3 * torch.randn(c, generator=g)).half().to(device)
+    y_full = K.groupnorm(x, gamma, beta, span=clip, groups=groups, eps=1e-5, silu=True)
+    part = K.groupnorm_stats(x, groups=groups)
+    y_own = K.groupnorm_apply(own(x), gamma, beta, part.view(batch, clip, *part.shape[1:]).contiguous(), span=fl,
+                              groups=groups, eps=1e-5, silu=True)
+    assert torch.equal(y_own, own(y_full)), "split GroupNorm must reproduce fz_groupnorm bit for bit"
+    # -- sparse-causal attention, index [-1, 'first', +1]: halos of one frame on both sides + anchor frame 0 -----
+    qk = _mk((batch * clip, tokens, 2 * c), g, device, 1.5)
+    q, k = qk[..., :c], qk[..., c:]
+    v = _mk((batch * clip, tokens, c), g, device)
+    vt = _vt(v, K.pad64(tokens))
+    idx = [-1, "first", 1]
+    o_full = torch.empty(batch * clip, tokens, c, dtype=torch.float16, device=device)
+    K.attn_self(q, k, vt, o_full, clip_len=clip, heads=heads, index_list=idx, mode=K.FZ_ATTN_FLASH)
+
+    def ext(t):
+        t4 = t.reshape(batch, clip, *t.shape[1:])
+        sel = [max(lo - 1, 0)] + list(range(lo, hi)) + [min(hi, clip - 1)] + [0]
+        return t4[:, sel].reshape(batch * len(sel), *t.shape[1:]).contiguous()
+    o_own = torch.empty(batch * fl, tokens, c, dtype=torch.float16, device=device)
+    K.attn_self(own(q), ext(k), ext(vt), o_own, clip_len=fl, heads=heads, index_list=idx, mode=K.FZ_ATTN_FLASH,
+                kv_slots_override=([0, 1, 0], [-1, fl + 2, 1]), kv_clip_len=fl + 3, kv_frame_off=1)
+    assert torch.equal(o_own, own(o_full)), "extended K/V frame axis must address the same frames"
+    p_full = torch.empty(batch * clip, heads, tokens, 3 * tokens, dtype=torch.float16, device=device)
+    K.attn_self(q, k, vt, o_full, clip_len=clip, heads=heads, index_list=idx, mode=K.FZ_ATTN_CAPTURE, p=p_full)
+    p_own = torch.empty(batch * fl, heads, tokens, 3 * tokens, dtype=torch.float16, device=device)
+    K.attn_self(own(q), ext(k), ext(vt), o_own, clip_len=fl, heads=heads, index_list=idx, mode=K.FZ_ATTN_CAPTURE, p=p_own,
+                kv_slots_override=([0, 1, 0], [-1, fl + 2, 1]), kv_clip_len=fl + 3, kv_frame_off=1)
+    assert torch.equal(p_own, own(p_full)) and torch.equal(o_own, own(o_full))
+    # -- temporal attention: own query frames against all frames' K/V ------------------------------------------
+    qkv = _mk((batch * clip, tokens, 3 * c), g, device)
+    t_full = torch.empty(batch * clip, tokens, c, dtype=torch.float16, device=device)
+    K.attn_temporal(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], t_full, batch=batch, clip_len=clip, heads=heads)
+    kv = qkv[..., c:].contiguous()
+    t_own = torch.empty(batch * fl, tokens, c, dtype=torch.float16, device=device)
+    K.attn_temporal(own(qkv)[..., :c], kv[..., :c], kv[..., c:], t_own, batch=batch, clip_len=fl, kv_frames=clip, heads=heads)
+    assert torch.equal(t_own, own(t_full))
+    return res
+
+
 def case_layernorm(device, *, rows, c, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = (torch.randn(rows, c, generator=g) * 2 + 1).half().to(device)

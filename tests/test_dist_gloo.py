@@ -87,3 +87,110 @@ def test_clip_partition():
         for w in (1, 2, 4, 8):
             allc = sum((clips_for_rank(n, w, r) for r in range(w)), [])
             assert allc == list(range(n))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# frame-sharding ONE clip: GroupNorm partials, K/V halos + anchors, temporal conv halo, temporal attention
+# ---------------------------------------------------------------------------------------------------------------
+def _frame_job_factory(frames, index_list):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fatezero_amd import _native, build
+    _native.use_test_backend(build.build_emu())
+    import pipeline_cases as PC
+    from fatezero_amd.synthetic import WordTokenizer
+    from fatezero_amd.video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline
+    from fatezero_amd.video_diffusion.schedulers import DDIMScheduler
+    # procedural weights have non-zero temporal LoRA `up` and temporal-attention output weights: every exchange is live
+    unet = PC.build_unet("tiny16", {"lora": 16, "SparseCausalAttention_index": index_list}, "cpu")
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=WordTokenizer(), unet=unet,
+                                         scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(7)
+    emb = torch.randn(2, 77, 64, generator=g)
+    pipe._encode_prompt = lambda *a, **k: emb
+    z0 = torch.randn(1, 4, frames, 8, 8, generator=g)
+
+    def job():
+        pipe.scheduler.set_timesteps(2)
+        pipe.store_controller = type(pipe.store_controller)()
+        lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1, text_embeddings=emb,
+                                                 store_attention=True, LOW_RESOURCE=True, latents=z0)
+        out = pipe(prompt="a red car", source_prompt="a blue car", edit_type="swap", num_inference_steps=2,
+                   latents=lat[-1], output_type="latent", cross_replace_steps={"default_": 0.5}, self_replace_steps=0.5,
+                   use_inversion_attention=True, is_replace_controller=True, save_self_attention=False, guidance_scale=3.0)
+        return torch.stack([lat[-1], out["sdimage_output"].images])
+    return pipe, job
+
+
+def _frame_worker(rank, world, port, frames, index_list, run_model, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), FZ_EMU_THREADS="2")
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    from fatezero_amd import dist as D
+    import torch.distributed as dist
+    D.init("gloo")
+    shard = D.FrameShard(frames)
+    # -- the exchange primitives against slicing of the full tensor ---------------------------------------------
+    full = torch.arange(2 * frames * 3, dtype=torch.float32).view(2, frames, 3) + 1.0
+    loc = shard.local(full, 1).contiguous()
+    assert torch.equal(shard.all_gather_frames(loc), full)
+    zpad = torch.zeros(2, 2, 3)
+    padded = torch.cat([zpad, full, zpad], 1)
+    assert torch.equal(shard.with_halo(loc, 1, 2, zero_outside=True), padded[:, shard.f0 + 1: shard.f1 + 4])
+    clamped = torch.cat([full[:, :1]] * 2 + [full] + [full[:, -1:]] * 2, 1)
+    assert torch.equal(shard.with_halo(loc, 2, 1, zero_outside=False), clamped[:, shard.f0: shard.f1 + 3])
+    anchors = shard.fetch_frames(loc, lambda r: [0, (frames - 1) // 2, frames - 1, frames + 3])
+    assert torch.equal(anchors, full[:, [0, (frames - 1) // 2, frames - 1, frames - 1]])
+    if run_model:
+        pipe, job = _frame_job_factory(frames, index_list)
+        assert D.weights_agree(pipe.unet, "cpu")
+        pipe.frame_shard = shard
+        res = job()
+        store = pipe.store_controller
+        n_maps = [t.shape[0] for t in store.attention_store_all_step[0]["down_self"]] if store.attention_store_all_step else []
+        if rank == 0:
+            q.put((res.clone(), n_maps, shard.n_local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_frame_worker, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=900) if args[2] else None
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    for k in ("WORLD_SIZE", "RANK"):
+        os.environ.pop(k, None)
+    return got
+
+
+def test_frame_shard_exchanges_three_ranks_ragged():
+    _spawn(3, 7, [-1, "first"], False)   # 3 + 2 + 2 frames: a middle rank with two neighbours, ragged all-gather
+
+
+@pytest.mark.parametrize("frames,index_list", [(5, [-1, "first"]), (4, ["mid", 1])])
+def test_frame_sharded_clip_matches_single_process(frames, index_list):
+    got, n_maps, n_local = _spawn(2, frames, index_list, True)
+    _, job = _frame_job_factory(frames, index_list)
+    from fatezero_amd import _native
+    try:
+        ref = job()
+    finally:
+        _native.reset_backend()
+    # each rank keeps only its own frames' attention maps
+    assert n_maps and all(n == n_local for n in n_maps), (n_maps, n_local)
+    # same kernels, same inputs; only the merge order of the GroupNorm partials and the shapes of the temporal-conv GEMMs
+    # differ (fp16 rounding of down(x)), which 2 + 2 DDIM steps with guidance amplify to a few 1e-3 of the latent range.
+    # A wrong halo / anchor frame shows up as tens of percent.
+    err = float((got.float() - ref.float()).abs().max())
+    scale = float(ref.float().abs().max())
+    assert torch.isfinite(got.float()).all()
+    assert err <= 1.5e-2 * scale, (err, scale)

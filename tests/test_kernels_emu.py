@@ -113,3 +113,9 @@ def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=3, tokens=20, cin=64, cout=32, with_res=False)
     KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
     KC.case_temporal_conv3(DEV, batch=1, clip=1, tokens=16, cin=32, cout=40, with_res=True)
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 2), (2, 4), (3, 5)])
+def test_frame_shard_kernel_forms(lo, hi):
+    # what a rank owning frames [lo, hi) of a 5-frame clip launches, against the single-GPU kernels on the whole clip
+    KC.case_sharded_pieces(DEV, batch=2, clip=5, lo=lo, hi=hi, heads=2, d=40, tokens=64, groups=8)

@@ -119,3 +119,9 @@ def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=160, cout=320, with_res=True)
     KC.case_temporal_conv3(DEV, batch=1, clip=8, tokens=64, cin=160, cout=1280, with_res=True)
     KC.case_temporal_conv3(DEV, batch=1, clip=3, tokens=100, cin=1280, cout=160, with_res=False)
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 2), (2, 4), (3, 5)])
+def test_frame_shard_kernel_forms(lo, hi):
+    # what a rank owning frames [lo, hi) of a 5-frame clip launches, against the single-GPU kernels on the whole clip
+    KC.case_sharded_pieces(DEV, batch=2, clip=5, lo=lo, hi=hi, heads=2, d=40, tokens=256, groups=8)
