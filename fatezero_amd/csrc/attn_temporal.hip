@@ -7,6 +7,7 @@
 // through L1 by the F threads of that pixel, and scores live in LDS.
 #include "fz_rt.h"
 #include "../../include/fatezero_hip.h"
+#include <stdlib.h>
 
 #define TMAXF 64
 #define TTHREADS 256
@@ -79,6 +80,90 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) 
     }
 }
 
+// LDS-staged form (the default whenever the K/V rows of a token group fit): the F key rows and F value rows of
+// `tok_per_block` tokens are copied global -> LDS once, with every lane moving 16 contiguous bytes of a 2C-byte row,
+// instead of being re-read through L1 by each of the F query frames with an 80..320-byte lane stride.
+FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_lds_kernel(TemporalArgs a) {
+    FZ_DYN_SMEM(raw);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int tok0 = blockIdx.x * a.tok_per_block;
+    const int C = a.heads * a.dh, cvec = C >> 3;
+    half_t* Ks = reinterpret_cast<half_t*>(raw);                  // [tok_per_block][F][C]
+    half_t* Vs = Ks + (size_t)a.tok_per_block * a.F * C;          // same
+    float* S = reinterpret_cast<float*>(Vs + (size_t)a.tok_per_block * a.F * C);  // [TTHREADS][F]
+    const int rows = a.tok_per_block * a.F;
+    for (int id = tid; id < rows * cvec; id += TTHREADS) {
+        const int row = id / cvec, cv = id % cvec;
+        const int tl = row / a.F, j = row % a.F;
+        int tok = tok0 + tl;
+        tok = tok < a.tokens ? tok : a.tokens - 1;
+        const int64_t g = ((int64_t)(b * a.F + j) * a.tokens + tok) * a.in_stride + cv * 8;
+        fz_st_h8(Ks + (size_t)row * C + cv * 8, fz_ld_h8(a.k + g));
+        fz_st_h8(Vs + (size_t)row * C + cv * 8, fz_ld_h8(a.v + g));
+    }
+    __syncthreads();
+    const int items = a.tok_per_block * a.heads * a.Fq;
+    const int nvec = a.dh >> 3;
+    float* myS = S + tid * a.F;
+    for (int w = tid; w < items; w += TTHREADS) {
+        const int h = w % a.heads;
+        const int tl = (w / a.heads) % a.tok_per_block;
+        const int i = w / (a.heads * a.tok_per_block);
+        const int tok = tok0 + tl;
+        if (tok >= a.tokens) continue;
+        const int col = h * a.dh;
+        const half_t* qrow = a.q + ((int64_t)(b * a.Fq + i) * a.tokens + tok) * a.q_stride + col;
+        const half_t* kt = Ks + (size_t)tl * a.F * C + col;
+        const half_t* vtok = Vs + (size_t)tl * a.F * C + col;
+        float mx = -1e30f;
+        for (int j = 0; j < a.F; ++j) {
+            float acc = 0.0f;
+            for (int c = 0; c < nvec; ++c) {
+                const half8_t qv = fz_ld_h8(qrow + 8 * c), kv = fz_ld_h8(kt + (size_t)j * C + 8 * c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)qv[e] * (float)kv[e];
+            }
+            acc *= a.scale;
+            myS[j] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        float sum = 0.0f;
+        for (int j = 0; j < a.F; ++j) {
+            const float e = __builtin_expf(myS[j] - mx);
+            myS[j] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < a.F; ++j) myS[j] = (float)(half_t)(myS[j] * inv);  // P is cast to fp16 before P.V
+        half_t* orow = a.o + ((int64_t)(b * a.Fq + i) * a.tokens + tok) * a.out_stride + col;
+        for (int c = 0; c < nvec; ++c) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+            for (int j = 0; j < a.F; ++j) {
+                const half8_t vv = fz_ld_h8(vtok + (size_t)j * C + 8 * c);
+                const float pj = myS[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+            }
+            half8_t ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (half_t)acc[e];
+            fz_st_h8(orow + 8 * c, ov);
+        }
+    }
+}
+
+static bool temporal_lds_disabled() {  // A/B knob
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_TEMPORAL_NOLDS");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, void* o, int batch, int q_frames,
                                    int kv_frames, int tokens, int heads, int head_dim, int64_t q_row_stride,
                                    int64_t kv_row_stride, int64_t o_row_stride, float scale, void* stream) {
@@ -92,10 +177,19 @@ extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, 
     a.in_stride = kv_row_stride; a.q_stride = q_row_stride; a.out_stride = o_row_stride; a.scale = scale;
     int tpb = TTHREADS / (heads * q_frames);
     if (tpb < 1) tpb = 1;
+    const size_t score_bytes = (size_t)TTHREADS * kv_frames * sizeof(float);
+    const size_t kv_bytes_per_token = (size_t)2 * kv_frames * heads * head_dim * sizeof(half_t);
+    int tpb_lds = tpb;
+    while (tpb_lds > 1 && tpb_lds * kv_bytes_per_token + score_bytes > 48 * 1024) tpb_lds >>= 1;
+    if (!temporal_lds_disabled() && tpb_lds * kv_bytes_per_token + score_bytes <= 64 * 1024) {
+        a.tok_per_block = tpb_lds;
+        dim3 grid((tokens + tpb_lds - 1) / tpb_lds, batch), block(TTHREADS);
+        FZ_LAUNCH(attn_temporal_lds_kernel, grid, block, tpb_lds * kv_bytes_per_token + score_bytes, stream, a);
+        return fz_last_launch_status();
+    }
     a.tok_per_block = tpb;
     dim3 grid((tokens + tpb - 1) / tpb, batch), block(TTHREADS);
-    const size_t smem = (size_t)TTHREADS * kv_frames * sizeof(float);
-    FZ_LAUNCH(attn_temporal_kernel, grid, block, smem, stream, a);
+    FZ_LAUNCH(attn_temporal_kernel, grid, block, score_bytes, stream, a);
     return fz_last_launch_status();
 }
 

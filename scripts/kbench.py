@@ -71,7 +71,19 @@ def tconv_bench():
     print(json.dumps(res))
 
 
+def temporal_bench():
+    dev, res = "cuda", {}
+    for (b, f, tokens, c) in [(1, 8, 4096, 320), (2, 8, 4096, 320), (1, 8, 1024, 640), (2, 8, 256, 1280), (2, 8, 64, 1280)]:
+        qkv = torch.randn(b * f, tokens, 3 * c).half().to(dev)
+        out = torch.empty(b * f, tokens, c, dtype=torch.float16, device=dev)
+        ms = timeit(lambda: K.attn_temporal(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], out, batch=b, clip_len=f, heads=8))
+        res[f"temporal_b{b}_f{f}_T{tokens}_C{c}"] = {"ms": ms, "GBps": qkv.numel() * 2 * (4 / 3) / ms / 1e6}
+    print(json.dumps(res))
+
+
 def main():
+    if "--temporal" in sys.argv:
+        return temporal_bench()
     if "--conv" in sys.argv:
         return conv_bench()
     if "--tconv" in sys.argv:
