@@ -5,19 +5,30 @@
 // statistics of one (batch, group) span ALL frames ("span" = F); inside SpatioTemporalTransformerModel
 // (attention.py:110) the input is 4-D [(b f),c,h,w] so they are per frame (span = 1).
 // Layout is x[n][token][C] fp16.  Three small HBM-bound kernels:
-//   gn_stats    : per (frame, 64-token chunk) Welford partials (n, mean, M2) for each group   (reads x once)
+//   gn_stats    : per (frame, token chunk) Welford partials (n, mean, M2) for each group      (reads x once)
 //   gn_finalize : deterministic Chan merge of the partials of a span -> (mean, rstd) per (span, group)
 //   gn_apply    : y = silu?((x - mean) * rstd * gamma + beta)                          (reads x once, writes y)
 // Split stats/apply is also the form frame-sharded multi-GPU needs: the finalize step is where the per-rank
 // partials are all-reduced.
 #include "fz_rt.h"
 #include "../../include/fatezero_hip.h"
+#include <stdlib.h>
 
-#define GN_TB 64 /* tokens per block */
+// Tokens per block ("chunk").  A block has V = C/8 vector lanes x R rows of threads; the chunk is sized so that a thread
+// owns <= 16 rows (all of them in flight as loads at once) and so that the small pyramid levels still launch >= 32 blocks
+// per frame -- at 16x16 tokens x 1280 channels a fixed 64-token chunk left 32 blocks to fill 256 CUs.
+static int gn_tb(int tokens, int channels) {
+    const int V = channels / 8;
+    const int R = V >= 256 ? 1 : 256 / (V > 0 ? V : 1);
+    int tb = 64;
+    while (tb > 8 && tb > 16 * R) tb >>= 1;
+    while (tb > 8 && tokens / tb < 32) tb >>= 1;
+    return tb;
+}
 
 extern "C" int fz_groupnorm_chunks(int tokens, int channels) {
-    (void)channels;
-    return (tokens + GN_TB - 1) / GN_TB;
+    const int tb = gn_tb(tokens, channels);
+    return (tokens + tb - 1) / tb;
 }
 
 struct GnArgs {
@@ -27,31 +38,52 @@ struct GnArgs {
     float* partial;  // [n_frames][chunks][G][3]
     float* stats;    // [n_frames/span][G][2]
     int n_frames, span, tokens, C, G, chunks, V, R;
+    int tb;          // tokens per chunk
     int fin_span;    // frames merged per stat set by gn_finalize (= span unless the partials were gathered from other ranks)
     float eps;
     int silu;
 };
 
+// ROWS > 0: the thread's (<= ROWS) rows of the chunk are loaded ONCE, all loads in flight together, and kept in registers
+// for the second sweep; ROWS == 0: rows are re-read (second sweep hits L2) -- wide channel counts that do not fit.
+template <int ROWS>
 FZ_KERNEL void gn_stats_kernel(GnArgs a) {
-    // two sweeps over the chunk (the second one hits L2): exact chunk mean first, then sum (x-mean)^2, so the
-    // partial variance never suffers the E[x^2]-E[x]^2 cancellation
+    // two sweeps over the chunk: exact chunk mean first, then sum (x-mean)^2, so the partial variance never suffers the
+    // E[x^2]-E[x]^2 cancellation
     FZ_DYN_SMEM(raw);
     float* red = reinterpret_cast<float*>(raw);  // [R][C]
     float* gmean = red + a.R * a.C;              // [G]
     const int tid = threadIdx.x, v = tid % a.V, r = tid / a.V;
     const int chunk = blockIdx.x, n = blockIdx.y;
-    const int t0 = chunk * GN_TB;
-    const int t1 = min(t0 + GN_TB, a.tokens);
+    const int t0 = chunk * a.tb;
+    const int t1 = min(t0 + a.tb, a.tokens);
     const int cg = a.C / a.G;
     const float cnt = (float)((t1 - t0) * cg);
     const half_t* base = a.x + ((int64_t)n * a.tokens) * a.C + v * 8;
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.0f;
-    for (int t = t0 + r; t < t1; t += a.R) {
-        const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+    half8_t xr[ROWS > 0 ? ROWS : 1];
+    if (ROWS > 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += (float)xv[e];
+        for (int i = 0; i < ROWS; ++i) {  // unconditional, clamped: every load is issued before the first use
+            int t = t0 + r + i * a.R;
+            t = t < t1 ? t : t1 - 1;
+            xr[i] = fz_ld_h8(base + (int64_t)t * a.C);
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if (t0 + r + i * a.R < t1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)xr[i][e];
+            }
+        }
+    } else {
+        for (int t = t0 + r; t < t1; t += a.R) {
+            const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)xv[e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[r * a.C + v * 8 + e] = s[e];
@@ -69,12 +101,25 @@ FZ_KERNEL void gn_stats_kernel(GnArgs a) {
         mu[e] = gmean[(v * 8 + e) / cg];
         s[e] = 0.0f;
     }
-    for (int t = t0 + r; t < t1; t += a.R) {
-        const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+    if (ROWS > 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float dlt = (float)xv[e] - mu[e];
-            s[e] += dlt * dlt;
+        for (int i = 0; i < ROWS; ++i) {
+            if (t0 + r + i * a.R < t1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dlt = (float)xr[i][e] - mu[e];
+                    s[e] += dlt * dlt;
+                }
+            }
+        }
+    } else {
+        for (int t = t0 + r; t < t1; t += a.R) {
+            const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dlt = (float)xv[e] - mu[e];
+                s[e] += dlt * dlt;
+            }
         }
     }
     __syncthreads();
@@ -133,8 +178,8 @@ FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
 FZ_KERNEL void gn_apply_kernel(GnArgs a) {
     const int tid = threadIdx.x, v = tid % a.V, r = tid / a.V;
     const int chunk = blockIdx.x, n = blockIdx.y;
-    const int t0 = chunk * GN_TB;
-    const int t1 = min(t0 + GN_TB, a.tokens);
+    const int t0 = chunk * a.tb;
+    const int t1 = min(t0 + a.tb, a.tokens);
     const int cg = a.C / a.G;
     const int sp = n / a.span;
     float sc[8], sh[8];
@@ -148,6 +193,7 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
     }
     const half_t* xb = a.x + ((int64_t)n * a.tokens) * a.C + v * 8;
     half_t* yb = a.y + ((int64_t)n * a.tokens) * a.C + v * 8;
+#pragma unroll 4
     for (int t = t0 + r; t < t1; t += a.R) {
         const half8_t xv = fz_ld_h8(xb + (int64_t)t * a.C);
         half8_t yv;
@@ -161,10 +207,33 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
     }
 }
 
+static bool gn_reread() {  // A/B knob: always re-read the chunk in the second sweep
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_GN_REREAD");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+static void gn_launch_stats(const GnArgs& a, dim3 grid, dim3 block, size_t smem, void* stream) {
+    const int rows = (a.tb + a.R - 1) / a.R;  // rows of a chunk per thread
+    if (gn_reread() || rows > 32) {
+        FZ_LAUNCH(gn_stats_kernel<0>, grid, block, smem, stream, a);
+    } else if (rows <= 12) {
+        FZ_LAUNCH(gn_stats_kernel<12>, grid, block, smem, stream, a);
+    } else if (rows <= 24) {
+        FZ_LAUNCH(gn_stats_kernel<24>, grid, block, smem, stream, a);
+    } else {
+        FZ_LAUNCH(gn_stats_kernel<32>, grid, block, smem, stream, a);
+    }
+}
+
 static int gn_setup(GnArgs& a, int n_frames, int span, int tokens, int channels, int groups, int& threads, size_t& smem) {
     if (n_frames <= 0 || span <= 0 || n_frames % span || channels % 8 || channels % groups || groups > 64)
         return FZ_ERR_BAD_ARG;
     a.n_frames = n_frames; a.span = span; a.fin_span = span; a.tokens = tokens; a.C = channels; a.G = groups;
+    a.tb = gn_tb(tokens, channels);
     a.chunks = fz_groupnorm_chunks(tokens, channels);
     a.V = channels / 8;
     if (a.V > 1024) return FZ_ERR_UNSUPPORTED;
@@ -189,7 +258,7 @@ extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const voi
     a.partial = partial;
     a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
     dim3 grid(a.chunks, n_frames), block(threads);
-    FZ_LAUNCH(gn_stats_kernel, grid, block, smem, stream, a);
+    gn_launch_stats(a, grid, block, smem, stream);
     const int nst = (n_frames / span) * groups;
     FZ_LAUNCH(gn_finalize_kernel, dim3(nst), dim3(64), 0, stream, a);
     FZ_LAUNCH(gn_apply_kernel, grid, block, 0, stream, a);
@@ -206,7 +275,7 @@ extern "C" int fz_groupnorm_stats(const void* x, int n_frames, int tokens, int c
     if (rc != FZ_OK) return rc;
     a.x = (const half_t*)x; a.y = nullptr; a.gamma = nullptr; a.beta = nullptr; a.eps = 0.0f; a.silu = 0;
     a.partial = partial; a.stats = nullptr;
-    FZ_LAUNCH(gn_stats_kernel, dim3(a.chunks, n_frames), dim3(threads), smem, stream, a);
+    gn_launch_stats(a, dim3(a.chunks, n_frames), dim3(threads), smem, stream);
     return fz_last_launch_status();
 }
 

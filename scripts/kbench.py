@@ -81,7 +81,20 @@ def temporal_bench():
     print(json.dumps(res))
 
 
+def norms_bench():
+    dev, res, F_ = "cuda", {}, 8
+    for (n, tokens, c) in [(8, 4096, 320), (16, 4096, 320), (8, 4096, 640), (8, 4096, 960), (8, 1024, 640), (8, 1024, 1920),
+                           (8, 256, 1280)]:
+        x = torch.randn(n, tokens, c).half().to(dev)
+        gm, bt = torch.ones(c).half().to(dev), torch.zeros(c).half().to(dev)
+        ms = timeit(lambda: K.groupnorm(x, gm, bt, span=F_, groups=32, eps=1e-5, silu=True))
+        res[f"groupnorm_n{n}_T{tokens}_C{c}"] = {"ms": ms, "GBps": x.numel() * 2 * 3 / ms / 1e6}
+    print(json.dumps(res))
+
+
 def main():
+    if "--norms" in sys.argv:
+        return norms_bench()
     if "--temporal" in sys.argv:
         return temporal_bench()
     if "--conv" in sys.argv:
