@@ -75,41 +75,63 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
 
     half8_t wreg[C::WLD], xreg[C::XLD];
     bool xz[C::XLD];
-    auto fetch = [&](int ks) {
-        const int tap = ks / kchunks, c0 = (ks % kchunks) * BK;
+    // Addresses are strength-reduced (the im2col gather used to cost ~14 VALU per MFMA, profiles/r01_pmc_conv64.json):
+    //   weights  [cout][tap][cin]: the K index of slab ks is ks*BK, so a wave-uniform pointer advances by one slab per
+    //            step and each lane keeps one constant 32-bit byte offset per chunk;
+    //   activations: the (tap-dependent) source pixel of a lane's chunk -- bounds test, clamp, upsample shift, frame shift
+    //            of the temporal form -- is recomputed only when the tap changes (every Cin/BK steps); inside a tap the
+    //            same wave-uniform pointer trick walks along the channels.
+    uint32_t woff[C::WLD], xoff[C::XLD];
+#pragma unroll
+    for (int i = 0; i < C::WLD; ++i) {
+        int id = tid + C::T * i;
+        id = id < C::WCH ? id : C::WCH - 1;
+        int co = co0 + id / (BK / 8);
+        co = co < a.Cout ? co : a.Cout - 1;
+        woff[i] = 2u * ((uint32_t)co * (uint32_t)(ntaps * a.Cin) + (uint32_t)(id % (BK / 8)) * 8u);
+    }
+    const char* wcur = reinterpret_cast<const char*>(a.wt);
+    const char* xcur = reinterpret_cast<const char*>(a.x);
+    int ftap = 0, fkc = 0;  // tap / channel slab of the next fetch
+    auto retarget = [&](int tap) {  // per-lane source pixels of tap `tap`
         const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int i = 0; i < C::WLD; ++i) {
-            int id = tid + C::T * i;
-            id = id < C::WCH ? id : C::WCH - 1;
-            int co = co0 + id / (BK / 8);
-            co = co < a.Cout ? co : a.Cout - 1;
-            wreg[i] = fz_ld_h8(a.wt + ((int64_t)co * ntaps + tap) * a.Cin + c0 + (id % (BK / 8)) * 8);
-        }
-        if (a.temporal) {
-#pragma unroll
-            for (int i = 0; i < C::XLD; ++i) {
+        for (int i = 0; i < C::XLD; ++i) {
+            if (a.temporal) {
                 const int f = xn[i] % a.frames_per_batch;
                 int fs = f + tap - 1;
                 xz[i] = !(fs >= 0 && fs < a.frames_per_batch && xok[i]);
                 fs = fs < 0 ? 0 : (fs >= a.frames_per_batch ? a.frames_per_batch - 1 : fs);
                 const int ns = xn[i] - f + fs;
-                xreg[i] = fz_ld_h8(a.x + (((int64_t)ns * a.Hi + xoy[i]) * a.Wi + xox[i]) * a.Cin + c0 + xch[i] * 8);
+                xoff[i] = 2u * ((((uint32_t)ns * a.Hi + xoy[i]) * a.Wi + xox[i]) * (uint32_t)a.Cin + xch[i] * 8u);
+            } else {
+                int iy = xoy[i] * a.stride + ky - 1, ix = xox[i] * a.stride + kx - 1;
+                const bool inb = iy >= 0 && iy < Hu && ix >= 0 && ix < Wu;
+                xz[i] = !(inb && xok[i]);
+                iy = iy < 0 ? 0 : (iy >= Hu ? Hu - 1 : iy);
+                ix = ix < 0 ? 0 : (ix >= Wu ? Wu - 1 : ix);
+                if (a.upsample) {
+                    iy >>= 1;
+                    ix >>= 1;
+                }
+                xoff[i] = 2u * ((((uint32_t)xn[i] * a.Hi + iy) * a.Wi + ix) * (uint32_t)a.Cin + xch[i] * 8u);
             }
-            return;
+        }
+    };
+    auto fetch = [&]() {
+        if (fkc == 0) {  // wave-uniform: a new tap starts (no loads inside the branch)
+            retarget(ftap);
+            xcur = reinterpret_cast<const char*>(a.x);
         }
 #pragma unroll
-        for (int i = 0; i < C::XLD; ++i) {
-            int iy = xoy[i] * a.stride + ky - 1, ix = xox[i] * a.stride + kx - 1;
-            const bool inb = iy >= 0 && iy < Hu && ix >= 0 && ix < Wu;
-            xz[i] = !(inb && xok[i]);
-            iy = iy < 0 ? 0 : (iy >= Hu ? Hu - 1 : iy);
-            ix = ix < 0 ? 0 : (ix >= Wu ? Wu - 1 : ix);
-            if (a.upsample) {
-                iy >>= 1;
-                ix >>= 1;
-            }
-            xreg[i] = fz_ld_h8(a.x + (((int64_t)xn[i] * a.Hi + iy) * a.Wi + ix) * a.Cin + c0 + xch[i] * 8);
+        for (int i = 0; i < C::WLD; ++i) wreg[i] = fz_ld_h8_off(wcur, woff[i]);
+#pragma unroll
+        for (int i = 0; i < C::XLD; ++i) xreg[i] = fz_ld_h8_off(xcur, xoff[i]);
+        wcur += BK * 2;
+        xcur += BK * 2;
+        if (++fkc == kchunks) {
+            fkc = 0;
+            ++ftap;
         }
     };
     auto stash = [&](int st) {
@@ -137,12 +159,12 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = fz_zero_f16v();
 
-    fetch(0);
+    fetch();
     stash(0);
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < nk) fetch(ks + 1);
+        if (ks + 1 < nk) fetch();
         const half_t* Ws = smem + cur * C::STAGE + (wm * 64 + l31) * C::KSTR + 8 * hi;
         const half_t* Xs = smem + cur * C::STAGE + C::BCO * C::KSTR + (wn * 64 + l31) * C::KSTR + 8 * hi;
 #pragma unroll
@@ -235,6 +257,9 @@ static int conv_cfg_override() {  // tuning knob FZ_CONV_CFG=<wm><wn><bk/32> e.g
 }
 
 static int dispatch_conv(const ConvArgs& a, void* stream) {
+    // the kernel addresses x and wt with 32-bit byte offsets from a 64-bit base
+    if ((int64_t)a.N * a.Hi * a.Wi * a.Cin >= (1ll << 31) || (int64_t)a.Cout * (a.temporal ? 3 : 9) * a.Cin >= (1ll << 31))
+        return FZ_ERR_UNSUPPORTED;
     const bool k64 = (a.Cin % 64) == 0;
     const int64_t npix = (int64_t)a.N * a.Ho * a.Wo;
     int cfg = conv_cfg_override();

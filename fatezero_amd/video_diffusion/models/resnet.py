@@ -65,9 +65,11 @@ class PseudoConv3d(nn.Module):
         self._packed = None
 
     # The hand-written implicit-GEMM kernel (fz_conv3x3) is used where it beats MIOpen's NHWC igemm on MI355X
-    # (scripts/kbench.py --conv): the 64x64-latent level (>= 4096 tokens per frame) and every upsample conv (the nearest
-    # 2x is folded into its addressing).  Elsewhere the conv runs through MIOpen on a channels-last view.
-    NATIVE_MIN_TOKENS = 4096
+    # (scripts/kbench.py --conv, profiles/r01_kbench_conv_final.json): launches with >= 4096 output pixels over all frames
+    # (607 vs 326 TF/s at 64x64, 521-584 vs 414-418 at 32x32, 561 vs 421 at 16x16 x 16 frames) and every upsample conv (the
+    # nearest 2x is folded into its addressing, 747 vs 409).  Smaller launches (16x16 x 8 frames, 8x8) cannot fill the chip
+    # with 128x128 tiles and run through MIOpen on a channels-last view.
+    NATIVE_MIN_PIXELS = 4096
 
     def _pack(self, dtype, device):
         if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
@@ -99,7 +101,8 @@ class PseudoConv3d(nn.Module):
             oh, ow = x.h, x.w
             fused = False
         else:
-            native = wt is not None and (upsample or hw >= self.NATIVE_MIN_TOKENS) and x.data.is_contiguous()
+            out_px = n * (((x.h - 1) // self.stride + 1) * ((x.w - 1) // self.stride + 1))
+            native = wt is not None and (upsample or out_px >= self.NATIVE_MIN_PIXELS) and x.data.is_contiguous()
             if native:
                 fuse_tail = not temporal_active  # the elementwise tail commutes with nothing but the last linear op
                 y, (oh, ow) = K.conv3x3(x.data, wt, bias, hw=(x.h, x.w), stride=self.stride, upsample=upsample,

@@ -92,7 +92,21 @@ def norms_bench():
     print(json.dumps(res))
 
 
+def conv64_bench():
+    """Only the hand-written conv at the 64x64 level (320 -> 320, 8 and 16 frames) and the temporal pair: the PMC target."""
+    dev, res = "cuda", {}
+    for n in (8, 16):
+        x = torch.randn(n, 4096, 320).half().to(dev)
+        w = (torch.randn(320, 320, 3, 3) * 0.02).half().to(dev)
+        wt, b = K.pack_conv3x3_weight(w), torch.zeros(320).half().to(dev)
+        ms = timeit(lambda: K.conv3x3(x, wt, b, hw=(64, 64)))
+        res[f"conv_n{n}_hw64_320to320"] = {"ms": ms, "TF": 2.0 * n * 4096 * 320 * 320 * 9 / ms / 1e9}
+    print(json.dumps(res))
+
+
 def main():
+    if "--conv64" in sys.argv:
+        return conv64_bench()
     if "--norms" in sys.argv:
         return norms_bench()
     if "--temporal" in sys.argv:
