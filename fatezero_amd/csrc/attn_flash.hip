@@ -447,8 +447,8 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
                            : launch_flash<40, 4, 1, true, 32>(d, q, k, vt, o, stream);
             if (two) {
                 if (w == 1) return launch_flash<40, 1, 2>(d, q, k, vt, o, stream);
-#ifndef FZ_EMU
-                {   // ablation builds for profiling only (results are wrong by construction)
+#ifdef FZ_TUNING  // only in builds made by the tuning scripts (hipcc -DFZ_TUNING), never in libfatezero_hip.so
+                {   // ablation variants for profiling only (results are wrong by construction, except 64)
                     static int abl = -1;
                     if (abl < 0) { const char* e = getenv("FZ_FLASH_ABLATE"); abl = e ? atoi(e) : 0; }
                     switch (abl) {

@@ -6,6 +6,7 @@ GPU box); its outputs are committed as small fixtures and pin `oracle/fatezero_o
 (tests/test_oracle_golden.py) and, through it or directly, the HIP path (tests -m gpu).
 
     python oracle/gen_golden.py            # all scenarios
+    python oracle/gen_golden.py pipeline:pipe_f4_prev_first,pipe_f3_mid_next   # (re)record only these pipeline runs
     python oracle/gen_golden.py const unet # a subset
 
 How the reference is made importable: `oracle/refshim` restates the
@@ -337,9 +338,13 @@ class _FakeVAE(torch.nn.Module):
         return O()
 
 
-def gen_pipeline(tok):
+def gen_pipeline(tok, only=None):
+    """only: set of scenario names to (re)record; the others keep their committed vectors and pipeline_meta.json entries."""
     meta = {}
-    F_, T = 2, 4
+    meta_path = os.path.join(GOLD, "pipeline_meta.json")
+    if only and os.path.exists(meta_path):
+        meta = json.load(open(meta_path))
+    T = 4
     scen = [
         # small-latent scenarios (every level <= 32x32 tokens is captured; no blend words): fast enough for the CPU suite
         ("pipe_small_replace", 0, {"lora": 16}, dict(self_replace_steps=0.5, L=32, no_blend=True)),
@@ -351,11 +356,19 @@ def gen_pipeline(tok):
          dict(self_replace_steps=0.75, blend_self_attention=True, blend_latents=True)),
         ("pipe_refine_noblend", 3, {"lora": 16, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 64},
          dict(self_replace_steps=0.5)),
+        # more than two frames, so that the 'previous frame', 'first', 'mid' and 'next frame' key/value sources are all
+        # different frames (with F = 2 the default [-1, 'first'] degenerates to frame 0 twice)
+        ("pipe_f4_prev_first", 0, {"lora": 16}, dict(self_replace_steps=0.5, L=16, no_blend=True, F=4)),
+        ("pipe_f3_mid_next", 2, {"lora": 16, "SparseCausalAttention_index": ["mid", 1]},
+         dict(self_replace_steps=0.8, L=16, no_blend=True, F=3)),
     ]
     for name, ci, mc, ov in scen:
+        if only and name not in only:
+            continue
         _, src, tgt, is_rep, crs, bw, eq, _ = PROMPT_CASES[ci]
         ov = dict(ov)
         L = ov.pop("L", 64)
+        F_ = ov.pop("F", 2)
         if ov.pop("no_blend", False):
             bw = None
         unet, _ = build_ref_unet("tiny16", mc)
@@ -436,13 +449,19 @@ def gen_pipeline(tok):
                       "timesteps": [int(t) for t in pipe.scheduler.timesteps]}
         mm = float(torch.stack(out["mask_list"]).float().mean()) if out["mask_list"] is not None else None
         print(f"  {name}: inv {t_inv:.1f}s edit {t_edit:.1f}s  attn-mask ones={ab_frac} latent-mask ones={mm}  |edited|={float(edited.abs().mean()):.4f}")
-    with open(os.path.join(GOLD, "pipeline_meta.json"), "w") as f:
+    with open(meta_path, "w") as f:
         json.dump(meta, f)
 
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    which = set(sys.argv[1:]) or {"const", "unet", "controller", "pipeline"}
+    args = sys.argv[1:]
+    only = set()
+    for a in list(args):  # "pipeline:name1,name2" records just those pipeline scenarios
+        if a.startswith("pipeline:"):
+            only |= set(a.split(":", 1)[1].split(","))
+            args[args.index(a)] = "pipeline"
+    which = set(args) or {"const", "unet", "controller", "pipeline"}
     rec = RecordingTokenizer(load_bpe_tokenizer())
     torch.set_grad_enabled(False)
     if "const" in which:
@@ -452,7 +471,7 @@ def main():
     if "controller" in which:
         print("[controller]"); gen_controller(rec)
     if "pipeline" in which:
-        print("[pipeline]"); gen_pipeline(rec)
+        print("[pipeline]"); gen_pipeline(rec, only or None)
     # tokenizer replay table (merge with an existing one so partial runs do not drop entries)
     path = os.path.join(GOLD, "tokenizer_replay.json")
     table = {"encode": {}, "decode": {}}

@@ -135,7 +135,8 @@ def test_controllers_on_synthetic_maps(tok, case, variant):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("name", ["pipe_small_replace", "pipe_small_refine_reweight", "pipe_replace_blend",
-                                  "pipe_refine_reweight_latentblend", "pipe_refine_noblend"])
+                                  "pipe_refine_reweight_latentblend", "pipe_refine_noblend", "pipe_f4_prev_first",
+                                  "pipe_f3_mid_next"])
 def test_pipeline_matches_reference(tok, name):
     meta = load_json("pipeline_meta.json")[name]
     consts = load_json("host_constants.json")[meta["prompt_case"]]
