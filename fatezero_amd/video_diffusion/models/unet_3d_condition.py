@@ -187,26 +187,31 @@ class UNetPseudo3DConditionModel(nn.Module):
         return UNetPseudo3DConditionOutput(sample=y) if return_dict else (y,)
 
     # ------------------------------------------------------------------------------------------------------
+    _BLOCKS_2D_TO_3D = {"CrossAttnDownBlock2D": "CrossAttnDownBlockPseudo3D", "DownBlock2D": "DownBlockPseudo3D",
+                        "UpBlock2D": "UpBlockPseudo3D", "CrossAttnUpBlock2D": "CrossAttnUpBlockPseudo3D"}
+
     @classmethod
     def from_2d_model(cls, model_path, model_config):
-        """unet_3d_condition.py:449-483: read a diffusers 2-D UNet folder (config.json + first *.bin)."""
-        config_path = os.path.join(model_path, "config.json")
-        if not os.path.isfile(config_path):
-            raise RuntimeError(f"{config_path} does not exist")
-        with open(config_path, "r") as f:
-            config = json.load(f)
-        config.pop("_class_name")
-        config.pop("_diffusers_version")
-        rep = {"CrossAttnDownBlock2D": "CrossAttnDownBlockPseudo3D", "DownBlock2D": "DownBlockPseudo3D",
-               "UpBlock2D": "UpBlockPseudo3D", "CrossAttnUpBlock2D": "CrossAttnUpBlockPseudo3D"}
-        config["down_block_types"] = [rep.get(b, b) for b in config["down_block_types"]]
-        config["up_block_types"] = [rep.get(b, b) for b in config["up_block_types"]]
-        if model_config is not None:
-            config.update(model_config)
+        """Build the pseudo-3D UNet from a diffusers 2-D UNet folder (reference: unet_3d_condition.py:449-483): the 2-D
+        `config.json` with the block types renamed and `model_config` merged in, then the 2-D weights if the folder holds any.
+        Extension: a `*.safetensors` file is accepted as well as the reference's `*.bin`."""
+        cfg_file = os.path.join(model_path, "config.json")
+        if not os.path.isfile(cfg_file):
+            raise RuntimeError(f"{cfg_file} does not exist")
+        with open(cfg_file, "r") as f:
+            config = {k: v for k, v in json.load(f).items() if k not in ("_class_name", "_diffusers_version")}
+        for key in ("down_block_types", "up_block_types"):
+            config[key] = [cls._BLOCKS_2D_TO_3D.get(name, name) for name in config[key]]
+        config.update(model_config or {})
         model = cls(**config)
-        cands = glob.glob(os.path.join(model_path, "*.bin"))
-        if cands:
-            model.load_2d_state_dict(state_dict=torch.load(cands[0], map_location="cpu"))
+        weights = sorted(glob.glob(os.path.join(model_path, "*.bin"))) or sorted(glob.glob(os.path.join(model_path, "*.safetensors")))
+        if weights:
+            if weights[0].endswith(".safetensors"):
+                from safetensors.torch import load_file
+                state = load_file(weights[0], device="cpu")
+            else:
+                state = torch.load(weights[0], map_location="cpu")
+            model.load_2d_state_dict(state_dict=state)
         return model
 
     def load_2d_state_dict(self, state_dict, **kwargs):
