@@ -263,7 +263,7 @@ class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
                     if new is not cur:  # latent blend (attention_util.py:47-78) changed the latents
                         state.assign(new)
                 if callback is not None and i % callback_steps == 0:
-                    callback(i, t, state.as_latents(latents_dtype))
+                    callback(i, t, state.as_latents(latents_dtype).clone())  # the master buffer is updated in place
         latents = state.as_latents(latents_dtype).clone()
         if shard is not None:
             latents = self._gather_frames([latents])[0]
