@@ -25,12 +25,20 @@ struct ConvArgs {
     int temporal;  // != 0: 3 taps along the FRAME axis (k=3, zero padded inside each clip of frames_per_batch frames)
 };
 
-template <int WM, int WN, int BK>
+// SWZ: LDS staging layout.  false: rows padded to BK + 8 halves (fragment reads conflict-free, but the staging writes
+// -- four 16-byte chunks of a row per four lanes -- collide 2-way: profiles/r01_pmc_conv64.json).  true: unpadded rows with
+// the 16-byte chunk index XOR-ed by (row / rows-per-256-bytes) % chunks-per-row, conflict-free for both the staging writes
+// and the 16-row fragment reads.  Selected with FZ_CONV_SWZ=1 until it has been timed on hardware.
+template <int WM, int WN, int BK, bool SWZ = false>
 struct ConvCfg {
     static constexpr int T = 64 * WM * WN;
     static constexpr int BCO = 64 * WM;  // couts per workgroup
     static constexpr int BPX = 64 * WN;  // pixels per workgroup
-    static constexpr int KSTR = BK + 8;  // halves; (BK+8)/8 odd for BK = 32, 64
+    static constexpr int KSTR = SWZ ? BK : BK + 8;  // halves; (BK+8)/8 odd for BK = 32, 64
+    static constexpr int NCH = BK / 8;              // 16-byte chunks per row
+    static constexpr int RPB = 128 / BK;            // rows per 256 bytes of LDS (one pass over all 64 banks)
+    // halves offset of chunk `ch` of row `row` inside a staged operand tile
+    static FZ_DEVICE int at(int row, int ch) { return row * KSTR + (SWZ ? (ch ^ ((row / RPB) % NCH)) : ch) * 8; }
     static constexpr int WCH = BCO * BK / 8;  // 16-byte chunks per weight tile
     static constexpr int XCH = BPX * BK / 8;
     static constexpr int WLD = (WCH + T - 1) / T;
@@ -41,9 +49,9 @@ struct ConvCfg {
     static constexpr int LDS_HALVES = (2 * STAGE > CS) ? 2 * STAGE : CS;
 };
 
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, bool SWZ = false>
 FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
-    typedef ConvCfg<WM, WN, BK> C;
+    typedef ConvCfg<WM, WN, BK, SWZ> C;
     FZ_SHARED __attribute__((aligned(16))) half_t smem[C::LDS_HALVES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -142,14 +150,14 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
             const int id = tid + C::T * i;
             if (id < C::WCH) {
                 const bool okc = co0 + id / (BK / 8) < a.Cout;
-                fz_st_h8(Ws + (id / (BK / 8)) * C::KSTR + (id % (BK / 8)) * 8, okc ? wreg[i] : fz_zero_h8());
+                fz_st_h8(Ws + C::at(id / (BK / 8), id % (BK / 8)), okc ? wreg[i] : fz_zero_h8());
             }
         }
 #pragma unroll
         for (int i = 0; i < C::XLD; ++i) {
             const int id = tid + C::T * i;
             if (id < C::XCH)
-                fz_st_h8(Xs + (id / (BK / 8)) * C::KSTR + (id % (BK / 8)) * 8, xz[i] ? fz_zero_h8() : xreg[i]);
+                fz_st_h8(Xs + C::at(id / (BK / 8), id % (BK / 8)), xz[i] ? fz_zero_h8() : xreg[i]);
         }
     };
 
@@ -165,15 +173,15 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < nk) fetch();
-        const half_t* Ws = smem + cur * C::STAGE + (wm * 64 + l31) * C::KSTR + 8 * hi;
-        const half_t* Xs = smem + cur * C::STAGE + C::BCO * C::KSTR + (wn * 64 + l31) * C::KSTR + 8 * hi;
+        const half_t* Ws = smem + cur * C::STAGE;
+        const half_t* Xs = Ws + C::BCO * C::KSTR;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             half8_t wf[2], xf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                wf[i] = fz_ld_h8(Ws + i * 32 * C::KSTR + 16 * kk);
-                xf[i] = fz_ld_h8(Xs + i * 32 * C::KSTR + 16 * kk);
+                wf[i] = fz_ld_h8(Ws + C::at(wm * 64 + i * 32 + l31, 2 * kk + hi));
+                xf[i] = fz_ld_h8(Xs + C::at(wn * 64 + i * 32 + l31, 2 * kk + hi));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -236,12 +244,12 @@ FZ_KERNEL void __launch_bounds__(64 * WM * WN) conv3x3_kernel(ConvArgs a) {
     }
 }
 
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, bool SWZ = false>
 static int launch_conv(const ConvArgs& a, void* stream) {
-    typedef ConvCfg<WM, WN, BK> C;
+    typedef ConvCfg<WM, WN, BK, SWZ> C;
     const int64_t npix = (int64_t)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((npix + C::BPX - 1) / C::BPX), (a.Cout + C::BCO - 1) / C::BCO), block(C::T);
-    FZ_LAUNCH((conv3x3_kernel<WM, WN, BK>), grid, block, 0, stream, a);
+    FZ_LAUNCH((conv3x3_kernel<WM, WN, BK, SWZ>), grid, block, 0, stream, a);
     return fz_last_launch_status();
 }
 
@@ -256,6 +264,15 @@ static int conv_cfg_override() {  // tuning knob FZ_CONV_CFG=<wm><wn><bk/32> e.g
     return v;
 }
 
+static bool conv_swizzled() {  // tuning knob FZ_CONV_SWZ=1: conflict-free LDS staging layout (see ConvCfg)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FZ_CONV_SWZ");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 static int dispatch_conv(const ConvArgs& a, void* stream) {
     // the kernel addresses x and wt with 32-bit byte offsets from a 64-bit base
     if ((int64_t)a.N * a.Hi * a.Wi * a.Cin >= (1ll << 31) || (int64_t)a.Cout * (a.temporal ? 3 : 9) * a.Cin >= (1ll << 31))
@@ -267,7 +284,19 @@ static int dispatch_conv(const ConvArgs& a, void* stream) {
         cfg = npix >= 16384 ? 221 : 222;  // measured on MI355X (scripts/kbench.py --conv)
     }
     if (!k64 && (cfg % 10) == 2) cfg -= 1;
+    if (conv_swizzled()) {
+        switch (cfg) {
+            case 121: return launch_conv<1, 2, 32, true>(a, stream);
+            case 221: return launch_conv<2, 2, 32, true>(a, stream);
+            case 222: return launch_conv<2, 2, 64, true>(a, stream);
+            default: break;  // other tile shapes: padded layout
+        }
+    }
     switch (cfg) {
+        case 111: return launch_conv<1, 1, 32>(a, stream);  // 64 x 64 tiles, one wave: candidates for the small levels
+        case 112: return launch_conv<1, 1, 64>(a, stream);
+        case 211: return launch_conv<2, 1, 32>(a, stream);
+        case 212: return launch_conv<2, 1, 64>(a, stream);
         case 121: return launch_conv<1, 2, 32>(a, stream);
         case 122: return launch_conv<1, 2, 64>(a, stream);
         case 141: return launch_conv<1, 4, 32>(a, stream);
