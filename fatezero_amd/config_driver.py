@@ -1,0 +1,116 @@
+"""Run a FateZero YAML config (reference: test_fatezero.py:196-262 + P2pSampleLogger.log_sample_images,
+video_diffusion/pipelines/p2p_validation_loop.py:68-128) on the MI355X pipeline, in latent space.
+
+The reference drives one job as: encode `dataset_config.prompt`, DDIM-invert the clip while capturing attention
+(`editing_config.use_invertion_latents` / `use_inversion_attention`), then call the pipeline once per entry of
+`editing_config.editing_prompts` with `p2p_config[idx]` merged into the keyword arguments.  This module reproduces that
+control flow without OmegaConf, accelerate, the dataset or the sample logger: images / VAE are optional,
+clean latents can be handed in directly, and every edit returns latents unless the pipeline has a VAE.
+"""
+import copy
+import re
+from typing import Any, Dict, List, Optional
+
+import torch
+
+_INTERP = re.compile(r"\$\{(\.*)([^}]+)\}")
+
+
+def _lookup(root, path_keys):
+    node = root
+    for key in path_keys:
+        if isinstance(node, list):
+            node = node[int(key)]
+        elif key in node:
+            node = node[key]
+        else:  # YAML maps with integer keys (p2p_config: {0: ..., 1: ...})
+            node = node[int(key)]
+    return node
+
+
+def _resolve(root, node, trail):
+    """OmegaConf's interpolation subset used by the shipped configs: "${a.b}" from the root, "${.a}" relative to the
+    mapping that holds the value, each further dot one level up ("${..dataset_config.n_sample_frame}")."""
+    if isinstance(node, dict):
+        return {k: _resolve(root, v, trail + [k]) for k, v in node.items()}
+    if isinstance(node, list):
+        return [_resolve(root, v, trail + [i]) for i, v in enumerate(node)]
+    if not isinstance(node, str):
+        return node
+
+    def value_of(match):
+        dots, dotted = match.group(1), match.group(2).split(".")
+        if not dots:
+            base = []
+        else:
+            up = len(dots)  # one dot = the mapping that holds this key
+            if up > len(trail):
+                raise KeyError(f"interpolation {match.group(0)!r} climbs above the root at {'.'.join(map(str, trail))}")
+            base = trail[:len(trail) - up]
+        return _resolve(root, _lookup(root, base + dotted), base + dotted)
+
+    whole = _INTERP.fullmatch(node)
+    if whole:  # the value IS the interpolation: keep the referenced type (int, list, ...)
+        return value_of(whole)
+    return _INTERP.sub(lambda m: str(value_of(m)), node)
+
+
+def load_config(path: str) -> Dict[str, Any]:
+    import yaml
+    with open(path, "r") as f:
+        raw = yaml.safe_load(f)
+    return _resolve(raw, raw, [])
+
+
+def plan_edits(editing_config: Dict[str, Any], source_prompt: Optional[str]) -> List[Dict[str, Any]]:
+    """One dict of pipeline keyword arguments per (editing prompt, seed), in the order the reference runs them."""
+    prompts = list(editing_config["editing_prompts"])
+    p2p = editing_config.get("p2p_config")
+    use_inv_attn = bool(editing_config.get("use_inversion_attention", False))
+    p2p_edit = bool(editing_config.get("prompt2prompt_edit", False))
+    calls = []
+    for idx, prompt in enumerate(prompts):
+        extra: Dict[str, Any] = {}
+        edit_type = None
+        if p2p_edit:
+            extra = copy.deepcopy(p2p[idx] if not isinstance(p2p, dict) or idx in p2p else p2p[str(idx)])
+            first_records = (idx == 0 and not use_inv_attn)  # without inversion attention the first prompt refreshes the store
+            edit_type = "save" if first_records else "swap"
+            extra["save_self_attention"] = first_records
+            extra["use_inversion_attention"] = use_inv_attn
+        for seed in (editing_config.get("sample_seeds") or [0]):
+            kw = dict(prompt=prompt, source_prompt=prompts[0] if source_prompt is None else source_prompt,
+                      edit_type=edit_type, strength=editing_config.get("strength"),
+                      num_inference_steps=editing_config.get("num_inference_steps", 20),
+                      clip_length=editing_config.get("clip_length"), guidance_scale=editing_config.get("guidance_scale", 7.5),
+                      num_images_per_prompt=1)
+            kw.update(extra)
+            calls.append({"prompt_index": idx, "seed": int(seed), "kwargs": kw})
+    return calls
+
+
+@torch.no_grad()
+def run_config(pipe, config: Dict[str, Any], *, latents: Optional[torch.Tensor] = None, images: Optional[torch.Tensor] = None,
+               device=None, output_type: str = "latent") -> Dict[str, Any]:
+    """Inversion + every edit of `config`.  latents: clean latents [1, 4, F, h, w] (or pass `images` [(F), 3, H, W] and a
+    pipeline with a VAE).  Returns {"inverted": [...], "edits": [{"prompt_index", "seed", "output"}]}."""
+    device = device if device is not None else pipe._execution_device
+    editing = config["editing_config"]
+    source_prompt = config.get("dataset_config", {}).get("prompt")
+    steps = editing.get("num_inference_steps", 20)
+    pipe.scheduler.set_timesteps(steps)
+    init = None
+    inverted = None
+    if editing.get("use_invertion_latents", False):  # (sic) the reference's spelling
+        emb = pipe._encode_prompt(source_prompt, device, 1, True, None)
+        inverted = pipe.prepare_latents_ddim_inverted(images, batch_size=1, num_images_per_prompt=1, text_embeddings=emb,
+                                                      prompt=source_prompt, LOW_RESOURCE=True, latents=latents,
+                                                      store_attention=bool(editing.get("use_inversion_attention", False)))
+        init = inverted[-1]
+    results = []
+    for call in plan_edits(editing, source_prompt):
+        kw = dict(call["kwargs"])
+        gen = torch.Generator(device="cpu").manual_seed(call["seed"])
+        out = pipe(image=images, latents=init, generator=gen, output_type=output_type, **kw)
+        results.append({"prompt_index": call["prompt_index"], "seed": call["seed"], "output": out})
+    return {"inverted": inverted, "edits": results}

@@ -1,0 +1,84 @@
+"""YAML job driver (fatezero_amd/config_driver.py): interpolation, the per-prompt call plan of the reference's sample
+logger (p2p_validation_loop.py:88-128), and an end-to-end run on the CPU emulation against direct pipeline calls."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fatezero_amd import config_driver as CD  # noqa: E402
+
+CFG = os.path.join(ROOT, "tests", "fixtures", "two_prompt_job.yaml")
+
+
+def test_interpolation_keeps_types_and_scopes():
+    cfg = CD.load_config(CFG)
+    ed = cfg["editing_config"]
+    assert ed["clip_length"] == 2 and isinstance(ed["clip_length"], int)          # "${..dataset_config.n_sample_frame}"
+    assert ed["logdir_note"] == "frames=2 steps=2"                                   # absolute + sibling, inside a string
+    assert sorted(ed["p2p_config"].keys()) == [0, 1]
+    assert cfg["model_config"]["SparseCausalAttention_index"] == ["mid"]
+
+
+def test_call_plan_matches_the_sample_logger():
+    ed = CD.load_config(CFG)["editing_config"]
+    calls = CD.plan_edits(ed, "a blue car driving down the road")
+    assert [c["prompt_index"] for c in calls] == [0, 1]
+    k0, k1 = calls[0]["kwargs"], calls[1]["kwargs"]
+    assert k0["edit_type"] == k1["edit_type"] == "swap"
+    assert k0["save_self_attention"] is False and k0["use_inversion_attention"] is True
+    assert k0["is_replace_controller"] is False and k1["is_replace_controller"] is True
+    assert k1["cross_replace_steps"] == {"default_": 0.5} and k1["source_prompt"].startswith("a blue car")
+    assert k0["clip_length"] == 2 and k0["guidance_scale"] == 3.0 and k0["num_inference_steps"] == 2
+    # without inversion-time attention the first prompt runs in 'save' mode and records self-attention
+    ed2 = dict(ed, use_inversion_attention=False, sample_seeds=[3, 4])
+    calls2 = CD.plan_edits(ed2, None)
+    assert [(c["prompt_index"], c["seed"]) for c in calls2] == [(0, 3), (0, 4), (1, 3), (1, 4)]
+    assert calls2[0]["kwargs"]["edit_type"] == "save" and calls2[0]["kwargs"]["save_self_attention"] is True
+    assert calls2[2]["kwargs"]["edit_type"] == "swap" and calls2[2]["kwargs"]["source_prompt"] == ed["editing_prompts"][0]
+
+
+def test_run_config_equals_direct_pipeline_calls():
+    from fatezero_amd import _native, build
+    _native.use_test_backend(build.build_emu())
+    try:
+        import pipeline_cases as PC
+        from fatezero_amd.synthetic import WordTokenizer
+        from fatezero_amd.video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline
+        from fatezero_amd.video_diffusion.schedulers import DDIMScheduler
+        cfg = CD.load_config(CFG)
+        unet = PC.build_unet("tiny16", cfg["model_config"], "cpu")
+        pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=WordTokenizer(), unet=unet,
+                                             scheduler=DDIMScheduler())
+        pipe.set_progress_bar_config(disable=True)
+        g = torch.Generator().manual_seed(21)
+        embs = {}
+
+        def encode(prompt, *a, **k):  # deterministic stand-in for the CLIP text encoder
+            if prompt not in embs:
+                ge = torch.Generator().manual_seed(abs(hash(prompt)) % (2 ** 31))
+                embs[prompt] = torch.cat([torch.zeros(1, 77, 64), torch.randn(1, 77, 64, generator=ge)])
+            return embs[prompt]
+        pipe._encode_prompt = encode
+        z0 = torch.randn(1, 4, 2, 8, 8, generator=g)
+        got = CD.run_config(pipe, cfg, latents=z0, device="cpu")
+        assert len(got["inverted"]) == 3 and len(got["edits"]) == 2
+        # the same job written out by hand
+        pipe.store_controller = type(pipe.store_controller)()
+        pipe.scheduler.set_timesteps(2)
+        lat = pipe.prepare_latents_ddim_inverted(None, batch_size=1, num_images_per_prompt=1,
+                                                 text_embeddings=encode(cfg["dataset_config"]["prompt"]), store_attention=True,
+                                                 LOW_RESOURCE=True, latents=z0)
+        assert torch.equal(lat[-1], got["inverted"][-1])
+        for idx, (rep, crs) in enumerate([(False, 0.8), (True, 0.5)]):
+            out = pipe(prompt=cfg["editing_config"]["editing_prompts"][idx], source_prompt=cfg["dataset_config"]["prompt"],
+                       edit_type="swap", num_inference_steps=2, guidance_scale=3.0, latents=lat[-1], output_type="latent",
+                       is_replace_controller=rep, cross_replace_steps={"default_": crs}, self_replace_steps=0.5,
+                       use_inversion_attention=True, save_self_attention=False)
+            want = out["sdimage_output"].images
+            have = got["edits"][idx]["output"]["sdimage_output"].images
+            assert torch.equal(want, have), idx
+    finally:
+        _native.reset_backend()
