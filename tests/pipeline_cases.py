@@ -169,3 +169,177 @@ def check(res):
     for k in ("attn_mask", "latent_mask"):
         if k + "_flips" in res:
             assert res[k + "_flips"] <= MASK_FLIP_TOL * res[k + "_total"], res
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Full SD-1.x width (the BASELINE cfg2 architecture: 320/640/1280/1280, 8 heads of d = 40/80/160, lora 160, 64x64 latents)
+# ------------------------------------------------------------------------------------------------------------
+SD15 = dict(block_out_channels=(320, 640, 1280, 1280), norm_num_groups=32, cross_attention_dim=768, attention_head_dim=8)
+FULL_SRC = "a silver jeep driving down a curvy road in the countryside,"
+FULL_TGT = "a Porsche car driving down a curvy road in the countryside,"
+
+
+def run_fullwidth_case(device, F=2, T=2, pure_edit=False, seed=11):
+    """Native pipeline vs the fp32 CPU oracle (oracle.OracleUNet / ddim_inversion / ddim_edit) at REAL width with the same
+    procedural weights: F frames, T inversion steps with capture + T CFG edit steps with the bench's controller (Replace +
+    blend-masked self-attention, unet_3d_condition.py:307-446 / attention_register.py:23-218 end to end).  This is the only
+    place where the d = 40 log2-folded flash path, the native / library conv routing, the batched time-embedding projection
+    and the level-adapted GroupNorm chunks are compared with the oracle as an assembled UNet."""
+    from oracle import fatezero_oracle as O
+    mc = {"lora": 160}
+    unet = UNetPseudo3DConditionModel(sample_size=64, **SD15, **mc)
+    shapes = [(k, tuple(v.shape)) for k, v in unet.state_dict().items()]
+    sd = procedural_state_dict(shapes)
+    unet.load_state_dict(sd)
+    unet = unet.half().to(device).eval()
+    ounet = O.OracleUNet(sd, O.UNetConfig(**SD15, model_config=mc))
+    tok = ReplayTokenizer()
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=tok, unet=unet, scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    pipe.scheduler.set_timesteps(T)
+    g = torch.Generator().manual_seed(seed)
+    z0 = torch.randn(1, 4, F, 64, 64, generator=g)
+    emb_src = torch.randn(2, 77, 768, generator=g) * 0.5
+    emb_tgt = emb_src + 0.25 * torch.randn(2, 77, 768, generator=g)
+    res = {}
+    # single UNet forward first (inversion mode, no controller side effects on the result)
+    lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1,
+                                             text_embeddings=emb_src.to(device), store_attention=True, LOW_RESOURCE=True,
+                                             latents=z0.to(device))
+    ostore = O.StoreController()
+    olat = O.ddim_inversion(ounet, O.DDIMSchedule(T), z0, emb_src[1:], ostore)
+    res["inv_scale"] = float(olat[-1].abs().max())
+    res["inv_err_steps"] = [float((lat[i].float().cpu() - olat[i]).abs().max()) for i in range(1, T + 1)]
+    res["inv_err"] = res["inv_err_steps"][-1]
+    store = pipe.store_controller
+    worst_cross = worst_self = 0.0
+    for k, lst in ostore.attention_store_all_step[0].items():
+        got = store.attention_store_all_step[0][k]
+        assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in lst], k
+        for a, b in zip(got, lst):
+            e = float((a.float().cpu() - b).abs().max())
+            if k.endswith("cross"):
+                worst_cross = max(worst_cross, e)
+            else:
+                worst_self = max(worst_self, e)
+    res["map_err"], res["self_map_err"] = worst_cross, worst_self
+    kw = dict(prompt=FULL_TGT, source_prompt=FULL_SRC, num_inference_steps=T, cross_replace_steps={"default_": 0.5},
+              self_replace_steps=1.0, use_inversion_attention=True, is_replace_controller=True,
+              blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_self_attention=True, blend_th=[0.3, 0.3],
+              save_self_attention=False, guidance_scale=7.5)
+    pipe._encode_prompt = lambda *a, **k: emb_tgt.to(device)
+    zT = lat[-1]
+    edited = pipe(latents=zT, edit_type="swap", output_type="latent", **kw)["sdimage_output"].images.float().cpu()
+    ctrl = pipe.last_edit_controller
+
+    def oracle_edit(ost, z):
+        c = O.make_edit_controller(tok, [FULL_SRC, FULL_TGT], ost, T, True, {"default_": 0.5}, 1.0,
+                                   blend_words=kw["blend_words"], blend_th=(0.3, 0.3), blend_self_attention=True,
+                                   save_self_attention=False)
+        return O.ddim_edit(ounet, O.DDIMSchedule(T), z, emb_tgt, c, guidance_scale=7.5), c
+    # oracle edit on the natively captured maps, from the native inverted latent: isolates the edit pass; masks bit-exact
+    ost = O.StoreController()
+    ost.attention_store_all_step = [{k: [t.float().cpu() for t in v] for k, v in d.items()}
+                                    for d in store.attention_store_all_step]
+    ost.latents_store = [t.float().cpu() for t in store.latents_store]
+    o_edit, o_ctrl = oracle_edit(ost, zT.float().cpu())
+    res["edit_scale"] = float(o_edit.abs().max())
+    res["edit_err_vs_oracle_on_native_maps"] = float((edited - o_edit).abs().max())
+    res["edit_err_vs_oracle_on_native_maps_q99"] = float(torch.quantile((edited - o_edit).abs().flatten(), 0.99))
+    res["attn_mask_flips_same_maps"], res["attn_mask_total"] = _mask_flips(ctrl.attention_blend.mask_list,
+                                                                            o_ctrl.attention_blend.mask_list)
+    res["mask_ones"] = int(sum(int(m.bool().sum()) for m in ctrl.attention_blend.mask_list))
+    if pure_edit:  # the all-fp32 run: oracle edit on the ORACLE's maps from the oracle's inverted latent
+        native2 = pipe(latents=olat[-1].to(device), edit_type="swap", output_type="latent", **kw)["sdimage_output"].images
+        p_edit, p_ctrl = oracle_edit(ostore, olat[-1])
+        res["edit_err"] = float((native2.float().cpu() - p_edit).abs().max())
+        res["attn_mask_flips"], _ = _mask_flips(pipe.last_edit_controller.attention_blend.mask_list,
+                                                p_ctrl.attention_blend.mask_list)
+    return res
+
+
+def check_fullwidth(res):
+    assert res["inv_err"] <= LATENT_TOL * res["inv_scale"], res
+    assert res["map_err"] <= MAP_TOL and res["self_map_err"] <= MAP_TOL, res
+    assert res["edit_err_vs_oracle_on_native_maps"] <= EDIT_TOL_SAME_MAPS * res["edit_scale"], res
+    assert res["attn_mask_flips_same_maps"] == 0, res
+    assert 0 < res["mask_ones"] < res["attn_mask_total"], res   # a degenerate (all-0 / all-1) mask would test nothing
+    if "edit_err" in res:
+        assert res["edit_err"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
+        assert res["attn_mask_flips"] <= MASK_FLIP_TOL * res["attn_mask_total"], res
+
+
+def run_unet_golden(name, device):
+    """Native UNet forward on a golden recorded from the UNMODIFIED reference UNet (oracle/gen_golden.py: gen_unet)."""
+    meta = load_json("unet_meta.json")
+    m = meta[name]
+    g = load_npz(name + ".npz")
+    shapes = m["state_dict_shapes"] or meta["unet_tiny16_default"]["state_dict_shapes"]
+    unet = UNetPseudo3DConditionModel(sample_size=g["x"].shape[-1], **TINY[m["kind"]], **m["model_config"])
+    unet.load_state_dict(procedural_state_dict([(n, tuple(s)) for n, s in shapes]))
+    unet = unet.half().to(device).eval()
+    y = unet(torch.from_numpy(g["x"]).to(device), int(g["t"]), torch.from_numpy(g["ctx"]).to(device)).sample.float().cpu()
+    ref = torch.from_numpy(g["y"])
+    return {"err": float((y - ref).abs().max()), "scale": float(ref.abs().max())}
+
+
+def run_drift_case(device, T=50, F=2, L=32, marks=(10, 25, 50), seed=5):
+    """T = 50 steps each way at tiny16 width: latent error of the native pipeline vs the fp32 oracle at `marks`, for the
+    inversion (vs oracle.ddim_inversion) and for a Replace edit started from the oracle's inverted latent on the oracle's
+    own maps (vs oracle.ddim_edit) -- shows the fp16 error does not grow past the stated latent tolerance over a full
+    50-step job."""
+    from oracle import fatezero_oracle as O
+    mc = {"lora": 16}
+    unet = build_unet("tiny16", mc, device)
+    shapes = [(k, tuple(v.shape)) for k, v in unet.state_dict().items()]
+    ounet = O.OracleUNet(procedural_state_dict(shapes), O.UNetConfig(**TINY["tiny16"], model_config=mc))
+    tok = ReplayTokenizer()
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=tok, unet=unet, scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    pipe.scheduler.set_timesteps(T)
+    g = torch.Generator().manual_seed(seed)
+    z0 = torch.randn(1, 4, F, L, L, generator=g)
+    emb_src = torch.randn(2, 77, 64, generator=g) * 0.5
+    emb_tgt = emb_src + 0.25 * torch.randn(2, 77, 64, generator=g)
+    lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1,
+                                             text_embeddings=emb_src.to(device), store_attention=True, LOW_RESOURCE=True,
+                                             latents=z0.to(device))
+    ostore = O.StoreController()
+    olat = O.ddim_inversion(ounet, O.DDIMSchedule(T), z0, emb_src[1:], ostore)
+    res = {"inv": {m: float((lat[m].float().cpu() - olat[m]).abs().max()) / float(olat[m].abs().max()) for m in marks}}
+    octrl = O.make_edit_controller(tok, [FULL_SRC, FULL_TGT], ostore, T, True, {"default_": 0.5}, 0.5,
+                                   save_self_attention=False)
+    trace = {}
+
+    class _Trace:
+        def __init__(self, inner):
+            self.inner, self.i = inner, 0
+
+        def __call__(self, *a):
+            return self.inner(*a)
+
+        def step_callback(self, x):
+            x = self.inner.step_callback(x)
+            self.i += 1
+            if self.i in marks:
+                trace[self.i] = x.clone()
+            return x
+    O.ddim_edit(ounet, O.DDIMSchedule(T), olat[-1], emb_tgt, _Trace(octrl), guidance_scale=7.5)
+    got = {}
+    pipe._encode_prompt = lambda *a, **k: emb_tgt.to(device)
+
+    def cb(i, t, x):
+        if i + 1 in marks:
+            got[i + 1] = x.float().cpu()
+    # the native edit reads the NATIVE inversion maps (same weights, same input): upstream fp16 noise included
+    pipe(latents=olat[-1].to(device), edit_type="swap", output_type="latent", prompt=FULL_TGT, source_prompt=FULL_SRC,
+         num_inference_steps=T, cross_replace_steps={"default_": 0.5}, self_replace_steps=0.5, use_inversion_attention=True,
+         is_replace_controller=True, save_self_attention=False, guidance_scale=7.5, callback=cb, callback_steps=1)
+    res["edit"] = {m: float((got[m] - trace[m]).abs().max()) / float(trace[m].abs().max()) for m in marks}
+    return res
+
+
+def check_drift(res):
+    for part in ("inv", "edit"):
+        for m, e in res[part].items():
+            assert e <= LATENT_TOL, (part, m, res)

@@ -1,0 +1,194 @@
+"""Boundary-contract scenarios shared by the CPU-emulation suite and the MI355X suite (test infrastructure):
+
+  * a FOREIGN controller -- an object with only the reference's tensor protocol `__call__(attn, is_cross, place)`,
+    `step_callback`, `between_steps` (attention_register.py:47-55, attention_store.py:38-49) -- registered on the native
+    pipeline.  The foreign controllers used here are the CPU oracle's own `StoreController` / `EditController`
+    (oracle/fatezero_oracle.py), i.e. literally the reference's controller algebra running through the
+    capture -> call -> inject path of fatezero_amd/video_diffusion/models/attention.py;
+  * `edit_type=None` (plain CFG sampling, no controller) and `edit_type='save'` (AttentionStore registered during the CFG
+    loop, conditional half captured) of P2pDDIMSpatioTemporalPipeline.__call__ (p2p_ddim_spatial_temporal.py:228-259).
+"""
+import torch
+
+from helpers import ReplayTokenizer
+from oracle import fatezero_oracle as O
+from oracle.weights import procedural_state_dict
+
+from fatezero_amd.video_diffusion.models import UNetPseudo3DConditionModel
+from fatezero_amd.video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline
+from fatezero_amd.video_diffusion.prompt_attention import attention_util
+from fatezero_amd.video_diffusion.schedulers import DDIMScheduler
+
+TINY16 = dict(block_out_channels=(32, 64, 128, 128), norm_num_groups=8, cross_attention_dim=64, attention_head_dim=2)
+SRC = "a silver jeep driving down a curvy road in the countryside,"
+TGT = "a Porsche car driving down a curvy road in the countryside,"
+
+
+def build(device, model_config, L=16, F=2, seed=3):
+    unet = UNetPseudo3DConditionModel(sample_size=L, **TINY16, **model_config)
+    shapes = [(k, tuple(v.shape)) for k, v in unet.state_dict().items()]
+    sd = procedural_state_dict(shapes)
+    unet.load_state_dict(sd)
+    unet = unet.half().to(device).eval()
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=ReplayTokenizer(), unet=unet,
+                                         scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    ounet = O.OracleUNet(sd, O.UNetConfig(**TINY16, model_config=model_config))
+    g = torch.Generator().manual_seed(seed)
+    z0 = torch.randn(1, 4, F, L, L, generator=g)
+    emb_src = torch.randn(2, 77, 64, generator=g)
+    emb_tgt = emb_src + 0.5 * torch.randn(2, 77, 64, generator=g)
+    return pipe, ounet, z0, emb_src, emb_tgt
+
+
+class _Recorder:
+    """Foreign controller wrapper: forwards to an oracle controller, counts calls, moves tensors to the oracle's fp32 CPU
+    world and back (a foreign controller may return a NEW tensor: attention.py's generic path copies it in)."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.calls = []
+        self.num_att_layers = -1
+
+    def __call__(self, attn, is_cross, place):
+        self.calls.append((tuple(attn.shape), bool(is_cross), place))
+        out = self.inner(attn.float().cpu().clone(), is_cross, place)
+        return out.to(device=attn.device, dtype=attn.dtype)
+
+    def step_callback(self, x_t):
+        return self.inner.step_callback(x_t.float().cpu()).to(device=x_t.device, dtype=x_t.dtype)
+
+    def between_steps(self):
+        return self.inner.between_steps()
+
+
+def foreign_store_inversion(device, T=2):
+    """Inversion with the oracle's StoreController installed as a foreign controller vs the native AttentionStore and
+    vs the all-CPU oracle run."""
+    mc = {"lora": 16}
+    pipe, ounet, z0, emb_src, _ = build(device, mc)
+    pipe.scheduler.set_timesteps(T)
+    # (1) native controller
+    lat_native = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1,
+                                                    text_embeddings=emb_src.to(device), store_attention=True,
+                                                    LOW_RESOURCE=True, latents=z0.to(device))
+    native_maps = {k: [t.float().cpu().clone() for t in v] for k, v in pipe.store_controller.attention_store_all_step[0].items()}
+    # (2) foreign controller: same loop, tensor protocol
+    ostore = O.StoreController()
+    ostore.LOW_RESOURCE = True
+    rec = _Recorder(ostore)
+    n = attention_util.register_attention_control(pipe, rec)
+    assert rec.num_att_layers == n == 32
+    lat_foreign = pipe.ddim_clean2noisy_loop(z0.to(device), emb_src.to(device), rec)
+    attention_util.register_attention_control(pipe, pipe.empty_controller)
+    # (3) oracle end to end
+    ref_store = O.StoreController()
+    lat_ref = O.ddim_inversion(ounet, O.DDIMSchedule(T), z0, emb_src[1:], ref_store)
+    res = {"calls_per_step": len(rec.calls) // T}
+    res["lat_foreign_vs_native"] = float((lat_foreign[-1].float().cpu() - lat_native[-1].float().cpu()).abs().max())
+    res["lat_foreign_vs_oracle"] = float((lat_foreign[-1].float().cpu() - lat_ref[-1]).abs().max())
+    res["scale"] = float(lat_ref[-1].abs().max())
+    worst = 0.0
+    for k, lst in ostore.attention_store_all_step[0].items():
+        assert len(lst) == len(native_maps[k]) == len(ref_store.attention_store_all_step[0][k]), k
+        for a, b, c in zip(lst, native_maps[k], ref_store.attention_store_all_step[0][k]):
+            assert a.shape == b.shape == c.shape
+            worst = max(worst, float((a - b).abs().max()), float((a - c).abs().max()))
+    res["map_err"] = worst
+    # every controlled layer <= 32x32 tokens reached the foreign controller with the reference's [B*F, heads, Lq, Lk] shape
+    res["shapes_ok"] = all(len(s) == 4 for s, _, _ in rec.calls)
+    return res
+
+
+def foreign_edit(device, T=2, L=16, blend=False):
+    """Edit pass with the oracle's EditController (Replace, optionally blend-masked self-attention) as a foreign controller
+    on the native pipeline vs the native AttentionReplace controller and vs the all-CPU oracle.  The blend mask needs the
+    512x512 map-list layout (spatial_blend.py:78), i.e. L = 64; layers above 32x32 tokens then bypass a foreign controller
+    exactly like the reference with xformers enabled (attention_register.py:112-116)."""
+    mc = {"lora": 16}
+    pipe, ounet, z0, emb_src, emb_tgt = build(device, mc, L=L)
+    tok = ReplayTokenizer()
+    pipe.scheduler.set_timesteps(T)
+    lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1,
+                                             text_embeddings=emb_src.to(device), store_attention=True, LOW_RESOURCE=True,
+                                             latents=z0.to(device))
+    zT = lat[-1]
+    kw = dict(prompt=TGT, source_prompt=SRC, num_inference_steps=T, cross_replace_steps={"default_": 0.5},
+              self_replace_steps=1.0, use_inversion_attention=True, is_replace_controller=True,
+              blend_words=[["silver", "jeep"], ["Porsche", "car"]] if blend else None, blend_self_attention=blend,
+              blend_th=[0.3, 0.3], save_self_attention=False, guidance_scale=7.5)
+    pipe._encode_prompt = lambda *a, **k: emb_tgt.to(device)
+    native = pipe(latents=zT, edit_type="swap", output_type="latent", **kw)["sdimage_output"].images.float().cpu()
+    # the oracle's store filled from the natively captured maps, its EditController installed as a foreign controller
+    store = pipe.store_controller
+    ost = O.StoreController()
+    ost.attention_store_all_step = [{k: [t.float().cpu() for t in v] for k, v in d.items()}
+                                    for d in store.attention_store_all_step]
+    ost.latents_store = [t.float().cpu() for t in store.latents_store]
+
+    def mk():
+        return O.make_edit_controller(tok, [SRC, TGT], ost, T, True, {"default_": 0.5}, 1.0, blend_words=kw["blend_words"],
+                                      blend_th=(0.3, 0.3), blend_self_attention=blend, save_self_attention=False)
+    rec = _Recorder(mk())
+    attention_util.register_attention_control(pipe, rec)
+    foreign = pipe.sd_ddim_pipeline(prompt=TGT, latents=zT, num_inference_steps=T, guidance_scale=7.5, controller=rec,
+                                    output_type="latent").images.float().cpu()
+    attention_util.register_attention_control(pipe, pipe.empty_controller)
+    oracle = O.ddim_edit(ounet, O.DDIMSchedule(T), zT.float().cpu(), emb_tgt, mk(), guidance_scale=7.5)
+    return {"foreign_vs_native": float((foreign - native).abs().max()),
+            "foreign_vs_oracle": float((foreign - oracle).abs().max()),
+            "native_vs_oracle": float((native - oracle).abs().max()),
+            "scale": float(oracle.abs().max()), "calls_per_step": len(rec.calls) // T}
+
+
+def edit_type_none_and_save(device, T=2):
+    mc = {"lora": 16, "SparseCausalAttention_index": ["mid"]}
+    pipe, ounet, z0, emb_src, emb_tgt = build(device, mc, F=3)
+    pipe._encode_prompt = lambda *a, **k: emb_tgt.to(device)
+    zT = z0.to(device)
+    common = dict(prompt=TGT, source_prompt=SRC, num_inference_steps=T, guidance_scale=7.5, latents=zT, output_type="latent",
+                  cross_replace_steps=0.5, self_replace_steps=0.5, use_inversion_attention=False)
+    plain = pipe(edit_type=None, **common).images.float().cpu()
+    ref_plain = O.ddim_edit(ounet, O.DDIMSchedule(T), z0, emb_tgt, None, guidance_scale=7.5)
+    out = pipe(edit_type="save", **common)
+    saved = out["sdimage_output"].images.float().cpu()
+    ref_store = O.StoreController()
+    ref_saved = O.ddim_edit(ounet, O.DDIMSchedule(T), z0, emb_tgt, ref_store, guidance_scale=7.5)
+    res = {"none_err": float((plain - ref_plain).abs().max()), "save_err": float((saved - ref_saved).abs().max()),
+           "scale": float(ref_plain.abs().max()), "mask_list": out["mask_list"]}
+    st = pipe.store_controller
+    assert len(st.attention_store_all_step) == T and len(ref_store.attention_store_all_step) == T
+    worst = [0.0] * T
+    for step in range(T):
+        for k, lst in ref_store.attention_store_all_step[step].items():
+            got = st.attention_store_all_step[step][k]
+            assert len(got) == len(lst), (k, len(got), len(lst))
+            for a, b in zip(got, lst):
+                assert tuple(a.shape) == tuple(b.shape), (k, a.shape, b.shape)   # conditional half only: [F, heads, Lq, Lk]
+                worst[step] = max(worst[step], float((a.float().cpu() - b).abs().max()))
+    res["save_map_err"], res["save_map_err_last"] = worst[0], worst[-1]
+    return res
+
+
+LATENT_TOL = 2.5e-2  # of max |latent| (fp16 storage vs the fp32 oracle), tests/pipeline_cases.py
+MAP_TOL = 2e-2
+
+
+def check_foreign_store(r):
+    assert r["calls_per_step"] == 32 and r["shapes_ok"], r
+    assert r["lat_foreign_vs_native"] <= LATENT_TOL * r["scale"], r
+    assert r["lat_foreign_vs_oracle"] <= LATENT_TOL * r["scale"], r
+    assert r["map_err"] <= MAP_TOL, r
+
+
+def check_foreign_edit(r):
+    assert r["calls_per_step"] in (32, 22), r   # 22: the ten 64x64-token layers bypass a foreign controller
+    for k in ("foreign_vs_native", "foreign_vs_oracle", "native_vs_oracle"):
+        assert r[k] <= 6e-2 * r["scale"], r   # blend masks in play (tests/pipeline_cases.py: EDIT_TOL_VS_REFERENCE)
+
+
+def check_none_save(r):
+    assert r["none_err"] <= LATENT_TOL * r["scale"] and r["save_err"] <= LATENT_TOL * r["scale"], r
+    # step 0 sees identical latents on both sides; after a guidance-7.5 step from pure noise the (deliberately peaky) cross
+    # maps carry the amplified fp16 noise of the first step, hence the wider band on the last step
+    assert r["save_map_err"] <= MAP_TOL and r["save_map_err_last"] <= 5 * MAP_TOL and r["mask_list"] is None, r

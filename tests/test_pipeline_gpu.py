@@ -22,3 +22,40 @@ def test_pipeline(name):
     print(name, res)
     PC.check(res)
     assert _native.loaded_path().endswith("libfatezero_hip.so")
+
+
+def test_fullwidth_sd15_pipeline_vs_oracle():
+    """BASELINE cfg2 architecture at real width (d = 40 / 80 / 160, lora 160, 64x64 latents), 2 frames, 2 + 2 steps,
+    the bench's controller -- native HIP path vs oracle.OracleUNet / ddim_inversion / ddim_edit (about 3 minutes of CPU
+    oracle time).  FZ_FULL_PARITY=1 adds the all-fp32 edit run (oracle edit on the oracle's own maps)."""
+    import os
+    res = PC.run_fullwidth_case("cuda", pure_edit=os.environ.get("FZ_FULL_PARITY") == "1")
+    print("fullwidth", res)
+    PC.check_fullwidth(res)
+    assert _native.loaded_path().endswith("libfatezero_hip.so")
+
+
+@pytest.mark.parametrize("name", ["unet_tiny40_default", "unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d"])
+def test_unet_vs_reference_golden(name):
+    r = PC.run_unet_golden(name, "cuda")
+    print(name, r)
+    assert r["err"] <= 1.5e-2 * r["scale"], r
+
+
+def test_drift_50_steps():
+    res = PC.run_drift_case("cuda")
+    print("drift (max latent error / max |latent| at steps 10, 25, 50):", res)
+    PC.check_drift(res)
+
+
+def test_foreign_controllers_and_edit_types():
+    import protocol_cases as PR
+    r = PR.foreign_store_inversion("cuda")
+    print(r)
+    PR.check_foreign_store(r)
+    r = PR.foreign_edit("cuda", L=64, blend=True)
+    print(r)
+    PR.check_foreign_edit(r)
+    r = PR.edit_type_none_and_save("cuda")
+    print(r)
+    PR.check_none_save(r)

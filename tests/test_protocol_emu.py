@@ -1,0 +1,68 @@
+"""Boundary contract on the CPU emulation backend: foreign (tensor-protocol) controllers, edit_type None / 'save', and the
+PRODUCT's host-side prompt constants against the values recorded from the unmodified reference."""
+import pytest
+import torch
+
+from fatezero_amd import _native, build
+from fatezero_amd.video_diffusion.prompt_attention import attention_util, ptp_utils, seq_aligner
+from fatezero_amd.video_diffusion.prompt_attention.spatial_blend import SpatialBlender
+
+from helpers import ReplayTokenizer, load_json
+import protocol_cases as PR
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_backend():
+    _native.use_test_backend(build.build_emu())
+    yield
+    _native.reset_backend()
+
+
+def test_product_host_constants_exact():
+    """SURVEY §8 a-14 ("must be bit-exact"), on fatezero_amd.video_diffusion.prompt_attention.* (the oracle's copies are pinned
+    by test_oracle_golden.py::test_host_constants_exact against the same file)."""
+    tok = ReplayTokenizer()
+    gold = load_json("host_constants.json")
+    assert len(gold) >= 6
+    for name, c in gold.items():
+        prompts, T = c["prompts"], c["T"]
+        for key, inds in c["word_inds"].items():
+            p, w = key.rsplit("|", 1)
+            assert ptp_utils.get_word_inds(p, w, tok).tolist() == inds, (name, key)
+        crs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c["cross_replace_steps"].items()}
+        a = ptp_utils.get_time_words_attention_alpha(prompts, T, crs, tok)
+        assert tuple(a.shape) == (T + 1, 1, 1, 1, 77)
+        assert a.reshape(T + 1, 77).to(torch.uint8).tolist() == c["cross_replace_alpha"], name
+        if c["is_replace"]:
+            assert seq_aligner.get_replacement_mapper(prompts, tok)[0].tolist() == c["replacement_mapper"], name
+        else:
+            mp, al = seq_aligner.get_refinement_mapper(prompts, tok)
+            assert mp[0].tolist() == c["refinement_mapper"], name
+            assert al[0].tolist() == c["refinement_alphas"], name
+        if c["eq_params"] is not None:
+            eq = attention_util.get_equalizer(prompts[1], c["eq_params"]["words"], c["eq_params"]["values"], tok)
+            assert eq[0].tolist() == c["equalizer"], name
+        if c["blend_words"] is not None:
+            bl = SpatialBlender(prompts, c["blend_words"], tokenizer=tok, NUM_DDIM_STEPS=T)
+            assert bl.alpha_layers.reshape(2, 77).tolist() == c["alpha_layers"], name
+        # the constants as the controller folds them for the kernels: num_self_replace (attention_util.py:195-197)
+        ctrl = attention_util.make_controller(tok, prompts, c["is_replace"], crs, 0.5, NUM_DDIM_STEPS=T)
+        assert ctrl.num_self_replace == (0, int(T * 0.5)), name
+
+
+def test_foreign_store_controller_inversion():
+    r = PR.foreign_store_inversion("cpu")
+    print(r)
+    PR.check_foreign_store(r)
+
+
+def test_foreign_edit_controller():
+    r = PR.foreign_edit("cpu")
+    print(r)
+    PR.check_foreign_edit(r)
+
+
+def test_edit_type_none_and_save():
+    r = PR.edit_type_none_and_save("cpu")
+    print(r)
+    PR.check_none_save(r)
