@@ -48,8 +48,23 @@ class FzAttnCrossDesc(C.Structure):
     ]
 
 
+class FzGemmDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int64), ("rows_store", C.c_int64), ("in_features", C.c_int32), ("out_features", C.c_int32),
+        ("ldx", C.c_int64), ("ldw", C.c_int64), ("ldy", C.c_int64), ("ldres", C.c_int64),
+        ("batch", C.c_int32), ("epilogue", C.c_int32),
+        ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64), ("res_batch_stride", C.c_int64),
+        ("transpose_out", C.c_int32), ("tile_cfg", C.c_int32), ("split_k", C.c_int32), ("reserved0", C.c_int32),
+        ("workspace_floats", C.c_int64),
+    ]
+
+
+FZ_GEMM_PLAIN, FZ_GEMM_GEGLU = 0, 1
+
 _P = C.c_void_p
 _SIGS = {
+    "fz_gemm": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fz_gemm_workspace_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "fz_attn_self": (C.c_int, [C.POINTER(FzAttnSelfDesc), _P, _P, _P, _P, _P, _P, _P]),
     "fz_attn_cross": (C.c_int, [C.POINTER(FzAttnCrossDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_attn_temporal": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
@@ -65,7 +80,7 @@ _SIGS = {
     "fz_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
                                      C.c_int, C.c_int, _P, _P]),
     "fz_conv3x3": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                             C.c_int, C.c_int, _P]),
+                             C.c_int, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "fz_temporal_conv3": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "fz_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "fz_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),

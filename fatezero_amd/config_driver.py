@@ -16,25 +16,48 @@ import torch
 _INTERP = re.compile(r"\$\{(\.*)([^}]+)\}")
 
 
+class Config(dict):
+    """A loaded YAML config: a plain dict plus `.unresolved`, the dotted paths whose `${...}` interpolation points at a node
+    that does not exist.  OmegaConf resolves lazily, so such a node only fails when it is READ -- and 24 of the reference's
+    27 configs carry one that nothing reads (`test_pipeline_config.num_inference_steps:
+    "${..validation_sample_logger.num_inference_steps}"`, e.g. config/teaser/jeep_posche.yaml:86).  They are kept as the raw
+    string here instead of failing the load."""
+    unresolved: List[str]
+
+
+class _Unresolvable(KeyError):
+    pass
+
+
 def _lookup(root, path_keys):
     node = root
     for key in path_keys:
         if isinstance(node, list):
-            node = node[int(key)]
-        elif key in node:
-            node = node[key]
-        else:  # YAML maps with integer keys (p2p_config: {0: ..., 1: ...})
-            node = node[int(key)]
+            try:
+                node = node[int(key)]
+            except (ValueError, IndexError):
+                raise _Unresolvable(f"no list element {key!r} on the way to {'.'.join(map(str, path_keys))}")
+        elif isinstance(node, dict):
+            if key in node:
+                node = node[key]
+            elif isinstance(key, str) and key.lstrip("-").isdigit() and int(key) in node:
+                node = node[int(key)]  # YAML maps with integer keys (p2p_config: {0: ..., 1: ...})
+            else:
+                raise _Unresolvable(f"no key {key!r} on the way to {'.'.join(map(str, path_keys))}")
+        else:
+            raise _Unresolvable(f"{'.'.join(map(str, path_keys))} descends into a scalar")
     return node
 
 
-def _resolve(root, node, trail):
+def _resolve(root, node, trail, unresolved, depth=0):
     """OmegaConf's interpolation subset used by the shipped configs: "${a.b}" from the root, "${.a}" relative to the
     mapping that holds the value, each further dot one level up ("${..dataset_config.n_sample_frame}")."""
+    if depth > 32:
+        raise ValueError(f"interpolation cycle at {'.'.join(map(str, trail))}")
     if isinstance(node, dict):
-        return {k: _resolve(root, v, trail + [k]) for k, v in node.items()}
+        return {k: _resolve(root, v, trail + [k], unresolved, depth) for k, v in node.items()}
     if isinstance(node, list):
-        return [_resolve(root, v, trail + [i]) for i, v in enumerate(node)]
+        return [_resolve(root, v, trail + [i], unresolved, depth) for i, v in enumerate(node)]
     if not isinstance(node, str):
         return node
 
@@ -45,21 +68,28 @@ def _resolve(root, node, trail):
         else:
             up = len(dots)  # one dot = the mapping that holds this key
             if up > len(trail):
-                raise KeyError(f"interpolation {match.group(0)!r} climbs above the root at {'.'.join(map(str, trail))}")
+                raise _Unresolvable(f"interpolation {match.group(0)!r} climbs above the root")
             base = trail[:len(trail) - up]
-        return _resolve(root, _lookup(root, base + dotted), base + dotted)
+        return _resolve(root, _lookup(root, base + dotted), base + dotted, unresolved, depth + 1)
 
-    whole = _INTERP.fullmatch(node)
-    if whole:  # the value IS the interpolation: keep the referenced type (int, list, ...)
-        return value_of(whole)
-    return _INTERP.sub(lambda m: str(value_of(m)), node)
+    try:
+        whole = _INTERP.fullmatch(node)
+        if whole:  # the value IS the interpolation: keep the referenced type (int, list, ...)
+            return value_of(whole)
+        return _INTERP.sub(lambda m: str(value_of(m)), node)
+    except _Unresolvable:
+        unresolved.append(".".join(map(str, trail)))
+        return node
 
 
-def load_config(path: str) -> Dict[str, Any]:
+def load_config(path: str) -> Config:
     import yaml
     with open(path, "r") as f:
         raw = yaml.safe_load(f)
-    return _resolve(raw, raw, [])
+    unresolved: List[str] = []
+    cfg = Config(_resolve(raw, raw, [], unresolved))
+    cfg.unresolved = unresolved
+    return cfg
 
 
 def plan_edits(editing_config: Dict[str, Any], source_prompt: Optional[str]) -> List[Dict[str, Any]]:

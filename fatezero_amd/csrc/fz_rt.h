@@ -59,6 +59,15 @@ FZ_DEVICE float fz_pair_max32(float v) {
 FZ_DEVICE float fz_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 FZ_DEVICE float fz_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 FZ_DEVICE float fz_rsqrt(float x) { return rsqrtf(x); }
+// LDS-DMA (global_load_lds_dwordx4): every lane fetches 16 bytes from its OWN global address; the wave's 64 chunks land
+// lane-linear at lds_wave_base + 16 * lane (M0 base + lane * 16, cdna_hip_programming.md section 5).  Asynchronous: tracked
+// by vmcnt only -- fz_wait_vm0() + a barrier must separate it from the ds_reads of the data.
+FZ_DEVICE void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+FZ_DEVICE void fz_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define FZ_DEVICE_GLOBAL __device__
 
 #else
 // ============================================================================================
@@ -149,6 +158,11 @@ static inline float fz_pair_max32(float v) { return fmaxf(v, fz_shfl_xor(v, 32))
 static inline float fz_exp2(float x) { return exp2f(x); }
 static inline float fz_rcp(float x) { return 1.0f / x; }
 static inline float fz_rsqrt(float x) { return 1.0f / sqrtf(x); }
+static inline void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {  // synchronous on the emulator
+    memcpy((unsigned char*)lds_wave_base + 16 * fz_emu::lane_id(), gsrc_lane, 16);
+}
+static inline void fz_wait_vm0() {}
+#define FZ_DEVICE_GLOBAL static
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 #endif

@@ -1,0 +1,644 @@
+// igemm.hip -- ONE MFMA implicit-GEMM kernel for every GEMM-shaped op of the pseudo-3D UNet:
+//   * nn.Linear / 1x1 nn.Conv2d (models/attention.py:64-66,91-93 proj_in / proj_out, :199,216 to_q/k/v/out of
+//     CrossAttention, :232 FeedForward GEGLU [3P diffusers], resnet.py:290 time_emb_proj, the 1x1 shortcuts)   -> fz_gemm
+//   * the 3x3 spatial convolution of PseudoConv3d.forward (resnet.py:57-64; stride 2: :203; nearest-2x: :145) -> fz_conv3x3
+//   * the k=3 temporal Conv1d pair of LoRALinearLayer (lora.py:31-54)                                        -> fz_temporal_conv3
+// GEMM view:  D[a][b] = sum_k A[a][k] * B[b][k];  A rows are plain dense rows (weights: a = cout, k = tap * Cin + ci),
+// B rows are gathered (pixel rows of x, shifted per tap, zero outside the image / clip); the output is y[b][a] (a
+// contiguous) -- token-major activations on both sides, so there is never a layout conversion.  fz_gemm's transposed
+// form (V^T = Wv X^T, the attention kernels' V operand) is the same kernel with the operands swapped.
+//
+// Structure (cdna_hip_programming.md section 5, "glds vs register staging"):  WA x WB waves, each owning a
+// (TA*32) x (TB*32) block of 32x32x16 f16 MFMA tiles; K step = 64 halves of one tap.  Both operand tiles go HBM/L2 -> LDS
+// by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write pass), double buffered, ONE barrier per K step:
+//     wait vmcnt(0); barrier;  issue tile t+1 -> buf[~cur];  ds_read_b128 + MFMA on buf[cur]
+// LDS-DMA writes lane-linear, so a tile is [row][8 chunks of 16 B] unpadded; the chunk index is XOR-swizzled with
+// (row >> 1) & 7 on the per-lane SOURCE address and again on the fragment read (conflict-free ds_read_b128, rule 21).
+// Zero padding (image border, clip ends, K tail) = lanes pointing at a device-global page of zeros.
+// Epilogue: + bias (fp32, in registers) [* GEGLU gate] -> fp16 tile through LDS -> (+ temb[b]) (+ res) (+ res2) -> full-row
+// 16-byte stores.  Split-K (small pyramid levels: too few tiles to fill 256 CUs) writes fp32 partial slabs that
+// igemm_reduce_kernel combines with the same tail.
+#include "fz_rt.h"
+#include "../../include/fatezero_hip.h"
+
+FZ_DEVICE_GLOBAL __attribute__((aligned(16))) half_t fz_zero_page[8192];  // 16 KB of zeros (K <= 8128 per tap)
+
+struct IgArgs {
+    const half_t* a;     // [Ma][lda]   (weights / the contiguous output dimension)
+    const half_t* b;     // plain: [Nb][ldb];  conv: x[N][Hi][Wi][Cin]
+    half_t* y;           // [Nb][ldy]
+    float* part;         // split-K partial slabs [ksplit][batch][Nb][Ma] or null
+    const half_t* bias;  // [Ma] or null
+    const half_t* temb;  // rows of Ma values, one per temb_group consecutive B rows, or null
+    const half_t* res;   // [Nb][ldres] or null
+    const half_t* res2;
+    int64_t lda, ldb, ldy, ldres, a_bs, b_bs, y_bs, res_bs, temb_stride;
+    int64_t Nb;          // B rows (tokens / output pixels) per batch element
+    int64_t temb_group;
+    int Ma, Ma_store;    // A rows; rows [Ma, Ma_store) of the output are written as zeros (V^T padding)
+    int Cin, taps, kchunks;
+    int N, Hi, Wi, Ho, Wo, stride, upsample, fpb;
+    int ksplit, tiles_a;
+};
+
+template <int WA, int TA, int WB, int TB, bool GEGLU>
+struct IgCfg {
+    static constexpr int NW = WA * WB, T = 64 * NW;
+    static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
+    static constexpr int ACH = BA * 8 / T, BCH = BB * 8 / T;  // LDS-DMA instructions per wave per K step
+    static_assert(ACH * T == BA * 8 && BCH * T == BB * 8, "tile rows must split evenly over the waves");
+    static constexpr int STAGE = (BA + BB) * 64;  // halves per buffer
+    static constexpr int LDS_HALVES = 2 * STAGE;
+    static constexpr int CW = GEGLU ? BA / 2 : BA;  // output columns of the tile
+    static constexpr int CSTR = CW + 8;
+    static constexpr int wbp() {
+        int w = WB;
+        while (w > 1 && w * TB * 32 * CSTR > LDS_HALVES) w /= 2;
+        return w;
+    }
+    static constexpr int WBP = wbp();  // B-direction waves staged per epilogue pass
+    static constexpr int RP = WBP * TB * 32;
+    static_assert(RP * CSTR <= LDS_HALVES, "epilogue staging does not fit");
+    static_assert(!GEGLU || TA % 2 == 0, "GEGLU pairs MFMA tiles (h, gate)");
+};
+
+FZ_DEVICE float ig_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int WA, int TA, int WB, int TB, int MODE, bool GEGLU>
+FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
+    typedef IgCfg<WA, TA, WB, TB, GEGLU> C;
+    FZ_DYN_SMEM(raw);
+    half_t* smem = reinterpret_cast<half_t*>(raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wa = wave / WB, wb = wave % WB;
+    // ---- tile of this workgroup: XCD-aware (blocks b, b+8, b+16.. share an XCD and get consecutive tiles, which share
+    //      their B rows: the activation panel is fetched once per XCD L2), a-tile fastest
+    const int nt = gridDim.x, bid = blockIdx.x;
+    const int q8 = nt >> 3, r8 = nt & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ta = lid % g.tiles_a, tb = lid / g.tiles_a;
+    const int a0 = ta * C::BA;
+    const int64_t b0 = (int64_t)tb * C::BB;
+    const int ks = blockIdx.y, z = blockIdx.z;
+    const half_t* A = g.a + (int64_t)z * g.a_bs;
+    const half_t* B = g.b + (int64_t)z * g.b_bs;
+    const char* zero = reinterpret_cast<const char*>(fz_zero_page);
+
+    // ---- per-lane sources.  Instruction (i, wave) of a tile covers rows 8*(i*NW+wave) .. +8, lane -> (row = lane/8, chunk
+    //      position lane%8); the lane fetches source chunk pos ^ ((row >> 1) & 7).
+    const int pos = lane & 7;
+    const char* aptr[C::ACH];
+    int asc[C::ACH];
+#pragma unroll
+    for (int i = 0; i < C::ACH; ++i) {
+        const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+        asc[i] = pos ^ ((row >> 1) & 7);
+        int ar = a0 + row;
+        ar = ar < g.Ma ? ar : g.Ma - 1;
+        aptr[i] = reinterpret_cast<const char*>(A + (int64_t)ar * g.lda) + asc[i] * 16;
+    }
+    const char* bptr[C::BCH];
+    int bsc[C::BCH];
+    int bn[C::BCH], boy[C::BCH], box[C::BCH];  // conv: (frame, oy, ox) of the lane's pixel
+    bool bok[C::BCH];
+#pragma unroll
+    for (int i = 0; i < C::BCH; ++i) {
+        const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+        bsc[i] = pos ^ ((row >> 1) & 7);
+        int64_t br = b0 + row;
+        bok[i] = br < g.Nb;
+        br = bok[i] ? br : g.Nb - 1;
+        if (MODE == 0) {
+            bptr[i] = reinterpret_cast<const char*>(B + br * g.ldb) + bsc[i] * 16;
+            bn[i] = boy[i] = box[i] = 0;
+        } else {
+            const int hw = g.Ho * g.Wo;
+            bn[i] = (int)(br / hw);
+            const int rem = (int)(br - (int64_t)bn[i] * hw);
+            boy[i] = rem / g.Wo;
+            box[i] = rem - boy[i] * g.Wo;
+            bptr[i] = zero;
+        }
+    }
+    const int Hu = g.upsample ? g.Hi * 2 : g.Hi, Wu = g.upsample ? g.Wi * 2 : g.Wi;
+    auto retarget = [&](int tap) {  // source pixel of every lane's chunk for tap `tap` (or the zero page)
+#pragma unroll
+        for (int i = 0; i < C::BCH; ++i) {
+            bool inb;
+            int64_t src;
+            if (MODE == 2) {  // temporal: taps along the frame axis inside each clip of fpb frames
+                const int f = bn[i] % g.fpb;
+                const int fs = f + tap - 1;
+                inb = fs >= 0 && fs < g.fpb;
+                src = ((int64_t)(bn[i] - f + (inb ? fs : f)) * g.Hi + boy[i]) * g.Wi + box[i];
+            } else {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                int iy = boy[i] * g.stride + ky - 1, ix = box[i] * g.stride + kx - 1;
+                inb = iy >= 0 && iy < Hu && ix >= 0 && ix < Wu;
+                iy = iy < 0 ? 0 : iy;
+                ix = ix < 0 ? 0 : ix;
+                if (g.upsample) {
+                    iy >>= 1;
+                    ix >>= 1;
+                }
+                iy = iy >= g.Hi ? g.Hi - 1 : iy;
+                ix = ix >= g.Wi ? g.Wi - 1 : ix;
+                src = ((int64_t)bn[i] * g.Hi + iy) * g.Wi + ix;
+            }
+            bptr[i] = (inb && bok[i]) ? reinterpret_cast<const char*>(B + src * g.ldb) + bsc[i] * 16 : zero;
+        }
+    };
+
+    const int nkt = g.taps * g.kchunks;
+    const int kt0 = (int)((int64_t)nkt * ks / g.ksplit), kt1 = (int)((int64_t)nkt * (ks + 1) / g.ksplit);
+    const bool has_tail = (g.Cin & 63) != 0;
+    int cur_tap = -1;
+    auto issue = [&](int kt, int buf) {
+        const int tap = kt / g.kchunks, kc = kt - tap * g.kchunks;  // wave-uniform
+        if (MODE != 0 && tap != cur_tap) {
+            retarget(tap);
+            cur_tap = tap;
+        }
+        const int64_t ka = ((int64_t)tap * g.Cin + kc * 64) * 2;
+        const int kb = kc * 128;
+        const bool tailk = has_tail && kc == g.kchunks - 1;
+        char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
+        char* Bb = Ab + C::BA * 128;
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) {
+            const char* src = aptr[i] + ka;
+            if (tailk && kc * 64 + asc[i] * 8 >= g.Cin) src = zero;
+            fz_glds16(src, Ab + (i * C::NW + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < C::BCH; ++i) {
+            const char* src = bptr[i] + kb;
+            if (tailk && kc * 64 + bsc[i] * 8 >= g.Cin) src = zero;
+            fz_glds16(src, Bb + (i * C::NW + wave) * 1024);
+        }
+    };
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = fz_zero_f16v();
+
+    // fragment read offsets (halves): row r, k chunk c -> r * 64 + ((c ^ ((r >> 1) & 7)) * 8); the tile rows of a lane
+    // are l31 + multiples of 32, so the swizzle term depends on the lane only
+    const int fsw = (l31 >> 1) & 7;
+    const int arow = (wa * TA * 32 + l31) * 64, brow = (wb * TB * 32 + l31) * 64;
+
+    if (kt0 < kt1) issue(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        fz_wait_vm0();    // this wave's LDS-DMA of tile kt has landed ...
+        __syncthreads();  // ... and everybody's; everybody is also done reading buf[cur ^ 1] (tile kt - 1)
+        if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
+        const half_t* As = smem + cur * C::STAGE;
+        const half_t* Bs = As + C::BA * 64;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = ((2 * kk + hi) ^ fsw) * 8;
+            half8_t af[TA], bf[TB];
+#pragma unroll
+            for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * 64 + co);
+#pragma unroll
+            for (int j = 0; j < TB; ++j) bf[j] = fz_ld_h8(Bs + brow + j * 32 * 64 + co);
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) acc[i][j] = fz_mfma_32x32x16_f16(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
+    if (g.part != nullptr) {
+        float* P = g.part + ((int64_t)(ks * gridDim.z + z) * g.Nb) * g.Ma;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int64_t px = b0 + (wb * TB + j) * 32 + l31;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int co = a0 + (wa * TA + i) * 32 + 8 * gq + 4 * hi;
+                    if (px < g.Nb && co < g.Ma) {  // Ma % 4 == 0 on this path (checked by the launcher)
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
+                        *reinterpret_cast<f32x4*>(P + px * g.Ma + co) = v;
+                    }
+                }
+            }
+        return;
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // bias in fp32 on the accumulators (lane <-> B row, register group gq <-> 4 consecutive A rows 8*gq + 4*hi)
+    if (g.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = a0 + (wa * TA + i) * 32 + 8 * gq + 4 * hi;
+                half4_t bv;
+                if (co + 3 < g.Ma) {
+                    bv = *reinterpret_cast<const half4_t*>(g.bias + co);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Ma ? g.bias[co + e] : (half_t)0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * gq + e] += (float)bv[e];
+            }
+    }
+    const int Mo = GEGLU ? g.Ma / 2 : g.Ma;          // output columns in total
+    const int o0 = GEGLU ? a0 / 2 : a0;              // first output column of this tile
+    const int Mo_store = GEGLU ? Mo : g.Ma_store;
+    half_t* Cs = smem;
+    half_t* Y = g.y + (int64_t)z * g.y_bs;
+    const half_t* R1 = g.res ? g.res + (int64_t)z * g.res_bs : nullptr;
+    const half_t* R2 = g.res2 ? g.res2 + (int64_t)z * g.res_bs : nullptr;
+    constexpr int OCH = C::CW / 8;
+    const bool vec_ok = (g.ldy % 8) == 0 && (g.y_bs % 8) == 0 && (g.ldres % 8) == 0 && (g.res_bs % 8) == 0 && (g.temb_stride % 8) == 0;
+    for (int ps = 0; ps < WB / C::WBP; ++ps) {
+        __syncthreads();  // main loop (ps = 0) / the previous pass's readers are done with the LDS
+        if (wb / C::WBP == ps) {
+            const int rl = (wb % C::WBP) * TB * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                half_t* crow = Cs + (rl + j * 32) * C::CSTR;
+                if (GEGLU) {
+#pragma unroll
+                    for (int i = 0; i < TA; i += 2)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            half4_t v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = (half_t)(acc[i][j][4 * gq + e] * ig_gelu(acc[i + 1][j][4 * gq + e]));
+                            *reinterpret_cast<half4_t*>(crow + (wa * TA / 2 + i / 2) * 32 + 8 * gq + 4 * hi) = v;
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            half4_t v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (half_t)acc[i][j][4 * gq + e];
+                            *reinterpret_cast<half4_t*>(crow + (wa * TA + i) * 32 + 8 * gq + 4 * hi) = v;
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        for (int id = tid; id < C::RP * OCH; id += C::T) {
+            const int pl = id / OCH, ch = id - pl * OCH;
+            const int64_t px = b0 + ps * C::RP + pl;
+            const int co = o0 + ch * 8;
+            if (px >= g.Nb || co >= Mo_store) continue;
+            const half8_t v = fz_ld_h8(Cs + pl * C::CSTR + ch * 8);
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = co + e < Mo ? (float)v[e] : 0.0f;  // [Mo, Mo_store): zero padding
+            const bool full = vec_ok && co + 8 <= Mo;
+            if (full) {  // aligned 16-byte accesses
+                if (g.temb != nullptr) {
+                    const half8_t t = fz_ld_h8(g.temb + (px / g.temb_group) * g.temb_stride + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += (float)t[e];
+                }
+                if (R1 != nullptr) {
+                    const half8_t r = fz_ld_h8(R1 + px * g.ldres + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+                }
+                if (R2 != nullptr) {
+                    const half8_t r = fz_ld_h8(R2 + px * g.ldres + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+                }
+            } else {
+                if (g.temb != nullptr) {
+                    const half_t* t = g.temb + (px / g.temb_group) * g.temb_stride + co;
+                    for (int e = 0; e < 8; ++e)
+                        if (co + e < Mo) f[e] += (float)t[e];
+                }
+                if (R1 != nullptr) {
+                    const half_t* r = R1 + px * g.ldres + co;
+                    for (int e = 0; e < 8; ++e)
+                        if (co + e < Mo) f[e] += (float)r[e];
+                }
+                if (R2 != nullptr) {
+                    const half_t* r = R2 + px * g.ldres + co;
+                    for (int e = 0; e < 8; ++e)
+                        if (co + e < Mo) f[e] += (float)r[e];
+                }
+            }
+            half_t* dst = Y + px * g.ldy + co;
+            if (full) {
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
+                fz_st_h8(dst, o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (co + e < Mo_store) dst[e] = (half_t)f[e];
+            }
+        }
+    }
+}
+
+// split-K tail: y[b][a] = sum_s part[s][b][a] + bias[a] (+ temb) (+ res) (+ res2); one thread per 4 outputs
+FZ_KERNEL void __launch_bounds__(256) igemm_reduce_kernel(IgArgs g, int batch) {
+    const int64_t per = g.Nb * (g.Ma / 4);
+    const int64_t total = per * batch;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int z = (int)(id / per);
+        const int64_t r = id - (int64_t)z * per;
+        const int64_t px = r / (g.Ma / 4);
+        const int co = (int)(r - px * (g.Ma / 4)) * 4;
+        f32x4 s = *reinterpret_cast<const f32x4*>(g.part + ((int64_t)z * g.Nb + px) * g.Ma + co);
+        for (int k = 1; k < g.ksplit; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(g.part + (((int64_t)k * batch + z) * g.Nb + px) * g.Ma + co);
+            s += t;
+        }
+        float f[4] = {s[0], s[1], s[2], s[3]};
+        if (g.bias != nullptr)
+            for (int e = 0; e < 4; ++e) f[e] += (float)g.bias[co + e];
+        if (g.temb != nullptr)
+            for (int e = 0; e < 4; ++e) f[e] += (float)g.temb[(px / g.temb_group) * g.temb_stride + co + e];
+        if (g.res != nullptr)
+            for (int e = 0; e < 4; ++e) f[e] += (float)g.res[(int64_t)z * g.res_bs + px * g.ldres + co + e];
+        if (g.res2 != nullptr)
+            for (int e = 0; e < 4; ++e) f[e] += (float)g.res2[(int64_t)z * g.res_bs + px * g.ldres + co + e];
+        half4_t o;
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)f[e];
+        *reinterpret_cast<half4_t*>(g.y + (int64_t)z * g.y_bs + px * g.ldy + co) = o;
+    }
+}
+
+// conv_in of the UNet (4 -> C channels, resnet.py:57-64 with in_channels = 4): K = 36 is far below one MFMA K step, so it
+// is a direct VALU convolution: one thread = one pixel x 8 output channels, weights [Cout][9][Cin] broadcast from L1.
+FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
+    const int och = g.Ma / 8;
+    const int64_t total = g.Nb * och;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int64_t px = id / och;
+        const int co = (int)(id - px * och) * 8;
+        const int hw = g.Ho * g.Wo;
+        const int n = (int)(px / hw), rem = (int)(px - (int64_t)n * hw);
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        float f[8];
+        for (int e = 0; e < 8; ++e) f[e] = g.bias ? (float)g.bias[co + e] : 0.0f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy * g.stride + tap / 3 - 1, ix = ox * g.stride + tap % 3 - 1;
+            if (iy < 0 || iy >= g.Hi || ix < 0 || ix >= g.Wi) continue;
+            const half_t* xs = g.b + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.ldb;
+            for (int ci = 0; ci < g.Cin; ++ci) {
+                const float xv = (float)xs[ci];
+                for (int e = 0; e < 8; ++e) f[e] += xv * (float)g.a[(int64_t)(co + e) * g.lda + tap * g.Cin + ci];
+            }
+        }
+        if (g.temb != nullptr)
+            for (int e = 0; e < 8; ++e) f[e] += (float)g.temb[(px / g.temb_group) * g.temb_stride + co + e];
+        if (g.res != nullptr)
+            for (int e = 0; e < 8; ++e) f[e] += (float)g.res[px * g.ldres + co + e];
+        half8_t o;
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
+        fz_st_h8(g.y + px * g.ldy + co, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//                                                   host side
+// ---------------------------------------------------------------------------------------------------------------
+template <int WA, int TA, int WB, int TB, int MODE, bool GEGLU>
+static int ig_launch(IgArgs g, int batch, void* stream) {
+    typedef IgCfg<WA, TA, WB, TB, GEGLU> C;
+    g.tiles_a = fz_ceil_div(g.Ma, C::BA);
+    const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
+    const int64_t nt = (int64_t)g.tiles_a * tiles_b;
+    if (nt <= 0 || nt >= (1ll << 31) || batch <= 0 || batch > 65535 || g.ksplit < 1 || g.ksplit > 65535) return FZ_ERR_BAD_ARG;
+    const size_t lds = (size_t)C::LDS_HALVES * sizeof(half_t);
+#ifndef FZ_EMU
+    static bool attr_set = false;  // LDS above 64 KB is an opt-in function attribute, not tuning state
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, MODE, GEGLU>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return FZ_ERR_LAUNCH;
+        attr_set = true;
+    }
+#endif
+    dim3 grid((unsigned)nt, (unsigned)g.ksplit, (unsigned)batch), block(C::T);
+    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, MODE, GEGLU>), grid, block, lds, stream, g);
+    return fz_last_launch_status();
+}
+
+// Tile configurations.  id = WA TA WB TB as decimal digits.
+//   2542: 320 x 256, 8 waves -- SD-1.x widths are all multiples of 320, no A-side waste, 142 FLOP per staged byte
+//   2442: 256 x 256, 8 waves -- the GEGLU projection (8C = multiples of 256) and generic large shapes
+//   2242: 128 x 256, 8 waves;  2222: 128 x 128, 4 waves (two workgroups per CU);  2122: 64 x 128, 4 waves
+template <int MODE, bool GEGLU>
+static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
+    switch (cfg) {
+        case 2442: return ig_launch<2, 4, 4, 2, MODE, GEGLU>(g, batch, stream);
+        case 2242: return ig_launch<2, 2, 4, 2, MODE, GEGLU>(g, batch, stream);
+        case 2222: return ig_launch<2, 2, 2, 2, MODE, GEGLU>(g, batch, stream);
+        default: break;
+    }
+    if (!GEGLU) {  // odd TA / TA = 1 cannot pair (h, gate) tiles
+        switch (cfg) {
+            case 2542: return ig_launch<2, 5, 4, 2, MODE, false>(g, batch, stream);
+            case 2122: return ig_launch<2, 1, 2, 2, MODE, false>(g, batch, stream);
+            default: break;
+        }
+    }
+    return FZ_ERR_BAD_ARG;
+}
+
+static const int kCfgs[] = {2542, 2442, 2242, 2222, 2122};
+static void cfg_dims(int cfg, int* ba, int* bb) {
+    const int wa = cfg / 1000, ta = (cfg / 100) % 10, wb = (cfg / 10) % 10, tb = cfg % 10;
+    *ba = wa * ta * 32;
+    *bb = wb * tb * 32;
+}
+
+// Choose (tile configuration, split-K factor).  The chip has 256 CUs; a configuration is scored by the MFMA work it
+// schedules (tile area x tiles, i.e. including edge waste) spread over ceil(workgroups / slots) rounds, divided by a
+// per-configuration efficiency factor measured with scripts/kbench.py --gemm on MI355X.
+static void ig_choose(const IgArgs& g, int batch, bool geglu, bool allow_split, int* cfg_out, int* ksplit_out) {
+    const int nkt = g.taps * g.kchunks;
+    double best = 1e300;
+    *cfg_out = 2222;
+    *ksplit_out = 1;
+    for (int ci = 0; ci < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++ci) {
+        const int cfg = kCfgs[ci];
+        if (geglu && (cfg == 2542 || cfg == 2122)) continue;
+        int ba, bb;
+        cfg_dims(cfg, &ba, &bb);
+        const int64_t tiles = (int64_t)fz_ceil_div(g.Ma, ba) * ((g.Nb + bb - 1) / bb) * batch;
+        const int wg_per_cu = (ba + bb) * 256 <= 80 * 1024 ? 2 : 1;
+        const double eff = cfg == 2542 ? 1.0 : cfg == 2442 ? 0.97 : cfg == 2242 ? 0.85 : cfg == 2222 ? 0.75 : 0.55;
+        for (int s = 1; s <= (allow_split ? 16 : 1); s *= 2) {
+            if (s > 1 && (nkt / s < 8 || (g.Ma % 4) != 0)) break;
+            const int64_t wgs = tiles * s;
+            const int64_t rounds = (wgs + 256 * wg_per_cu - 1) / (256 * wg_per_cu);
+            // time ~ rounds x (K steps per slice + fixed prologue/epilogue worth ~3 K steps) x tile area / efficiency
+            double t = (double)rounds * ((double)nkt / s + 3.0) * ((double)ba * bb) / (eff * wg_per_cu);
+            if (s > 1) t += 2.0 * ((double)g.Nb * g.Ma * batch * s) / 4096.0;  // partial slab write + read
+            if (t < best) {
+                best = t;
+                *cfg_out = cfg;
+                *ksplit_out = s;
+            }
+        }
+    }
+}
+
+template <int MODE, bool GEGLU>
+static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, int64_t workspace_floats, void* stream) {
+    if (g.Cin % 8 || g.Cin > 8128 || g.Cin <= 0) return FZ_ERR_UNSUPPORTED;
+    g.kchunks = fz_ceil_div(g.Cin, 64);
+    if (cfg == 0) {
+        int c, s;
+        ig_choose(g, batch, GEGLU, workspace != nullptr && !GEGLU && g.Ma_store == g.Ma, &c, &s);
+        cfg = c;
+        if (ksplit == 0) ksplit = s;
+    }
+    if (ksplit == 0) ksplit = 1;
+    g.ksplit = ksplit;
+    g.part = nullptr;
+    if (ksplit > 1) {
+        if (GEGLU || workspace == nullptr || (g.Ma % 4) || g.Ma_store != g.Ma || (g.ldy % 4)) return FZ_ERR_UNSUPPORTED;
+        if ((int64_t)ksplit * batch * g.Nb * g.Ma > workspace_floats) return FZ_ERR_BAD_ARG;
+        if (ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
+        g.part = workspace;
+    }
+    const int rc = ig_dispatch_cfg<MODE, GEGLU>(cfg, g, batch, stream);
+    if (rc != FZ_OK || ksplit == 1) return rc;
+    const int64_t total = g.Nb * (g.Ma / 4) * batch;
+    dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+    FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, batch);
+    return fz_last_launch_status();
+}
+
+extern "C" int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch) {
+    return 16 * rows * (int64_t)out_features * (batch > 0 ? batch : 1);
+}
+
+extern "C" int fz_gemm(const FzGemmDesc* d, const void* x, const void* w, const void* bias, const void* res, const void* res2,
+                       void* y, void* workspace, void* stream) {
+    if (!d || !x || !w || !y || d->rows <= 0 || d->in_features <= 0 || d->out_features <= 0) return FZ_ERR_BAD_ARG;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    IgArgs g = {};
+    g.taps = 1;
+    g.fpb = 1;
+    g.Cin = d->in_features;
+    g.temb = nullptr;
+    g.temb_group = 1;
+    g.res = (const half_t*)res;
+    g.res2 = (const half_t*)res2;
+    g.ldres = d->ldres ? d->ldres : d->ldy;
+    g.res_bs = d->res_batch_stride;
+    g.y = (half_t*)y;
+    g.ldy = d->ldy;
+    g.y_bs = d->y_batch_stride;
+    if (d->ldx < d->in_features || d->ldw < d->in_features || (d->ldx % 8) || (d->ldw % 8)) return FZ_ERR_BAD_ARG;
+    const bool geglu = d->epilogue == FZ_GEMM_GEGLU;
+    if (d->epilogue != FZ_GEMM_PLAIN && !geglu) return FZ_ERR_BAD_ARG;
+    if (!d->transpose_out) {  // y[row][out]:  A = W (out features), B = x rows
+        g.a = (const half_t*)w;
+        g.lda = d->ldw;
+        g.a_bs = 0;
+        g.Ma = d->out_features;
+        g.Ma_store = d->out_features;
+        g.b = (const half_t*)x;
+        g.ldb = d->ldx;
+        g.b_bs = d->x_batch_stride;
+        g.Nb = d->rows;
+        g.bias = (const half_t*)bias;
+        const int outw = geglu ? d->out_features / 2 : d->out_features;
+        if (d->ldy < outw) return FZ_ERR_BAD_ARG;
+        if (geglu) {
+            if (d->out_features % 64 || res || res2) return FZ_ERR_UNSUPPORTED;
+            return ig_run<0, true>(g, batch, d->tile_cfg, 1, nullptr, 0, stream);
+        }
+        return ig_run<0, false>(g, batch, d->tile_cfg, d->split_k, (float*)workspace, d->workspace_floats, stream);
+    }
+    // y[b][out][row] (V^T): A = x rows of the batch element (row index contiguous in the output), B = W rows
+    if (geglu || bias || res || res2) return FZ_ERR_UNSUPPORTED;
+    if (d->rows >= (1ll << 31)) return FZ_ERR_UNSUPPORTED;
+    g.a = (const half_t*)x;
+    g.lda = d->ldx;
+    g.a_bs = d->x_batch_stride;
+    g.Ma = (int)d->rows;
+    g.Ma_store = d->rows_store > d->rows ? (int)d->rows_store : (int)d->rows;
+    g.b = (const half_t*)w;
+    g.ldb = d->ldw;
+    g.b_bs = 0;
+    g.Nb = d->out_features;
+    g.bias = nullptr;
+    if (d->ldy < g.Ma_store) return FZ_ERR_BAD_ARG;
+    return ig_run<0, false>(g, batch, d->tile_cfg, 1, nullptr, 0, stream);
+}
+
+static int conv_common(IgArgs& g, const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride,
+                       const void* res, const void* res2, void* y, int cin, int cout) {
+    g.a = (const half_t*)wt;
+    g.lda = (int64_t)g.taps * cin;
+    g.Ma = g.Ma_store = cout;
+    g.b = (const half_t*)x;
+    g.ldb = cin;
+    g.Cin = cin;
+    g.bias = (const half_t*)bias;
+    g.temb = (const half_t*)temb;
+    g.temb_stride = temb_stride ? temb_stride : cout;
+    g.temb_group = (int64_t)g.fpb * g.Ho * g.Wo;
+    g.res = (const half_t*)res;
+    g.res2 = (const half_t*)res2;
+    g.y = (half_t*)y;
+    g.ldy = g.ldres = cout;
+    g.Nb = (int64_t)g.N * g.Ho * g.Wo;
+    return FZ_OK;
+}
+
+extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
+                                int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len,
+                                void* stream) {
+    if (!x || !wt || !y || n <= 0 || tokens <= 0 || clip_len <= 0 || n % clip_len) return FZ_ERR_BAD_ARG;
+    if (cin % 8) return FZ_ERR_UNSUPPORTED;
+    IgArgs g = {};
+    g.taps = 3;
+    g.N = n; g.Hi = 1; g.Wi = tokens; g.Ho = 1; g.Wo = tokens; g.stride = 1; g.upsample = 0; g.fpb = clip_len;
+    conv_common(g, x, wt, nullptr, temb, temb_stride, res, res2, y, cin, cout);
+    return ig_run<2, false>(g, 1, 0, 1, nullptr, 0, stream);
+}
+
+extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
+                          void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
+                          void* workspace, int64_t workspace_floats, int tile_cfg, int split_k, void* stream) {
+    if (!x || !wt || !y || n <= 0 || hi <= 0 || wi <= 0) return FZ_ERR_BAD_ARG;
+    if ((stride != 1 && stride != 2) || (upsample && stride != 1)) return FZ_ERR_UNSUPPORTED;
+    IgArgs g = {};
+    g.taps = 9;
+    g.N = n; g.Hi = hi; g.Wi = wi; g.stride = stride; g.upsample = upsample;
+    g.fpb = frames_per_batch > 0 ? frames_per_batch : 1;
+    const int hu = upsample ? 2 * hi : hi, wu = upsample ? 2 * wi : wi;
+    g.Ho = (hu + 2 - 3) / stride + 1;
+    g.Wo = (wu + 2 - 3) / stride + 1;
+    conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout);
+    if (cin % 8) {  // conv_in (4 input channels): direct VALU convolution
+        if (cout % 8 || upsample) return FZ_ERR_UNSUPPORTED;
+        const int64_t total = g.Nb * (cout / 8);
+        dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
+        FZ_LAUNCH(conv3x3_small_cin_kernel, grid, block, 0, stream, g);
+        return fz_last_launch_status();
+    }
+    return ig_run<1, false>(g, 1, tile_cfg, split_k, (float*)workspace, workspace_floats, stream);
+}

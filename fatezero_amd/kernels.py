@@ -267,9 +267,94 @@ def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
     return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).to(torch.float16).contiguous()
 
 
+_ws = {}
+
+
+def _workspace(device, floats: int) -> torch.Tensor:
+    """fp32 scratch for split-K partial slabs (one per device, grown on demand, never shrunk)."""
+    buf = _ws.get(device)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        _ws[device] = buf
+    return buf
+
+
+# launches with at most this many output elements get a split-K workspace (above it the tile count fills the chip)
+_SPLITK_MAX_OUT = 1 << 23
+
+
+def pack_geglu(w: torch.Tensor, b: Optional[torch.Tensor]):
+    """GEGLU projection weight [2*inner, K] (rows [h ; gate], diffusers GEGLU.proj) -> rows regrouped so that every 64-row
+    group is 32 h rows followed by the 32 matching gate rows (include/fatezero_hip.h, FZ_GEMM_GEGLU)."""
+    two, k = w.shape
+    inner = two // 2
+    assert inner % 32 == 0, inner
+    wp = torch.stack([w[:inner].reshape(inner // 32, 32, k), w[inner:].reshape(inner // 32, 32, k)], 1).reshape(two, k)
+    bp = None
+    if b is not None:
+        bp = torch.stack([b[:inner].reshape(inner // 32, 32), b[inner:].reshape(inner // 32, 32)], 1).reshape(two)
+    return wp.contiguous(), (None if bp is None else bp.contiguous())
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
+         res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, geglu: bool = False, tile_cfg: int = 0,
+         split_k: int = 0):
+    """y[..., o] = x[..., :] @ w[o, :] + bias (+ res) (+ res2); x: [..., K] with unit channel stride and ONE row stride
+    (a channel slice of a token-major tensor is fine); w: [O, K] fp16 (GEGLU: packed by pack_geglu); res / out: [..., O']."""
+    k = x.shape[-1]
+    o = w.shape[0]
+    ow = o // 2 if geglu else o
+    rows = x.numel() // k
+    assert x.stride(-1) == 1 and w.stride(1) == 1 and w.shape[1] == k
+    ldx = x.stride(-2) if x.dim() > 1 else k
+    for d in range(x.dim() - 2):  # leading dims must collapse onto the row stride
+        assert x.stride(d) == x.stride(d + 1) * x.shape[d + 1], "x must have a single row stride"
+    _chk16(x, w, bias, res, res2)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], ow, dtype=torch.float16, device=x.device)
+    assert out.stride(-1) == 1 and out.shape[-1] == ow and out.numel() // ow == rows
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = rows, k, o
+    d.ldx, d.ldw, d.ldy = ldx, w.stride(0), (out.stride(-2) if out.dim() > 1 else ow)
+    d.batch, d.epilogue = 1, (N.FZ_GEMM_GEGLU if geglu else N.FZ_GEMM_PLAIN)
+    d.tile_cfg, d.split_k = tile_cfg, split_k
+    for r in (res, res2):
+        if r is not None:
+            assert r.shape[-1] == ow and r.stride(-1) == 1 and r.numel() // ow == rows
+    if res is not None:
+        d.ldres = res.stride(-2) if res.dim() > 1 else ow
+        if res2 is not None:
+            assert (res2.stride(-2) if res2.dim() > 1 else ow) == d.ldres
+    ws = None
+    if not geglu and rows * o <= _SPLITK_MAX_OUT and o % 4 == 0:
+        need = N.lib().fz_gemm_workspace_floats(rows, o, 1)
+        ws = _workspace(x.device, need)
+        d.workspace_floats = ws.numel()
+    N.check(N.lib().fz_gemm(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(res2), _ptr(out), _ptr(ws), _stream(x)),
+            "fz_gemm")
+    return out
+
+
+def gemm_vt(x: torch.Tensor, w: torch.Tensor, lp: int, out: Optional[torch.Tensor] = None, tile_cfg: int = 0):
+    """x: [N, L, K] (unit channel stride), w: [C, K] -> V^T [N, C, lp] = w @ x[n]^T, columns [L, lp) zero."""
+    n, l, k = x.shape
+    c = w.shape[0]
+    assert x.stride(2) == 1 and w.stride(1) == 1 and lp >= l and lp % 8 == 0
+    _chk16(x, w)
+    if out is None:
+        out = torch.empty(n, c, lp, dtype=torch.float16, device=x.device)
+    d = N.FzGemmDesc()
+    d.rows, d.rows_store, d.in_features, d.out_features = l, lp, k, c
+    d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(0), out.stride(1)
+    d.batch, d.x_batch_stride, d.y_batch_stride = n, x.stride(0), out.stride(0)
+    d.transpose_out, d.tile_cfg = 1, tile_cfg
+    N.check(N.lib().fz_gemm(C.byref(d), _ptr(x), _ptr(w), None, None, None, _ptr(out), None, _stream(x)), "fz_gemm(vt)")
+    return out
+
+
 def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, hw: Tuple[int, int], stride: int = 1,
             upsample: bool = False, temb: Optional[torch.Tensor] = None, frames_per_batch: int = 1,
-            res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+            res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tile_cfg: int = 0, split_k: int = 0):
     """x: [N, H*W, Cin] token-major fp16 -> [N, Ho*Wo, Cout]."""
     n, _, cin = x.shape
     h, w = hw
@@ -286,8 +371,13 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, 
     if temb is not None:
         assert temb.shape == (n // frames_per_batch, cout) and temb.stride(1) == 1
         ts = temb.stride(0)
+    ws, wsn = None, 0
+    if n * ho * wo * cout <= _SPLITK_MAX_OUT and cout % 4 == 0 and cin % 8 == 0:
+        ws = _workspace(x.device, N.lib().fz_gemm_workspace_floats(n * ho * wo, cout, 1))
+        wsn = ws.numel()
     N.check(N.lib().fz_conv3x3(_ptr(x), _ptr(wt), _ptr(bias), _ptr(temb), ts, _ptr(res), _ptr(out), n, h, w, cin, cout, stride,
-                               1 if upsample else 0, frames_per_batch, _stream(x)), "fz_conv3x3")
+                               1 if upsample else 0, frames_per_batch, _ptr(ws), wsn, tile_cfg, split_k, _stream(x)),
+            "fz_conv3x3")
     return out, (ho, wo)
 
 

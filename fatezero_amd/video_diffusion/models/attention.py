@@ -17,7 +17,6 @@ from dataclasses import dataclass
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from ... import dist as D
@@ -101,8 +100,9 @@ class CrossAttention(nn.Module):
         run_inject(p)
 
     # -- cross attention (attention_register.py:71-128) ------------------------------------------------------
-    def forward_cross(self, x: Tokens, ctx, clip: int):
-        """x.data: LayerNorm'ed hidden states [N, L, C]; ctx: [B, 77, Dctx] fp16."""
+    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None):
+        """x.data: LayerNorm'ed hidden states [N, L, C]; ctx: [B, 77, Dctx] fp16.  Returns residual + to_out(attention)
+        (the block's `hidden_states = attn2(...) + hidden_states`, attention.py:303-311, fused into the GEMM epilogue)."""
         n, lq, c = x.data.shape
         q = self.to_q.apply(x.data)
         # K / V^T of the text context depend only on (ctx, weights): the DDIM loops pass the same embedding tensor at
@@ -112,7 +112,7 @@ class CrossAttention(nn.Module):
             kk, vt = kvc[2], kvc[3]
         else:
             kk = self.to_k.apply(ctx)
-            vt = K.transpose_pad(self.to_v.apply(ctx), K.CROSS_KEYS)
+            vt = K.gemm_vt(ctx, self.to_v.packed(ctx.dtype, ctx.device)[0], K.CROSS_KEYS)  # V^T straight out of the GEMM
             self._ctx_kv = (ctx, ctx._version, kk, vt)
         lk = ctx.shape[1]
         out = torch.empty(n, lq, self.inner_dim, dtype=q.dtype, device=q.device)
@@ -138,16 +138,16 @@ class CrossAttention(nn.Module):
             if plan.n_plain < n:
                 K.attn_cross(q, kk, vt, out, mode=plan.mode, frame0=plan.n_plain, n_frames=n - plan.n_plain, p=plan.p,
                              mapper_t=plan.mapper_t, coef=plan.coef, cur_out=plan.cur_out, **kw)
-        return self.to_out[0].apply(out)
+        return self.to_out[0].apply(out, res=residual)
 
     # -- temporal attention (attention.py:327-337; never controlled, attention_register.py:242) ---------------
-    def forward_temporal(self, x_norm, batch: int, clip: int):
-        """x_norm: [B*F, L, C] LayerNorm'ed; attention over the F frames of every (b, token)."""
+    def forward_temporal(self, x_norm, batch: int, clip: int, residual=None):
+        """x_norm: [B*F, L, C] LayerNorm'ed; attention over the F frames of every (b, token); + residual in the epilogue."""
         n, l, c = x_norm.shape
         if self._qkv is None or self._qkv.device != x_norm.device:
             self._qkv = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device),
                                    self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0).contiguous()
-        qkv = F.linear(x_norm, self._qkv)
+        qkv = K.gemm(x_norm, self._qkv)
         inner = self.inner_dim
         out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
         shard = D.active_shard()
@@ -156,14 +156,15 @@ class CrossAttention(nn.Module):
             kv = kv.reshape(batch * shard.clip_len, l, 2 * inner)
             K.attn_temporal(qkv[..., :inner], kv[..., :inner], kv[..., inner:], out, batch=batch, clip_len=clip,
                             kv_frames=shard.clip_len, heads=self.heads, scale=self.scale)
-            return self.to_out[0].apply(out)
+            return self.to_out[0].apply(out, res=residual)
         K.attn_temporal(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], out, batch=batch, clip_len=clip,
                         heads=self.heads, scale=self.scale)
-        return self.to_out[0].apply(out)
+        return self.to_out[0].apply(out, res=residual)
 
-    def load_state_dict(self, *a, **k):  # packed weights must follow the parameters
+    def load_state_dict(self, *a, **k):  # packed weights / cached projections must follow the parameters
         self._qk = None
         self._qkv = None
+        self._ctx_kv = None
         return super().load_state_dict(*a, **k)
 
 
@@ -200,20 +201,17 @@ def _sharded_kv(shard, kk, vt, batch, clip, index_list):
 class SparseCausalAttention(CrossAttention):
     """attention.py:340-422 / attention_register.py:131-218: frame f attends the K/V of frames idx_j(f)."""
 
-    def forward_self(self, x: Tokens, clip: int, index_list):
+    def forward_self(self, x: Tokens, clip: int, index_list, residual=None):
         n, lq, c = x.data.shape
         xn = x.data
         # head dims with a free MFMA contraction slot (SD-1.x: 40): the softmax scale and log2(e) go into Wq, q comes out of
         # the projection GEMM in the log2 domain and the flash kernel gets its running max for free (csrc/attn_flash.hip)
         d_head = self.inner_dim // self.heads
         folded = d_head % 16 != 0 and d_head % 8 == 0
-        qk = F.linear(xn, self._qk_weight(xn.dtype, xn.device, self.scale * _LOG2E if folded else 1.0))
+        qk = K.gemm(xn, self._qk_weight(xn.dtype, xn.device, self.scale * _LOG2E if folded else 1.0))
         q, kk = qk[..., : self.inner_dim], qk[..., self.inner_dim:]
-        wv = self.to_v.packed(xn.dtype, xn.device)[0]
-        if lq % 64 == 0:
-            vt = torch.matmul(wv, xn.transpose(1, 2))  # V^T straight out of the projection GEMM: [N, C, L]
-        else:
-            vt = K.transpose_pad(F.linear(xn, wv), K.pad64(lq))
+        # V^T straight out of the projection GEMM (operands swapped: [N, C, L], rows zero-padded to a multiple of 64 keys)
+        vt = K.gemm_vt(xn, self.to_v.packed(xn.dtype, xn.device)[0], K.pad64(lq))
         out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
         n_kv = max(1, len(index_list))
         kw = dict(clip_len=clip, heads=self.heads, index_list=index_list, scale=self.scale, q_log2_scaled=folded)
@@ -245,13 +243,22 @@ class SparseCausalAttention(CrossAttention):
                                 row_mask=plan.row_mask, **rest, **kw)
                 elif not (plan.mode == K.FZ_ATTN_FLASH and plan.capture_first is not None):
                     K.attn_self(q, kk, vt, out, mode=plan.mode, p=plan.p, **rest, **kw)
-        return self.to_out[0].apply(out)
+        return self.to_out[0].apply(out, res=residual)
 
 
 class _GEGLU(nn.Module):
     def __init__(self, dim, inner):
         super().__init__()
         self.proj = _LinearParams(dim, inner * 2)
+        self._packed = None
+
+    def packed(self, dtype, device):
+        """The projection's rows regrouped (32 h rows | 32 gate rows) for the GEGLU epilogue of fz_gemm."""
+        if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
+            w = self.proj.weight.detach().to(device=device, dtype=dtype)
+            b = None if self.proj.bias is None else self.proj.bias.detach().to(device=device, dtype=dtype)
+            self._packed = K.pack_geglu(w, b)
+        return self._packed
 
 
 class FeedForward(nn.Module):
@@ -261,8 +268,16 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([_GEGLU(dim, dim * mult), nn.Identity(), _LinearParams(dim * mult, dim)])
 
-    def apply(self, x):
-        return self.net[2].apply(K.geglu(self.net[0].proj.apply(x)))
+    def apply(self, x, res=None):
+        """res + Linear(h * gelu(gate)): the 8C-wide GEGLU intermediate is never written (gate applied in the epilogue of the
+        projection GEMM), the residual add rides in the epilogue of the output GEMM."""
+        g = self.net[0]
+        if g.proj.weight.shape[0] % 64 == 0:
+            w, b = g.packed(x.dtype, x.device)
+            h = K.gemm(x, w, b, geglu=True)
+        else:
+            h = K.geglu(g.proj.apply(x))
+        return self.net[2].apply(h, res=res)
 
 
 def layer_norm_tokens(norm: _NormParams, x):
@@ -297,10 +312,11 @@ class SpatioTemporalTransformerBlock(nn.Module):
     def forward_tokens(self, x: Tokens, ctx):
         hs = x.data
         clip = x.f
-        hs = hs + self.attn1.forward_self(x.like(layer_norm_tokens(self.norm1, hs)), clip, self.sc_index)
-        hs = hs + self.attn2.forward_cross(x.like(layer_norm_tokens(self.norm2, hs)), ctx, clip)
-        hs = hs + self.ff.apply(layer_norm_tokens(self.norm3, hs))
-        hs = hs + self.attn_temporal.forward_temporal(layer_norm_tokens(self.norm_temporal, hs), x.b, clip)
+        # every `x = f(norm(x)) + x` of attention.py:295-337 ends in a GEMM: the residual add is that GEMM's epilogue
+        hs = self.attn1.forward_self(x.like(layer_norm_tokens(self.norm1, hs)), clip, self.sc_index, residual=hs)
+        hs = self.attn2.forward_cross(x.like(layer_norm_tokens(self.norm2, hs)), ctx, clip, residual=hs)
+        hs = self.ff.apply(layer_norm_tokens(self.norm3, hs), res=hs)
+        hs = self.attn_temporal.forward_temporal(layer_norm_tokens(self.norm_temporal, hs), x.b, clip, residual=hs)
         return x.like(hs)
 
 
@@ -323,7 +339,7 @@ class SpatioTemporalTransformerModel(nn.Module):
         h = group_norm_tokens(self.norm, x, span_frames=False, silu=False)
         h = h.like(self.proj_in.apply(h.data))
         h = self.transformer_blocks[0].forward_tokens(h, ctx)
-        return x.like(self.proj_out.apply(h.data) + x.data)
+        return x.like(self.proj_out.apply(h.data, res=x.data))
 
 
 class _Conv1x1Params(nn.Module):
@@ -336,8 +352,8 @@ class _Conv1x1Params(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
         self._packed = None
 
-    def apply(self, x):
+    def apply(self, x, res=None):
         if self._packed is None or self._packed[0].dtype != x.dtype or self._packed[0].device != x.device:
             self._packed = (self.weight.detach().reshape(self.weight.shape[0], -1).to(device=x.device, dtype=x.dtype).contiguous(),
                             self.bias.detach().to(device=x.device, dtype=x.dtype))
-        return F.linear(x, *self._packed)
+        return K.gemm(x, self._packed[0], self._packed[1], res=res)

@@ -49,8 +49,6 @@ def temporal_conv_tokens(x4, w_taps, bias=None, residual=None):
 
 
 class LoRALinearLayer(nn.Module):
-    NATIVE_MIN_ROWS = 8192  # (frames x tokens) from which the hand-written temporal conv beats three library GEMMs
-
     def __init__(self, in_features, out_features, rank=4, stride=1):
         super().__init__()
         if rank > min(in_features, out_features):
@@ -68,12 +66,12 @@ class LoRALinearLayer(nn.Module):
             rank, cin = dw.shape[0], dw.shape[1]
             cout = uw.shape[0]
             is_noop = bool((self.up.weight == 0).all())  # un-tuned SD: up == 0 -> exact identity
-            native = (rank % 32 == 0 and cin % 32 == 0 and cout % 8 == 0 and dtype == torch.float16)
+            native = (rank % 8 == 0 and cin % 8 == 0 and dtype == torch.float16)
             # [Cout][3][Cin] packing of the implicit-GEMM kernel (fz_temporal_conv3) ...
             wdn = dw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous() if native else None
             wun = uw.permute(0, 2, 1).to(device=device, dtype=dtype).contiguous() if native else None
-            # ... and tap-major [3, Cin, Cout] for the library-GEMM form used for tiny ranks (conv_out's rank 2) and for
-            # the small pyramid levels, where a few workgroups cannot fill the chip (scripts/kbench.py --tconv)
+            # ... and tap-major [3, Cin, Cout] for conv_out's rank-2 LoRA (4 -> 2 -> 4 channels: below the 16-byte chunk of the
+            # MFMA kernel; three [rows, 4] x [4, 2] products, only alive with a tuned checkpoint)
             wd = dw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
             wu = uw.to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
             self._packed = (wd, wu, is_noop, native, wdn, wun)
@@ -98,15 +96,15 @@ class LoRALinearLayer(nn.Module):
             # the clip's frames are split over ranks: one-frame halos from the neighbours (zeros beyond the clip ends, the
             # conv's own padding), first of x, then of down(x); the halo frames' outputs are dropped
             x_ext = shard.with_halo(x4, 1, 1, zero_outside=True)
-            d = temporal_conv_tokens(x_ext, wd)[:, 1:-1].contiguous()
+            d = self._conv(x_ext, wd, wdn, native)[:, 1:-1].contiguous()
             d_ext = shard.with_halo(d, 1, 1, zero_outside=True)
-            y = temporal_conv_tokens(d_ext, wu)[:, 1:-1] + x4
+            y = self._conv(d_ext, wu, wun, native)[:, 1:-1] + x4
             if temb is not None:
                 y = y + temb[:, None, None, :]
             if residual is not None:
                 y = y + residual.view(b, f, t, c)
             return y
-        if native and b * f * t >= self.NATIVE_MIN_ROWS:
+        if native:
             x3 = x4.reshape(b * f, t, c)
             d = K.temporal_conv3(x3, wdn, clip_len=f)
             y = K.temporal_conv3(d, wun, clip_len=f, res=x3, res2=residual, temb=temb)
@@ -118,3 +116,13 @@ class LoRALinearLayer(nn.Module):
         if residual is not None:
             y = y + residual.view(b, f, t, c)
         return y
+
+    @staticmethod
+    def _conv(x_ext, w_taps, w_native, native):
+        """k=3 temporal conv of a haloed clip [B, F+2, T, C] (the extended clip is its own zero-padded sequence; the halo
+        frames' outputs are dropped by the caller)."""
+        if not native:
+            return temporal_conv_tokens(x_ext, w_taps)
+        b, fe, t, c = x_ext.shape
+        y = K.temporal_conv3(x_ext.reshape(b * fe, t, c).contiguous(), w_native, clip_len=fe)
+        return y.view(b, fe, t, w_native.shape[0])

@@ -2,13 +2,12 @@
 
 Token-major fp16 engine: x is [N = B*F, H*W, C].  GroupNorm(+SiLU) is the HIP kernel (statistics span all F
 frames of a batch element, exactly like torch.nn.GroupNorm on the reference's 5-D [b,c,f,h,w] input,
-resnet.py:338,369); the 3x3 convolution currently runs through MIOpen on a channels-last *view* of the same
-buffer (no layout copies); the temporal conv is GEMMs over shifted frame views (lora.py).
+resnet.py:338,369); every convolution and projection is the MFMA implicit-GEMM kernel of csrc/igemm.hip (no layout
+copies, no library GEMM / convolution on the path).
 """
 import copy
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from ... import dist as D
@@ -64,58 +63,45 @@ class PseudoConv3d(nn.Module):
             self.conv_temporal = None
         self._packed = None
 
-    # The hand-written implicit-GEMM kernel (fz_conv3x3) is used where it beats MIOpen's NHWC igemm on MI355X
-    # (scripts/kbench.py --conv, profiles/r01_kbench_conv_final.json): launches with >= 4096 output pixels over all frames
-    # (607 vs 326 TF/s at 64x64, 521-584 vs 414-418 at 32x32, 561 vs 421 at 16x16 x 16 frames) and every upsample conv (the
-    # nearest 2x is folded into its addressing, 747 vs 409).  Smaller launches (16x16 x 8 frames, 8x8) cannot fill the chip
-    # with 128x128 tiles and run through MIOpen on a channels-last view.
-    NATIVE_MIN_PIXELS = 4096
-
     def _pack(self, dtype, device):
         if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
+            if dtype != torch.float16:
+                raise RuntimeError("the MI355X engine computes in fp16 storage / fp32 accumulation: call unet.half()")
             w = self.weight.detach().to(device=device, dtype=dtype)
-            wt = None
             if self.kernel_size == 1:
                 w = w.reshape(self.out_channels, self.in_channels).contiguous()
             else:
-                if self.in_channels % 32 == 0 and self.out_channels % 8 == 0 and dtype == torch.float16:
-                    wt = K.pack_conv3x3_weight(w)
-                w = w.contiguous(memory_format=torch.channels_last)
+                assert self.kernel_size == 3 and self.padding == 1, "the pseudo-3D UNet only uses 3x3 pad-1 and 1x1 convolutions"
+                w = K.pack_conv3x3_weight(w)  # [Cout][tap][Cin]: K contiguous per output channel (csrc/igemm.hip)
             bias = self.bias.detach().to(device=device, dtype=dtype)
             wtt = btt = None
             if self.conv_temporal is not None and not isinstance(self.conv_temporal, LoRALinearLayer):
                 wtt = self.conv_temporal.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
                 btt = self.conv_temporal.bias.detach().to(device=device, dtype=dtype)
-            self._packed = (w, bias, wtt, btt, wt)
+            self._packed = (w, bias, wtt, btt)
         return self._packed
 
     def forward_tokens(self, x: Tokens, residual=None, temb=None, upsample=False) -> Tokens:
-        """conv (+ temporal conv) (+ temb[b] per batch element) (+ residual). temb: [B, Cout] view, residual: [N, T, Cout]."""
-        w, bias, wtt, btt, wt = self._pack(x.data.dtype, x.data.device)
+        """conv (+ temporal conv) (+ temb[b] per batch element) (+ residual). temb: [B, Cout] view, residual: [N, T, Cout].
+        Every spatial convolution of the UNet -- all pyramid levels, conv_in, conv_out, the 1x1 shortcuts -- runs through
+        the hand-written implicit-GEMM kernel (fz_conv3x3 / fz_gemm); the elementwise tail (time embedding, residual)
+        rides in the epilogue of the LAST linear op of the layer (the temporal conv when it is active)."""
+        w, bias, wtt, btt = self._pack(x.data.dtype, x.data.device)
         n, hw, c = x.data.shape
         lora = self.conv_temporal if isinstance(self.conv_temporal, LoRALinearLayer) else None
         plain_t = self.conv_temporal is not None and lora is None
         temporal_active = plain_t or (lora is not None and not lora.is_noop(x.data.dtype, x.data.device))
+        fuse_tail = not temporal_active  # the elementwise tail commutes with nothing but the last linear op
         if self.kernel_size == 1:
-            y = F.linear(x.data, w, bias)
+            y = K.gemm(x.data, w, bias, res=residual if (fuse_tail and temb is None) else None)
             oh, ow = x.h, x.w
-            fused = False
+            fused = fuse_tail and temb is None
         else:
-            out_px = n * (((x.h - 1) // self.stride + 1) * ((x.w - 1) // self.stride + 1))
-            native = wt is not None and (upsample or out_px >= self.NATIVE_MIN_PIXELS) and x.data.is_contiguous()
-            if native:
-                fuse_tail = not temporal_active  # the elementwise tail commutes with nothing but the last linear op
-                y, (oh, ow) = K.conv3x3(x.data, wt, bias, hw=(x.h, x.w), stride=self.stride, upsample=upsample,
-                                        temb=temb if fuse_tail else None, frames_per_batch=x.f,
-                                        res=residual if fuse_tail else None)
-                fused = fuse_tail
-            else:
-                xin = upsample_nearest2x(x) if upsample else x
-                xi = xin.data.view(n, xin.h, xin.w, c).permute(0, 3, 1, 2)  # NCHW view of NHWC memory (channels_last)
-                yo = F.conv2d(xi, w, bias, stride=self.stride, padding=self.padding)
-                oh, ow = yo.shape[2], yo.shape[3]
-                y = yo.permute(0, 2, 3, 1).reshape(n, oh * ow, self.out_channels)
-                fused = False
+            xin = x.data if x.data.is_contiguous() else x.data.contiguous()
+            y, (oh, ow) = K.conv3x3(xin, w, bias, hw=(x.h, x.w), stride=self.stride, upsample=upsample,
+                                    temb=temb if fuse_tail else None, frames_per_batch=x.f,
+                                    res=residual if fuse_tail else None)
+            fused = fuse_tail
         if lora is not None and temporal_active:
             y4 = lora.forward_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), temb=temb, residual=residual)
             y = y4.reshape(n, oh * ow, self.out_channels)
@@ -210,9 +196,10 @@ class _LinearParams(nn.Module):
                             None if self.bias is None else self.bias.detach().to(device=device, dtype=dtype))
         return self._packed
 
-    def apply(self, x):
+    def apply(self, x, res=None):
+        """x @ W^T + b (+ res) through fz_gemm (csrc/igemm.hip)."""
         w, b = self.packed(x.dtype, x.device)
-        return F.linear(x, w, b)
+        return K.gemm(x, w, b, res=res)
 
 
 class ResnetBlockPseudo3D(nn.Module):

@@ -138,6 +138,7 @@ class UNetPseudo3DConditionModel(nn.Module):
 
     def _project_time_embeddings(self, temb_act):
         """All 22 `time_emb_proj` Linear layers of the ResNet blocks as ONE GEMM (they only depend on the timestep)."""
+        from ... import kernels as K
         pk = getattr(self, "_temb_pack", None)
         if pk is None or pk[0].device != temb_act.device:
             from .resnet import ResnetBlockPseudo3D
@@ -151,7 +152,7 @@ class UNetPseudo3DConditionModel(nn.Module):
             pk = (w.contiguous(), bias, blocks, offs)
             self._temb_pack = pk
         w, bias, blocks, offs = pk
-        t_all = F.linear(temb_act, w, bias)  # [B, sum Cout]
+        t_all = K.gemm(temb_act, w, bias)  # [B, sum Cout]
         for b, (o, c) in zip(blocks, offs):
             b._temb_cached = t_all[:, o:o + c]
 

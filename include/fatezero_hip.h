@@ -146,15 +146,52 @@ int fz_groupnorm_apply(const void* x, void* y, const void* gamma, const void* be
                        int channels, int groups, float eps, int silu, const float* partial_all, int stat_sets,
                        int frames_per_set, float* stats, void* stream);
 
+/* Linear projection GEMM with fused epilogues: nn.Linear / 1x1 nn.Conv2d of the transformer blocks and ResNet
+ * shortcuts -- attention.py:64-66,91-93 (proj_in / proj_out), :199,216 (CrossAttention to_q/k/v/out [3P diffusers 0.11.1]),
+ * :232 (FeedForward GEGLU), resnet.py:290 (time_emb_proj), the 1x1 conv_shortcut (resnet.py:302-305):
+ *   y[b][r][o] = sum_i x[b][r][i] * w[o][i] + bias[o] (+ res[b][r][o]) (+ res2[b][r][o])
+ * FZ_GEMM_GEGLU: w / bias rows are the GEGLU projection (2*inner rows) PACKED so that every group of 64 rows holds 32 `h`
+ *   rows followed by the 32 matching `gate` rows (fatezero_amd.kernels.pack_geglu); y[r][c] = h * gelu_erf(gate), inner
+ *   columns -- the 2*inner wide intermediate of GEGLU.forward is never written.
+ * transpose_out: y[b][o][r] = sum_i x[b][r][i] * w[o][i] (no bias / residual) -- V^T, the value operand of fz_attn_self /
+ *   fz_attn_cross, straight out of the projection; columns [rows, rows_store) of every output row are written as zeros.
+ * in_features % 8 == 0; ldx, ldw, ldy, ldres % 8 == 0 for the vector paths; fp16 in/out, fp32 accumulation.
+ * workspace (optional): fp32 scratch of workspace_floats elements enabling split-K for shapes with too few output tiles
+ *   to fill the chip; fz_gemm_workspace_floats(rows, out_features, batch) is always enough.
+ * tile_cfg / split_k: 0 = chosen by the library (the normal use); non-zero values pin the tile shape (2542, 2442, 2242,
+ *   2222, 2122 = waves x MFMA tiles, csrc/igemm.hip) / the K split for benchmarking. */
+#define FZ_GEMM_PLAIN 0
+#define FZ_GEMM_GEGLU 1
+typedef struct FzGemmDesc {
+    int64_t rows;          /* rows of x (tokens) per batch element                     */
+    int64_t rows_store;    /* transpose_out: zero-padded row length (>= rows), else 0  */
+    int32_t in_features;
+    int32_t out_features;  /* rows of w (GEGLU: 2 * inner)                             */
+    int64_t ldx, ldw, ldy, ldres; /* row strides in elements (ldres 0: = ldy)          */
+    int32_t batch;         /* >= 1; w and bias are shared by the batch                 */
+    int32_t epilogue;      /* FZ_GEMM_*                                                */
+    int64_t x_batch_stride, y_batch_stride, res_batch_stride;
+    int32_t transpose_out;
+    int32_t tile_cfg;
+    int32_t split_k;
+    int32_t reserved0;
+    int64_t workspace_floats;
+} FzGemmDesc;
+int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch);
+int fz_gemm(const FzGemmDesc* desc, const void* x, const void* w, const void* bias, const void* res, const void* res2,
+            void* y, void* workspace, void* stream);
+
 /* 3x3 convolution (pad 1) of PseudoConv3d's spatial part (resnet.py:57-64) on token-major activations, as an MFMA
  * implicit GEMM with the elementwise tail fused: y = conv(x) + bias (+ temb[n / frames_per_batch]) (+ res).
  * x: [n][hi][wi][cin]; wt: weights packed [cout][3*3][cin]; y / res: [n][ho][wo][cout]; temb: n/frames_per_batch rows of
  * cout values, temb_stride elements apart.
  * stride 1 or 2; upsample != 0 reads x through a nearest-2x upsampling (UpsamplePseudo3D, resnet.py:145) without
- * materialising it.  cin % 32 == 0, cout % 8 == 0. */
+ * materialising it.  cin % 8 == 0 (MFMA path, any cout) or cin < 8 with cout % 8 == 0 (conv_in: direct convolution).
+ * workspace / workspace_floats / tile_cfg / split_k: as for fz_gemm (split-K is what fills the chip at the 16x16 and 8x8
+ * levels); workspace may be NULL. */
 int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
                void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
-               void* stream);
+               void* workspace, int64_t workspace_floats, int tile_cfg, int split_k, void* stream);
 
 /* Temporal k=3 convolution over the frame axis (the two Conv1d of LoRALinearLayer, lora.py:31-54, applied on
  * '(b h w) c f'): y[n][tok][co] = sum_{t=0..2, ci} x[n - f + (f+t-1)][tok][ci] * wt[co][t][ci] (+ res), zero padded at the

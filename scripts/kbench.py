@@ -26,13 +26,20 @@ def timeit(fn, iters=10, warm=3):
     return st.elapsed_time(en) / iters
 
 
-def conv_bench():
+CFGS = (2542, 2442, 2242, 2222, 2122)
+
+
+def conv_bench(sweep=True):
+    """fz_conv3x3 (csrc/igemm.hip) vs MIOpen's NHWC implicit GEMM on the 3x3 convolutions of the SD-1.x UNet at 8 / 16 frames.
+    `auto` = the library's own (tile, split-K) choice; with sweep=True every tile shape x split-K is timed as well so that
+    the choice heuristic (ig_choose) can be checked against the best measured configuration."""
     import torch.nn.functional as F
     dev = "cuda"
     res = {}
     shapes = [(8, 64, 320, 320, 1, False), (8, 64, 960, 320, 1, False), (8, 64, 640, 320, 1, False), (8, 32, 640, 640, 1, False),
               (8, 32, 1920, 640, 1, False), (8, 16, 1280, 1280, 1, False), (8, 16, 2560, 1280, 1, False), (8, 8, 1280, 1280, 1, False),
-              (8, 64, 320, 320, 2, False), (8, 32, 640, 640, 1, True), (16, 64, 320, 320, 1, False), (16, 16, 1280, 1280, 1, False)]
+              (8, 64, 320, 320, 2, False), (8, 32, 640, 640, 1, True), (16, 64, 320, 320, 1, False), (16, 16, 1280, 1280, 1, False),
+              (16, 8, 2560, 1280, 1, False), (16, 32, 640, 640, 1, False), (8, 64, 320, 4, 1, False), (8, 32, 320, 640, 1, False)]
     for (n, hw, cin, cout, stride, up) in shapes:
         x = torch.randn(n, hw * hw, cin).half().to(dev)
         w = (torch.randn(cout, cin, 3, 3) * 0.02).half().to(dev)
@@ -50,8 +57,80 @@ def conv_bench():
             return F.conv2d(xi, wcl, b, stride=stride, padding=1)
         ms_mi = timeit(mi)
         ms_fz = timeit(lambda: K.conv3x3(x, wt, b, hw=(hw, hw), stride=stride, upsample=up))
-        res[f"conv_n{n}_hw{hw}_{cin}to{cout}_s{stride}_u{int(up)}"] = {"miopen_ms": ms_mi, "fz_ms": ms_fz, "miopen_TF": flops / ms_mi / 1e9,
-                                                                    "fz_TF": flops / ms_fz / 1e9}
+        r = {"miopen_ms": ms_mi, "fz_ms": ms_fz, "miopen_TF": flops / ms_mi / 1e9, "fz_TF": flops / ms_fz / 1e9}
+        if sweep:
+            best = None
+            for cfg in CFGS:
+                for sk in (1, 2, 4, 8):
+                    if sk > 1 and n * ho * ho * cout > (1 << 23):
+                        continue
+                    try:
+                        ms = timeit(lambda: K.conv3x3(x, wt, b, hw=(hw, hw), stride=stride, upsample=up, tile_cfg=cfg, split_k=sk),
+                                    iters=5, warm=2)
+                    except RuntimeError:
+                        continue
+                    r[f"c{cfg}_k{sk}_TF"] = round(flops / ms / 1e9, 1)
+                    if best is None or ms < best[0]:
+                        best = (ms, cfg, sk)
+            r["best"] = {"cfg": best[1], "split_k": best[2], "TF": flops / best[0] / 1e9}
+        res[f"conv_n{n}_hw{hw}_{cin}to{cout}_s{stride}_u{int(up)}"] = r
+    print(json.dumps(res, indent=1))
+
+
+def gemm_bench(sweep=True):
+    """fz_gemm (csrc/igemm.hip) vs torch F.linear (hipBLASLt) on the projection shapes of the SD-1.x transformer blocks
+    (models/attention.py) at 8 (inversion) and 16 (edit) frames: rows = frames x tokens."""
+    import torch.nn.functional as F
+    dev, res = "cuda", {}
+    shapes = []
+    for frames in (8, 16):
+        for (tok, c) in ((4096, 320), (1024, 640), (256, 1280), (64, 1280)):
+            rows = frames * tok
+            shapes += [(rows, c, c, "plain"), (rows, c, 2 * c, "plain"), (rows, c, 3 * c, "plain"), (rows, c, c, "res"),
+                       (rows, c, 8 * c, "geglu"), (rows, 4 * c, c, "res")]
+    shapes += [(2, 1280, 22 * 640, "plain"), (154, 768, 320, "plain")]
+    for (rows, k, o, kind) in shapes:
+        x = torch.randn(rows, k).half().to(dev)
+        w = (torch.randn(o, k) * k ** -0.5).half().to(dev)
+        b = torch.randn(o).half().to(dev)
+        flops = 2.0 * rows * k * o
+        r = {}
+        if kind == "geglu":
+            wp, bp = K.pack_geglu(w, b)
+
+            def lib():
+                h = F.linear(x, w, b)
+                return K.geglu(h)
+            fz = lambda cfg=0: K.gemm(x, wp, bp, geglu=True, tile_cfg=cfg)
+        elif kind == "res":
+            rs = torch.randn(rows, o).half().to(dev)
+            lib = lambda: F.linear(x, w, b) + rs
+            fz = lambda cfg=0, sk=0: K.gemm(x, w, b, res=rs, tile_cfg=cfg, split_k=sk)
+        else:
+            lib = lambda: F.linear(x, w, b)
+            fz = lambda cfg=0, sk=0: K.gemm(x, w, b, tile_cfg=cfg, split_k=sk)
+        ms_lib = timeit(lib)
+        ms_fz = timeit(fz)
+        r.update({"lib_ms": ms_lib, "fz_ms": ms_fz, "lib_TF": flops / ms_lib / 1e9, "fz_TF": flops / ms_fz / 1e9})
+        if sweep:
+            best = None
+            for cfg in CFGS:
+                if kind == "geglu" and cfg in (2542, 2122):
+                    continue
+                ms = timeit(lambda: fz(cfg), iters=5, warm=2)
+                r[f"c{cfg}_TF"] = round(flops / ms / 1e9, 1)
+                if best is None or ms < best[0]:
+                    best = (ms, cfg)
+            r["best"] = {"cfg": best[1], "TF": flops / best[0] / 1e9}
+        res[f"gemm_{kind}_r{rows}_k{k}_o{o}"] = r
+    # the transposed-output form (V^T) against torch.matmul(Wv, x^T)
+    for (n, l, c) in ((8, 4096, 320), (16, 4096, 320), (8, 1024, 640), (16, 256, 1280)):
+        x = torch.randn(n, l, c).half().to(dev)
+        w = (torch.randn(c, c) * c ** -0.5).half().to(dev)
+        flops = 2.0 * n * l * c * c
+        ms_lib = timeit(lambda: torch.matmul(w, x.transpose(1, 2)))
+        ms_fz = timeit(lambda: K.gemm_vt(x, w, l))
+        res[f"gemm_vt_n{n}_l{l}_c{c}"] = {"lib_ms": ms_lib, "fz_ms": ms_fz, "lib_TF": flops / ms_lib / 1e9, "fz_TF": flops / ms_fz / 1e9}
     print(json.dumps(res, indent=1))
 
 
@@ -112,7 +191,9 @@ def main():
     if "--temporal" in sys.argv:
         return temporal_bench()
     if "--conv" in sys.argv:
-        return conv_bench()
+        return conv_bench(sweep="--nosweep" not in sys.argv)
+    if "--gemm" in sys.argv:
+        return gemm_bench(sweep="--nosweep" not in sys.argv)
     if "--tconv" in sys.argv:
         return tconv_bench()
     dev = "cuda"

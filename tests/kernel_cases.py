@@ -375,7 +375,8 @@ def case_blend_mask(device, *, prompts, frames, heads, res, out_hw, or_first, th
     return {"ones": frac}
 
 
-def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_temb=False, with_res=False, fpb=1, seed=0):
+def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_temb=False, with_res=False, fpb=1, seed=0,
+                 tile_cfg=0, split_k=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, h * w, cin, generator=g).half().to(device)
     wgt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
@@ -388,7 +389,8 @@ def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_t
     yr = F.conv2d(xi, wgt.float(), bias.float().cpu(), stride=stride, padding=1)
     ho, wo = yr.shape[2], yr.shape[3]
     res = torch.randn(n, ho * wo, cout, generator=g).half().to(device) if with_res else None
-    y, (ho2, wo2) = K.conv3x3(x, wt, bias, hw=(h, w), stride=stride, upsample=upsample, temb=temb, frames_per_batch=fpb, res=res)
+    y, (ho2, wo2) = K.conv3x3(x, wt, bias, hw=(h, w), stride=stride, upsample=upsample, temb=temb, frames_per_batch=fpb, res=res,
+                              tile_cfg=tile_cfg, split_k=split_k)
     assert (ho2, wo2) == (ho, wo)
     yr = yr.permute(0, 2, 3, 1).reshape(n, ho * wo, cout)
     if with_temb:
@@ -414,4 +416,51 @@ def case_temporal_conv3(device, *, batch, clip, tokens, cin, cout, with_res, see
         yr = yr + res.float().cpu()
     err = (y.float().cpu() - yr).abs().max().item()
     assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err}
+
+
+def case_gemm(device, *, rows, k, o, bias=True, n_res=0, geglu=False, ldx_extra=0, ldy_extra=0, tile_cfg=0, split_k=0, seed=0,
+              lead=None):
+    """fz_gemm vs fp32 torch: y = x @ w^T + bias (+ res) (+ res2), GEGLU epilogue, strided x / y views."""
+    g = torch.Generator().manual_seed(seed)
+    xfull = torch.randn(rows, k + ldx_extra, generator=g).half().to(device)
+    x = xfull[:, ldx_extra:] if ldx_extra else xfull
+    w = (torch.randn(o, k, generator=g) * k ** -0.5).half()
+    b = (torch.randn(o, generator=g) * 0.3).half() if bias else None
+    ow = o // 2 if geglu else o
+    res = [torch.randn(rows, ow, generator=g).half().to(device) for _ in range(n_res)]
+    ref = x.float().cpu() @ w.float().t()
+    if bias:
+        ref = ref + b.float()
+    if geglu:
+        ref = ref[:, :ow] * F.gelu(ref[:, ow:])
+        wd, bd = K.pack_geglu(w, b)
+    else:
+        wd, bd = w, b
+    for r in res:
+        ref = ref + r.float().cpu()
+    outfull = torch.full((rows, ow + ldy_extra), 7.0, dtype=torch.float16, device=device)
+    out = outfull[:, :ow] if ldy_extra else outfull
+    xin = x if lead is None else x.reshape(*lead, k)
+    y = K.gemm(xin, wd.to(device), None if bd is None else bd.to(device), res=res[0] if n_res > 0 else None,
+               res2=res[1] if n_res > 1 else None, out=out, geglu=geglu, tile_cfg=tile_cfg, split_k=split_k)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert torch.isfinite(y.float()).all()
+    assert err < 4e-3 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
+    if ldy_extra:
+        assert bool((outfull[:, ow:] == 7.0).all()), "wrote outside the output columns"
+    return {"max_err": err}
+
+
+def case_gemm_vt(device, *, n, l, k, c, lp, tile_cfg=0, seed=0):
+    """Transposed-output form: V^T[n][c][lp] = w @ x[n]^T with zero padding of columns [l, lp)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, l, k, generator=g).half().to(device)
+    w = (torch.randn(c, k, generator=g) * k ** -0.5).half()
+    out = torch.full((n, c, lp), 3.0, dtype=torch.float16, device=device)
+    K.gemm_vt(x, w.to(device), lp, out=out, tile_cfg=tile_cfg)
+    ref = torch.zeros(n, c, lp)
+    ref[:, :, :l] = (x.float().cpu() @ w.float().t()).transpose(1, 2)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, float(ref.abs().max())), err
     return {"max_err": err}

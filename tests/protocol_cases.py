@@ -36,8 +36,10 @@ def build(device, model_config, L=16, F=2, seed=3):
     ounet = O.OracleUNet(sd, O.UNetConfig(**TINY16, model_config=model_config))
     g = torch.Generator().manual_seed(seed)
     z0 = torch.randn(1, 4, F, L, L, generator=g)
-    emb_src = torch.randn(2, 77, 64, generator=g)
-    emb_tgt = emb_src + 0.5 * torch.randn(2, 77, 64, generator=g)
+    # (0.5: the procedural cross-attention weights are 2.5x He-scaled to make the maps peaky; unit-variance embeddings on
+    # top of that put single logits at +-20 and turn fp16 rounding of q.k into percent-level map differences)
+    emb_src = 0.5 * torch.randn(2, 77, 64, generator=g)
+    emb_tgt = emb_src + 0.25 * torch.randn(2, 77, 64, generator=g)
     return pipe, ounet, z0, emb_src, emb_tgt
 
 

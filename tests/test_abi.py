@@ -57,13 +57,14 @@ def test_descriptor_layouts_match_the_header():
     prog = r'''
 #include <stdio.h>
 #include "fatezero_hip.h"
-int main(){ printf("%zu %zu\n", sizeof(FzAttnSelfDesc), sizeof(FzAttnCrossDesc)); return 0; }
+int main(){ printf("%zu %zu %zu\n", sizeof(FzAttnSelfDesc), sizeof(FzAttnCrossDesc), sizeof(FzGemmDesc)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
         open(src, "w").write(prog)
         exe = os.path.join(d, "t")
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
-        a, b = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+        a, b, c = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
     assert int(a) == ctypes.sizeof(_native.FzAttnSelfDesc)
     assert int(b) == ctypes.sizeof(_native.FzAttnCrossDesc)
+    assert int(c) == ctypes.sizeof(_native.FzGemmDesc)

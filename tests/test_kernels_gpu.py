@@ -114,6 +114,52 @@ def test_conv3x3(kw):
     print(kw, r)
 
 
+@pytest.mark.parametrize("kw", [dict(n=8, h=64, w=64, cin=4, cout=320, with_temb=True, fpb=8),        # conv_in (direct)
+                                dict(n=8, h=64, w=64, cin=320, cout=4),                                # conv_out
+                                dict(n=8, h=16, w=16, cin=2560, cout=1280, with_temb=True, fpb=8),     # split-K territory
+                                dict(n=8, h=8, w=8, cin=1280, cout=1280, with_res=True),
+                                dict(n=16, h=8, w=8, cin=2560, cout=1280, with_temb=True, with_res=True, fpb=8)])
+def test_conv3x3_small_levels_and_ends(kw):
+    r = KC.case_conv3x3(DEV, **kw)
+    print(kw, r)
+
+
+@pytest.mark.parametrize("tile_cfg,split_k", [(2542, 1), (2442, 1), (2242, 1), (2222, 1), (2122, 1), (2222, 4), (2442, 2)])
+def test_conv3x3_every_tile_shape(tile_cfg, split_k):
+    KC.case_conv3x3(DEV, n=4, h=16, w=16, cin=640, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
+                    split_k=split_k)
+
+
+@pytest.mark.parametrize("rows,k,o,kw", [(32768, 320, 320, dict(n_res=1)), (32768, 320, 640, dict(bias=False)),
+                                         (65536, 320, 960, dict(bias=False)), (8192, 640, 640, dict(n_res=2)),
+                                         (8192, 2560, 640, dict(n_res=1)), (2048, 1280, 1280, dict()),
+                                         (4096, 5120, 1280, dict(n_res=1)), (512, 1280, 3840, dict(bias=False)),
+                                         (2, 1280, 14080, dict()), (154, 768, 1280, dict(bias=False)),
+                                         (1000, 320, 328, dict(n_res=1, ldx_extra=320, ldy_extra=8))])
+def test_gemm_sd_shapes(rows, k, o, kw):
+    r = KC.case_gemm(DEV, rows=rows, k=k, o=o, **kw)
+    print(rows, k, o, kw, r)
+
+
+@pytest.mark.parametrize("rows,k,o", [(32768, 320, 2560), (8192, 640, 5120), (2048, 1280, 10240), (300, 64, 256)])
+def test_gemm_geglu(rows, k, o):
+    r = KC.case_gemm(DEV, rows=rows, k=k, o=o, geglu=True)
+    print(rows, k, o, r)
+
+
+@pytest.mark.parametrize("tile_cfg", [2542, 2442, 2242, 2222, 2122])
+def test_gemm_every_tile_shape(tile_cfg):
+    KC.case_gemm(DEV, rows=3000, k=640, o=960, n_res=1, tile_cfg=tile_cfg)
+    KC.case_gemm(DEV, rows=520, k=1280, o=320, tile_cfg=tile_cfg, split_k=4)
+
+
+def test_gemm_transposed_output():
+    KC.case_gemm_vt(DEV, n=8, l=4096, k=320, c=320, lp=4096)
+    KC.case_gemm_vt(DEV, n=4, l=1024, k=640, c=640, lp=1024)
+    KC.case_gemm_vt(DEV, n=2, l=77, k=768, c=1280, lp=96)
+    KC.case_gemm_vt(DEV, n=3, l=1296, k=320, c=320, lp=1344)
+
+
 def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=320, cout=160, with_res=False)
     KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=160, cout=320, with_res=True)
