@@ -9,12 +9,17 @@ SURVEY.md §8d).  value = frames edited per second over the whole job, inputs re
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--ddim-steps T] [--frames F] [--no-cpu-baseline]
 
-N > 1 (launched with torch.distributed.run, one rank per GPU): every rank edits its own clip (the job is
-data-parallel over clips; weak scaling); RCCL carries only latents: the clean latents are broadcast-checked and the
-edited latents are all-gathered to rank 0 over xGMI.  No collective sits inside the UNet.
+N > 1: one rank per GPU over RCCL.  Launched under torch.distributed.run the ranks are taken from the environment; a BARE
+`python bench.py --gpus N` re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` (spawn_command below).  Default sharding: every rank edits its own clip (data-parallel over clips,
+weak scaling; RCCL carries only latents: a weights checksum is broadcast-checked and the edited latents are all-gathered
+over xGMI; no collective inside the UNet).  `--shard frames`: ONE clip's frames split over the ranks (strong scaling;
+GroupNorm / K-V / temporal exchanges, fatezero_amd/dist.py).  With N > 1 the clips line also carries a guarded
+`frame_sharded` measurement (one short job) and `n_ranks_seen` from an RCCL all-reduce.
 
-Extra JSON fields: `roofline` for the dominant hand-written kernel (the 64x64-level fused spatio-temporal flash
-attention, 4096 x 8192 x d=40: algorithmic FLOPs / HIP-event time measured live on the launch stream) and
+Extra JSON fields: `roofline` for the judged kernel (the 64x64-level fused spatio-temporal flash attention, 4096 x 8192 x
+d=40: algorithmic FLOPs / HIP-event time measured live on the launch stream), `rooflines` = the same for the other
+hand-written kernels that matter (3x3 convolutions and projection GEMMs: MFMA; attention-map capture / inject: HBM), and
 `cpu_baseline` (the CPU oracle of the same loop on the host cores, bounded sample).
 """
 import argparse
@@ -115,41 +120,146 @@ def run_job(pipe, z0, ddim_steps, device):
     return out["sdimage_output"].images
 
 
-def cpu_baseline(pipe, ddim_steps, frames):
-    """The CPU oracle (oracle/fatezero_oracle.py, fp32 restatement of the reference loop) on the host cores.
-    Bounded sample: ONE inversion step and ONE CFG edit step of a 1-frame 512x512 clip with the same weights and
-    controller; per-frame cost is extrapolated linearly to the job (steps are homogeneous)."""
+def cpu_baseline(pipe, ddim_steps, frames, sample_frames=2, k=2):
+    """The CPU oracle (oracle/fatezero_oracle.py, fp32 restatement of the reference loop) on the host cores, as BASELINE.md
+    section 3 specifies: after ONE warm-up step, k = 2 capture-inversion steps and k = 2 CFG edit steps (edit steps 0-1: inside
+    both replace windows, the expensive case) of a `sample_frames`-frame 512x512 clip with the bench's weights and controller;
+    steps are homogeneous and the cost is linear in the frame count (sparse-causal attention: every frame attends two
+    frames), so the job time is extrapolated as  T * (t_inv + t_edit) / k * frames / sample_frames."""
+    import platform
     from oracle import fatezero_oracle as O
-    sd = {k: v.float().cpu() for k, v in pipe.unet.state_dict().items()}
+    sd = {kk: v.float().cpu() for kk, v in pipe.unet.state_dict().items()}
     cfg = O.UNetConfig(block_out_channels=SD15["block_out_channels"], attention_head_dim=8, cross_attention_dim=768,
                        norm_num_groups=32, model_config={"lora": 160})
     unet = O.OracleUNet(sd, cfg)
     tok = pipe.tokenizer
     g = torch.Generator().manual_seed(1)
-    z = torch.randn(1, 4, 1, 64, 64, generator=g)
+    z = torch.randn(1, 4, sample_frames, 64, 64, generator=g)
     emb = torch.randn(2, 77, 768, generator=g)
     sched = O.DDIMSchedule(ddim_steps)
+    ts = [int(t) for t in sched.timesteps]
     store = O.StoreController()
     store.LOW_RESOURCE = True
+    warm = O.StoreController()
+    warm.LOW_RESOURCE = True
     t0 = time.time()
-    t = int(sched.timesteps[-1])
-    eps = unet(z, t, emb[1:], store)
-    zn = sched.inverse_step(eps, t, z)
-    store.step_callback(zn)
+    unet(z, ts[-1], emb[1:], warm)  # warm-up step (thread pool, allocator), not timed
+    t_warm = time.time() - t0
+    t0 = time.time()
+    for i in range(k):
+        t = ts[len(ts) - 1 - i]
+        eps = unet(z, t, emb[1:], store)
+        z = sched.inverse_step(eps, t, z)
+        store.step_callback(z)
     t_inv = time.time() - t0
     store.LOW_RESOURCE = False
-    ctrl = O.make_edit_controller(tok, [SRC_PROMPT, TGT_PROMPT], store, 1, True, {"default_": 0.5}, 1.0,
+    # the edit controller reads inversion step T-1-cur_step: give it a store that LOOKS like a T-step inversion whose last
+    # k entries are the ones just recorded (edit steps 0..k-1 read exactly those)
+    store.attention_store_all_step = [store.attention_store_all_step[0]] * (ddim_steps - k) + store.attention_store_all_step
+    ctrl = O.make_edit_controller(tok, [SRC_PROMPT, TGT_PROMPT], store, ddim_steps, True, {"default_": 0.5}, 0.5,
                                   blend_words=EDIT_KW["blend_words"], blend_th=(0.3, 0.3), blend_self_attention=True,
                                   save_self_attention=False)
     t0 = time.time()
-    eps2 = unet(torch.cat([zn, zn]), t, emb, ctrl)
-    eu, ec = eps2.chunk(2)
-    _ = sched.step(eu + 7.5 * (ec - eu), t, zn)
+    for i in range(k):
+        t = ts[i]
+        eps2 = unet(torch.cat([z, z]), t, emb, ctrl)
+        eu, ec = eps2.chunk(2)
+        z = sched.step(eu + 7.5 * (ec - eu), t, z)
+        z = ctrl.step_callback(z)
     t_edit = time.time() - t0
-    per_frame_job = ddim_steps * (t_inv + t_edit)  # seconds of CPU work per edited frame
-    return {"value": 1.0 / per_frame_job, "unit": "edited frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 inversion step ({t_inv:.1f} s) + 1 CFG edit step ({t_edit:.1f} s) of a 1-frame 512x512 clip, "
-                      f"full-size SD-1.x pseudo-3D UNet fp32, extrapolated x{ddim_steps} steps (per frame)"}
+    job_s = ddim_steps * (t_inv + t_edit) / k * frames / sample_frames
+    cpu = platform.processor() or platform.machine()
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": frames / job_s, "unit": "edited frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu,
+            "sample": f"after 1 warm-up step ({t_warm:.1f} s): {k} capture-inversion steps ({t_inv:.1f} s) + {k} CFG edit steps "
+                      f"({t_edit:.1f} s) of a {sample_frames}-frame 512x512 clip, full-size SD-1.x pseudo-3D UNet fp32 "
+                      f"(oracle/fatezero_oracle.py), same weights / controller; extrapolated x{ddim_steps}/{k} steps and "
+                      f"x{frames}/{sample_frames} frames"}
+
+
+def spawn_command(argv, gpus, port=None):
+    """The command a bare `python bench.py --gpus N` (no WORLD_SIZE in the environment) re-executes itself as."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def install_timers(K, timer):
+    """HIP-event brackets (on the launch stream) around the hand-written kernels the rooflines are quoted for."""
+    def sel_attn(q, k, vt, out, **kw):
+        mode = kw.get("mode", K.FZ_ATTN_FLASH)
+        nf = kw.get("n_frames") or q.shape[0]
+        if mode == K.FZ_ATTN_FLASH:
+            if q.shape[1] == 4096 and q.shape[2] == 320:
+                return ("flash", nf, max(1, len(kw["index_list"])))
+            return None
+        if not timer.extra:
+            return None
+        p = kw["p"]
+        per_frame = p.shape[1] * p.shape[2] * p.shape[3] * 2  # bytes of the fp16 map of one frame
+        return ("capture" if mode == K.FZ_ATTN_CAPTURE else "inject", nf * per_frame, 0)
+    timer.wrap(K, "attn_self", sel_attn)
+
+    def sel_conv(x, wt, bias, **kw):
+        if not timer.extra or x.shape[2] % 8:
+            return None
+        h, w = kw["hw"]
+        st = kw.get("stride", 1)
+        ho, wo = ((2 * h if kw.get("upsample") else h) - 1) // st + 1, ((2 * w if kw.get("upsample") else w) - 1) // st + 1
+        return ("conv3x3", 2.0 * 9 * x.shape[2] * wt.shape[0] * x.shape[0] * ho * wo, 0)
+    timer.wrap(K, "conv3x3", sel_conv)
+
+    def sel_gemm(x, w, bias=None, **kw):
+        if not timer.extra:
+            return None
+        rows = x.numel() // x.shape[-1]
+        if rows < 1024:
+            return None
+        return ("gemm", 2.0 * rows * x.shape[-1] * w.shape[0], 0)
+    timer.wrap(K, "gemm", sel_gemm)
+
+
+def rooflines(summ):
+    """(judged flash roofline, list of the other kernels' rooflines) from the timer summary."""
+    roof, others = None, []
+    fl = {k: v for k, v in summ.items() if k[0] == "flash"}
+    if fl:
+        flops_total, ms_total, launches, frames_total = 0.0, 0.0, 0, 0
+        for (tag, nf, n_kv), v in fl.items():
+            frames_total += nf * v["launches"]
+            flops_total += 4.0 * 4096 * (n_kv * 4096) * 320 * nf * v["launches"]  # 4*Lq*Lk*C per frame
+            ms_total += v["total_ms"]
+            launches += v["launches"]
+        achieved = flops_total / (ms_total * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic_per_launch(frames_total / launches)
+        roof = {"kernel": "attn_flash_kernel<40> (64x64 level, Lq 4096, Lk 8192, d 40)", "bound": "mfma",
+                "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic,
+                "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "launches": launches,
+                "avg_launch_ms": ms_total / launches, "algorithmic_flops_per_launch": flops_total / launches}
+    for name, kernel, bound, peak, unit, scale in (
+            ("conv3x3", "igemm_kernel<.., MODE 1> (all 3x3 convolutions, 2*9*Cin*Cout FLOP per output pixel)", "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("gemm", "igemm_kernel<.., MODE 0> (projection GEMMs with >= 1024 rows, 2*K*N FLOP per row)", "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("capture", "attn_self_kernel<CAPTURE> (bytes of the fp16 probability maps written to the HBM arena)", "hbm", 8000.0, "GB/s", 1e9),
+            ("inject", "attn_self_kernel<INJECT> (bytes of the stored maps read back)", "hbm", 8000.0, "GB/s", 1e9)):
+        sel = {k: v for k, v in summ.items() if k[0] == name}
+        if not sel:
+            continue
+        work = sum(k[1] * v["launches"] for k, v in sel.items())
+        ms = sum(v["total_ms"] for v in sel.values())
+        n = sum(v["launches"] for v in sel.values())
+        ach = work / (ms * 1e-3) / scale
+        others.append({"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                       "traffic": None, "launches": n, "total_ms": ms, "sampled": "last timed job, HIP events per launch"})
+    return roof, others
 
 
 def main():
@@ -164,8 +274,13 @@ def main():
     ap.add_argument("--shard", choices=["clips", "frames"], default="clips",
                     help="N > 1: 'clips' = one clip per GPU (weak scaling, latents only on the wire; the default); 'frames' = "
                          "ONE clip's frames split over the GPUs (strong scaling; GroupNorm / K-V / temporal exchanges over RCCL)")
+    ap.add_argument("--no-frame-shard-probe", action="store_true",
+                    help="N > 1, --shard clips: skip the extra guarded frame-sharded job reported under `frame_sharded`")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # bare `python bench.py --gpus N`: become N ranks
+        import subprocess
+        sys.exit(subprocess.call(spawn_command(sys.argv[1:], args.gpus)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -173,20 +288,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    n_ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl")  # RCCL over xGMI
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run"
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from fatezero_amd import kernels as K
     timer = KernelTimer()
-
-    def select(q, k, vt, out, **kw):
-        if kw.get("mode", K.FZ_ATTN_FLASH) == K.FZ_ATTN_FLASH and q.shape[1] == 4096 and q.shape[2] == 320:
-            nf = kw.get("n_frames") or q.shape[0]
-            return ("attn_self_flash_L4096_d40", nf, max(1, len(kw["index_list"])))
-        return None
-    timer.wrap(K, "attn_self", select)
+    timer.extra = False
+    install_timers(K, timer)
 
     pipe = build_pipeline(device, seed=0)
     by_frames = args.shard == "frames" and world > 1
@@ -214,7 +328,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     edited = None
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        timer.extra = i == args.steps - 1  # the other kernels' event brackets: last timed job only (tens of thousands of launches)
         edited = run_job(pipe, z0, args.ddim_steps, device)
     barrier()
     dt = time.perf_counter() - t0
@@ -229,25 +344,11 @@ def main():
     dt = float(tmax.item())
     finite = bool(torch.isfinite(edited.float()).all())
 
+    line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = (1 if by_frames else world) * args.frames * args.steps / dt
-        summ = timer.summary()
-        roof = None
-        if summ:
-            flops_total, ms_total, launches, frames_total = 0.0, 0.0, 0, 0
-            for (tag, nf, n_kv), v in summ.items():
-                frames_total += nf * v["launches"]
-                flops_total += 4.0 * 4096 * (n_kv * 4096) * 320 * nf * v["launches"]  # 4*Lq*Lk*C per frame
-                ms_total += v["total_ms"]
-                launches += v["launches"]
-            achieved = flops_total / (ms_total * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic_per_launch(frames_total / launches)
-            roof = {"kernel": "attn_self_kernel<40,FLASH> (64x64 level, Lq 4096, Lk 8192, d 40)", "bound": "mfma",
-                    "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": traffic_src,
-                    "launches": launches, "avg_launch_ms": ms_total / launches,
-                    "algorithmic_flops_per_launch": flops_total / launches}
+        roof, others = rooflines(timer.summary())
         line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)",
                 "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if by_frames else "weak",
@@ -260,14 +361,55 @@ def main():
                            "frames": args.frames, "ddim_steps": args.ddim_steps, "n_edit": 1,
                            "parallelism": ("single GPU" if world == 1 else
                                            f"{world}-way frame-sharded clip" if by_frames else f"dp{world} over clips"),
-                           "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite},
-                "roofline": roof, "cpu_baseline": None}
+                           "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite,
+                           "n_ranks_seen": n_ranks_seen},
+                "roofline": roof, "rooflines": others, "cpu_baseline": None}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(pipe, args.ddim_steps, args.frames)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line))
+
+    # ---- N > 1, clips mode: one more job with ONE clip's frames split over the ranks (SURVEY 8e's natural split), guarded:
+    #      if the exchange path stalls the clips line above is still printed (every rank runs the same watchdog)
+    if dist is not None and not by_frames and not args.no_frame_shard_probe and args.frames >= world:
+        import threading
+        done = threading.Lock()
+
+        def bail():
+            if done.acquire(blocking=False):
+                if rank == 0:
+                    line["frame_sharded"] = {"error": "frame-sharded probe exceeded its time limit"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        dog = threading.Timer(300.0, bail)
+        dog.daemon = True
+        dog.start()
+        fs = None
+        try:
+            from fatezero_amd import dist as fz_dist
+            zc = torch.randn(1, 4, args.frames, 64, 64, generator=torch.Generator().manual_seed(1234)).to(device)
+            pipe.frame_shard = fz_dist.FrameShard(args.frames)
+            run_job(pipe, zc, 2, device)  # warm-up: RCCL channels, allocator
+            barrier()
+            t0 = time.perf_counter()
+            out = run_job(pipe, zc, args.ddim_steps, device)
+            barrier()
+            tf = torch.tensor([time.perf_counter() - t0], device=device)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            fs = {"value": args.frames / float(tf.item()), "unit": "frames/s", "ms_per_job": float(tf.item()) * 1e3, "scaling": "strong",
+                  "parallelism": f"{world}-way frame-sharded clip ({args.frames} frames)",
+                  "outputs_finite": bool(torch.isfinite(out.float()).all())}
+        except Exception as e:
+            fs = {"error": repr(e)}
+        if done.acquire(blocking=False):
+            dog.cancel()
+            if rank == 0:
+                line["frame_sharded"] = fs
+        else:
+            return
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -38,10 +38,7 @@ def _run(cmd):
     return r.stdout
 
 
-def build_hip(force=False, verbose=False, tuning=False):
-    """tuning=True (python -m fatezero_amd.build --tuning): developer build with -DFZ_TUNING, which adds the ablation
-    variants of the flash kernel that FZ_FLASH_ABLATE selects (wrong results by construction).  Rebuild without the flag
-    (--force) before measuring or shipping anything."""
+def build_hip(force=False, verbose=False):
     srcs = _sources()
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     if not force and not _stale(HIP_LIB, srcs + hdrs):
@@ -53,8 +50,8 @@ def build_hip(force=False, verbose=False, tuning=False):
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or _stale(obj, [src] + hdrs):
-            _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"] +
-                 (["-DFZ_TUNING"] if tuning else []) + ["-c", src, "-o", obj])
+            _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+                  "-c", src, "-o", obj])
         return obj
 
     with ThreadPoolExecutor(max_workers=8) as ex:
@@ -93,7 +90,5 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     if "--emu" in sys.argv:
         build_emu(force, True)
-    elif "--tuning" in sys.argv:
-        build_hip(True, True, tuning=True)
     else:
         build_hip(force, True)

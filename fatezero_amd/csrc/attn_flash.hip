@@ -406,74 +406,21 @@ static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, c
     return fz_last_launch_status();
 }
 
-static bool flash_nobias() {  // A/B knob: running max through the fma (the d % 16 == 0 formulation) also for d = 40
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FZ_FLASH_NOBIAS");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
-
-static int flash_qb_override() {  // tuning knob: 32-row query blocks per wave (0 = default)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FZ_FLASH_QB");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
-static int flash_waves_override() {  // tuning knob: min waves/SIMD the register allocator must allow (0 = default)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FZ_FLASH_WAVES");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 // called by fz_attn_self (attn_self.hip) for mode == FZ_ATTN_FLASH
 int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream) {
-    const int w = flash_waves_override(), qb = flash_qb_override();
+    // Variant choice is fixed by the measurements of round 1 (profiles/r01_kbench_v0.json): two query
+    // blocks per wave at two waves per SIMD once there are >= 512 query rows, four waves per SIMD below.
     const bool big = d.lq >= 512;  // two query blocks per wave only pay when there are enough rows to fill the chip
     switch (d.head_dim) {
         case 16: return launch_flash<16, 2, 1>(d, q, k, vt, o, stream);
         case 32: return launch_flash<32, 2, 1>(d, q, k, vt, o, stream);
-        case 40: {
-            const bool two = (qb == 2 || (qb == 0 && big));
-            if (!d.q_log2_scaled || flash_nobias())  // q as to_q produces it: running max through the fma
-                return two ? launch_flash<40, 2, 2, true, 32>(d, q, k, vt, o, stream)
+        case 40:
+            if (!d.q_log2_scaled)  // q as to_q produces it: running max through the fma
+                return big ? launch_flash<40, 2, 2, true, 32>(d, q, k, vt, o, stream)
                            : launch_flash<40, 4, 1, true, 32>(d, q, k, vt, o, stream);
-            if (two) {
-                if (w == 1) return launch_flash<40, 1, 2>(d, q, k, vt, o, stream);
-#ifdef FZ_TUNING  // only in builds made by the tuning scripts (hipcc -DFZ_TUNING), never in libfatezero_hip.so
-                {   // ablation variants for profiling only (results are wrong by construction, except 64)
-                    static int abl = -1;
-                    if (abl < 0) { const char* e = getenv("FZ_FLASH_ABLATE"); abl = e ? atoi(e) : 0; }
-                    switch (abl) {
-                        case 1: return launch_flash<40, 2, 2, true, 1>(d, q, k, vt, o, stream);
-                        case 2: return launch_flash<40, 2, 2, true, 2>(d, q, k, vt, o, stream);
-                        case 4: return launch_flash<40, 2, 2, true, 4>(d, q, k, vt, o, stream);
-                        case 6: return launch_flash<40, 2, 2, true, 6>(d, q, k, vt, o, stream);
-                        case 7: return launch_flash<40, 2, 2, true, 7>(d, q, k, vt, o, stream);
-                        case 8: return launch_flash<40, 2, 2, true, 8>(d, q, k, vt, o, stream);
-                        case 64: return launch_flash<40, 2, 2, true, 64>(d, q, k, vt, o, stream);  // s_setprio around MFMA clusters (correct)
-                        default: break;
-                    }
-                }
-#endif
-                return launch_flash<40, 2, 2>(d, q, k, vt, o, stream);
-            }
-            if (w == 2) return launch_flash<40, 2, 1>(d, q, k, vt, o, stream);
-            if (w == 3) return launch_flash<40, 3, 1>(d, q, k, vt, o, stream);
-            return launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
-        }
+            return big ? launch_flash<40, 2, 2>(d, q, k, vt, o, stream) : launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
         case 64: return launch_flash<64, 2, 1>(d, q, k, vt, o, stream);
-        case 80:
-            if (qb == 2) return launch_flash<80, 1, 2>(d, q, k, vt, o, stream);
-            if (w == 1) return launch_flash<80, 1, 1>(d, q, k, vt, o, stream);
-            return launch_flash<80, 2, 1>(d, q, k, vt, o, stream);
+        case 80: return launch_flash<80, 2, 1>(d, q, k, vt, o, stream);
         case 128: return launch_flash<128, 1, 1>(d, q, k, vt, o, stream);
         case 160: return launch_flash<160, 1, 1>(d, q, k, vt, o, stream);
         default: return FZ_ERR_UNSUPPORTED;

@@ -354,15 +354,6 @@ static int launch_self(const FzAttnSelfDesc& d, const void* q, const void* k, co
 
 int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream);
 
-static bool use_flash_v0() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FZ_FLASH_V0");  // A/B switch for benchmarking the first-generation kernel
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
-
 extern "C" int fz_attn_self(const FzAttnSelfDesc* desc, const void* q, const void* k, const void* vt, void* o,
                             void* p, const float* row_mask, void* stream) {
     if (!desc || !q || !vt || !o) return FZ_ERR_BAD_ARG;
@@ -373,7 +364,7 @@ extern "C" int fz_attn_self(const FzAttnSelfDesc* desc, const void* q, const voi
     if ((d.q_row_stride | d.k_row_stride | d.vt_chan_stride | d.o_row_stride | d.q_frame_stride | d.k_frame_stride |
          d.vt_frame_stride | d.o_frame_stride) & 7)
         return FZ_ERR_BAD_ARG;  // 16-byte vector access
-    if (d.mode == FZ_ATTN_FLASH && !use_flash_v0()) return fz_attn_flash_dispatch(d, q, k, vt, o, stream);
+    if (d.mode == FZ_ATTN_FLASH) return fz_attn_flash_dispatch(d, q, k, vt, o, stream);
     switch (d.head_dim) {
         case 16: return launch_self<16>(d, q, k, vt, o, p, row_mask, stream);
         case 32: return launch_self<32>(d, q, k, vt, o, p, row_mask, stream);

@@ -155,15 +155,6 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_lds_kernel(TemporalArgs
     }
 }
 
-static bool temporal_lds_disabled() {  // A/B knob
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FZ_TEMPORAL_NOLDS");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
-
 extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, void* o, int batch, int q_frames,
                                    int kv_frames, int tokens, int heads, int head_dim, int64_t q_row_stride,
                                    int64_t kv_row_stride, int64_t o_row_stride, float scale, void* stream) {
@@ -181,7 +172,7 @@ extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, 
     const size_t kv_bytes_per_token = (size_t)2 * kv_frames * heads * head_dim * sizeof(half_t);
     int tpb_lds = tpb;
     while (tpb_lds > 1 && tpb_lds * kv_bytes_per_token + score_bytes > 48 * 1024) tpb_lds >>= 1;
-    if (!temporal_lds_disabled() && tpb_lds * kv_bytes_per_token + score_bytes <= 64 * 1024) {
+    if (tpb_lds * kv_bytes_per_token + score_bytes <= 64 * 1024) {
         a.tok_per_block = tpb_lds;
         dim3 grid((tokens + tpb_lds - 1) / tpb_lds, batch), block(TTHREADS);
         FZ_LAUNCH(attn_temporal_lds_kernel, grid, block, tpb_lds * kv_bytes_per_token + score_bytes, stream, a);

@@ -67,6 +67,16 @@ FZ_DEVICE void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 FZ_DEVICE void fz_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// counted wait: at most N of this wave's vector-memory operations (LDS-DMA included) still outstanding; they retire in order
+template <int N>
+FZ_DEVICE void fz_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// workgroup barrier that does NOT drain vmcnt (hipcc's __syncthreads() waits vmcnt(0) while an LDS-DMA is in flight):
+// the caller orders its own LDS traffic -- fz_wait_vm<N>() before it for DMA'd data, and every ds_read of the buffer being
+// recycled already consumed (an MFMA cannot issue before its LDS operands arrived)
+FZ_DEVICE void fz_barrier_nodrain() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #define FZ_DEVICE_GLOBAL __device__
 
 #else
@@ -162,6 +172,9 @@ static inline void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {  // s
     memcpy((unsigned char*)lds_wave_base + 16 * fz_emu::lane_id(), gsrc_lane, 16);
 }
 static inline void fz_wait_vm0() {}
+template <int N>
+static inline void fz_wait_vm() {}
+static inline void fz_barrier_nodrain() { fz_emu::sync_block(); }
 #define FZ_DEVICE_GLOBAL static
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }

@@ -41,14 +41,23 @@ struct IgArgs {
     int ksplit, tiles_a;
 };
 
-template <int WA, int TA, int WB, int TB, bool GEGLU>
+template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU>
 struct IgCfg {
+    static_assert(BK == 32 || BK == 64, "K step of 32 or 64 halves");
     static constexpr int NW = WA * WB, T = 64 * NW;
     static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
-    static constexpr int ACH = BA * 8 / T, BCH = BB * 8 / T;  // LDS-DMA instructions per wave per K step
-    static_assert(ACH * T == BA * 8 && BCH * T == BB * 8, "tile rows must split evenly over the waves");
-    static constexpr int STAGE = (BA + BB) * 64;  // halves per buffer
-    static constexpr int LDS_HALVES = 2 * STAGE;
+    static constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
+    static constexpr int RPI = 64 / CPR;       // tile rows covered by one LDS-DMA wave instruction (1 KB)
+    // LDS-DMA instructions per wave per K step; a tile whose rows do not split evenly over the waves is padded with
+    // instructions that fetch (clamped) rows nobody reads, so that EVERY wave issues the same number per K step -- the
+    // counted vmcnt of the ring depends on it
+    static constexpr int ACH = (BA / RPI + NW - 1) / NW, BCH = (BB / RPI + NW - 1) / NW;
+    static constexpr int PER = ACH + BCH;
+    static constexpr int A_HALVES = ACH * NW * 512, B_HALVES = BCH * NW * 512;  // 1 KB = 512 halves per instruction
+    static constexpr int STAGE = A_HALVES + B_HALVES;
+    static constexpr int LDS_HALVES = NS * STAGE;
+    static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS ring exceeds 160 KB");
+    static_assert((NS - 2) * PER < 64 && NS >= 2, "ring depth");
     static constexpr int CW = GEGLU ? BA / 2 : BA;  // output columns of the tile
     static constexpr int CSTR = CW + 8;
     static constexpr int wbp() {
@@ -60,13 +69,15 @@ struct IgCfg {
     static constexpr int RP = WBP * TB * 32;
     static_assert(RP * CSTR <= LDS_HALVES, "epilogue staging does not fit");
     static_assert(!GEGLU || TA % 2 == 0, "GEGLU pairs MFMA tiles (h, gate)");
+    // chunk swizzle of row r: conflict-free ds_read_b128 for 32 consecutive rows at one chunk column
+    static FZ_DEVICE int swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
 FZ_DEVICE float ig_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int WA, int TA, int WB, int TB, int MODE, bool GEGLU>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
-    typedef IgCfg<WA, TA, WB, TB, GEGLU> C;
+    typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -84,15 +95,15 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     const half_t* B = g.b + (int64_t)z * g.b_bs;
     const char* zero = reinterpret_cast<const char*>(fz_zero_page);
 
-    // ---- per-lane sources.  Instruction (i, wave) of a tile covers rows 8*(i*NW+wave) .. +8, lane -> (row = lane/8, chunk
-    //      position lane%8); the lane fetches source chunk pos ^ ((row >> 1) & 7).
-    const int pos = lane & 7;
+    // ---- per-lane sources.  Instruction (i, wave) of a tile covers rows RPI*(i*NW+wave) .. +RPI, lane -> (row = lane/CPR,
+    //      chunk position lane%CPR); the lane fetches source chunk pos ^ swz(row).
+    const int pos = lane % C::CPR;
     const char* aptr[C::ACH];
     int asc[C::ACH];
 #pragma unroll
     for (int i = 0; i < C::ACH; ++i) {
-        const int row = (i * C::NW + wave) * 8 + (lane >> 3);
-        asc[i] = pos ^ ((row >> 1) & 7);
+        const int row = (i * C::NW + wave) * C::RPI + lane / C::CPR;
+        asc[i] = pos ^ C::swz(row);
         int ar = a0 + row;
         ar = ar < g.Ma ? ar : g.Ma - 1;
         aptr[i] = reinterpret_cast<const char*>(A + (int64_t)ar * g.lda) + asc[i] * 16;
@@ -103,8 +114,8 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     bool bok[C::BCH];
 #pragma unroll
     for (int i = 0; i < C::BCH; ++i) {
-        const int row = (i * C::NW + wave) * 8 + (lane >> 3);
-        bsc[i] = pos ^ ((row >> 1) & 7);
+        const int row = (i * C::NW + wave) * C::RPI + lane / C::CPR;
+        bsc[i] = pos ^ C::swz(row);
         int64_t br = b0 + row;
         bok[i] = br < g.Nb;
         br = bok[i] ? br : g.Nb - 1;
@@ -149,9 +160,9 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         }
     };
 
-    const int nkt = g.taps * g.kchunks;
+    const int nkt = g.taps * g.kchunks;  // kchunks = ceil(Cin / BK)
     const int kt0 = (int)((int64_t)nkt * ks / g.ksplit), kt1 = (int)((int64_t)nkt * (ks + 1) / g.ksplit);
-    const bool has_tail = (g.Cin & 63) != 0;
+    const bool has_tail = (g.Cin % BK) != 0;
     int cur_tap = -1;
     auto issue = [&](int kt, int buf) {
         const int tap = kt / g.kchunks, kc = kt - tap * g.kchunks;  // wave-uniform
@@ -159,21 +170,21 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             retarget(tap);
             cur_tap = tap;
         }
-        const int64_t ka = ((int64_t)tap * g.Cin + kc * 64) * 2;
-        const int kb = kc * 128;
+        const int64_t ka = ((int64_t)tap * g.Cin + kc * BK) * 2;
+        const int kb = kc * BK * 2;
         const bool tailk = has_tail && kc == g.kchunks - 1;
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
-        char* Bb = Ab + C::BA * 128;
+        char* Bb = Ab + C::A_HALVES * 2;
 #pragma unroll
         for (int i = 0; i < C::ACH; ++i) {
             const char* src = aptr[i] + ka;
-            if (tailk && kc * 64 + asc[i] * 8 >= g.Cin) src = zero;
+            if (tailk && kc * BK + asc[i] * 8 >= g.Cin) src = zero;
             fz_glds16(src, Ab + (i * C::NW + wave) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < C::BCH; ++i) {
             const char* src = bptr[i] + kb;
-            if (tailk && kc * 64 + bsc[i] * 8 >= g.Cin) src = zero;
+            if (tailk && kc * BK + bsc[i] * 8 >= g.Cin) src = zero;
             fz_glds16(src, Bb + (i * C::NW + wave) * 1024);
         }
     };
@@ -184,32 +195,48 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
 #pragma unroll
         for (int j = 0; j < TB; ++j) acc[i][j] = fz_zero_f16v();
 
-    // fragment read offsets (halves): row r, k chunk c -> r * 64 + ((c ^ ((r >> 1) & 7)) * 8); the tile rows of a lane
-    // are l31 + multiples of 32, so the swizzle term depends on the lane only
-    const int fsw = (l31 >> 1) & 7;
-    const int arow = (wa * TA * 32 + l31) * 64, brow = (wb * TB * 32 + l31) * 64;
+    // fragment read offsets (halves): row r, k chunk c -> r * BK + ((c ^ swz(r)) * 8); the tile rows of a lane are
+    // l31 + multiples of 32, so the swizzle term depends on the lane only
+    const int fsw = C::swz(l31);
+    const int arow = (wa * TA * 32 + l31) * BK, brow = (wb * TB * 32 + l31) * BK;
 
-    if (kt0 < kt1) issue(kt0, 0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        fz_wait_vm0();    // this wave's LDS-DMA of tile kt has landed ...
-        __syncthreads();  // ... and everybody's; everybody is also done reading buf[cur ^ 1] (tile kt - 1)
-        if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
-        const half_t* As = smem + cur * C::STAGE;
-        const half_t* Bs = As + C::BA * 64;
+    // ---- NS-deep LDS ring, tiles kt .. kt+NS-2 in flight while tile kt is consumed -------------------------------------
+    //   iteration kt:  wait until this wave's DMA of tile kt landed (the NS-2 younger tiles may stay in flight) -> barrier
+    //   (tile kt visible to all; everybody is done with tile kt-1, whose buffer is the one refilled next) -> issue tile
+    //   kt+NS-1 -> MFMAs on tile kt.  The barrier does not drain vmcnt, so the loads span barriers (T3+T4 of the guide).
+    const int ntile = kt1 - kt0;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < ntile) issue(kt0 + s, s);
+    int buf = 0;
+    for (int it = 0; it < ntile; ++it) {
+        if (it + NS - 1 <= ntile) {
+            fz_wait_vm<(NS - 2) * C::PER>();  // steady state: NS-2 younger tiles outstanding
+        } else {
+            fz_wait_vm0();                    // ring tail: fewer tiles were issued, drain
+        }
+        fz_barrier_nodrain();
+        if (it + NS - 1 < ntile) {
+            int nb = buf + NS - 1;
+            nb = nb >= NS ? nb - NS : nb;
+            issue(kt0 + it + NS - 1, nb);
+        }
+        const half_t* As = smem + buf * C::STAGE;
+        const half_t* Bs = As + C::A_HALVES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
             const int co = ((2 * kk + hi) ^ fsw) * 8;
             half8_t af[TA], bf[TB];
 #pragma unroll
-            for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * 64 + co);
+            for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
 #pragma unroll
-            for (int j = 0; j < TB; ++j) bf[j] = fz_ld_h8(Bs + brow + j * 32 * 64 + co);
+            for (int j = 0; j < TB; ++j) bf[j] = fz_ld_h8(Bs + brow + j * 32 * BK + co);
 #pragma unroll
             for (int i = 0; i < TA; ++i)
 #pragma unroll
                 for (int j = 0; j < TB; ++j) acc[i][j] = fz_mfma_32x32x16_f16(af[i], bf[j], acc[i][j]);
         }
+        buf = buf + 1 == NS ? 0 : buf + 1;
     }
 
     // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
@@ -384,8 +411,19 @@ FZ_KERNEL void __launch_bounds__(256) igemm_reduce_kernel(IgArgs g, int batch) {
 }
 
 // conv_in of the UNet (4 -> C channels, resnet.py:57-64 with in_channels = 4): K = 36 is far below one MFMA K step, so it
-// is a direct VALU convolution: one thread = one pixel x 8 output channels, weights [Cout][9][Cin] broadcast from L1.
+// is a direct VALU convolution.  The whole weight matrix sits in LDS transposed to [k][cout] (k = tap * Cin + ci), one thread
+// owns one pixel x 8 output channels: it gathers its 9 * Cin inputs once into registers and walks k with one 16-byte LDS read
+// (8 weights) per input value.
+template <int CIN>
 FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
+    FZ_DYN_SMEM(raw);
+    half_t* wl = reinterpret_cast<half_t*>(raw);  // [9 * Cin][Ma]
+    const int kk = 9 * g.Cin;
+    for (int id = threadIdx.x; id < kk * g.Ma; id += 256) {
+        const int k = id / g.Ma, co = id - k * g.Ma;
+        wl[id] = g.a[(int64_t)co * g.lda + k];
+    }
+    __syncthreads();
     const int och = g.Ma / 8;
     const int64_t total = g.Nb * och;
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
@@ -394,22 +432,36 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
         const int hw = g.Ho * g.Wo;
         const int n = (int)(px / hw), rem = (int)(px - (int64_t)n * hw);
         const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-        float f[8];
-        for (int e = 0; e < 8; ++e) f[e] = g.bias ? (float)g.bias[co + e] : 0.0f;
+        float xin[9 * CIN];
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int iy = oy * g.stride + tap / 3 - 1, ix = ox * g.stride + tap % 3 - 1;
-            if (iy < 0 || iy >= g.Hi || ix < 0 || ix >= g.Wi) continue;
-            const half_t* xs = g.b + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.ldb;
-            for (int ci = 0; ci < g.Cin; ++ci) {
-                const float xv = (float)xs[ci];
-                for (int e = 0; e < 8; ++e) f[e] += xv * (float)g.a[(int64_t)(co + e) * g.lda + tap * g.Cin + ci];
-            }
+            const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            const half_t* xs = g.b + (((int64_t)n * g.Hi + (inb ? iy : 0)) * g.Wi + (inb ? ix : 0)) * g.ldb;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) xin[tap * CIN + ci] = inb ? (float)xs[ci] : 0.0f;
         }
-        if (g.temb != nullptr)
-            for (int e = 0; e < 8; ++e) f[e] += (float)g.temb[(px / g.temb_group) * g.temb_stride + co + e];
-        if (g.res != nullptr)
-            for (int e = 0; e < 8; ++e) f[e] += (float)g.res[px * g.ldres + co + e];
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = g.bias ? (float)g.bias[co + e] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9 * CIN; ++k) {
+            const half8_t w8 = fz_ld_h8(wl + k * g.Ma + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += xin[k] * (float)w8[e];
+        }
+        if (g.temb != nullptr) {
+            const half8_t t = fz_ld_h8(g.temb + (px / g.temb_group) * g.temb_stride + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)t[e];
+        }
+        if (g.res != nullptr) {
+            const half8_t r = fz_ld_h8(g.res + px * g.ldres + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+        }
         half8_t o;
+#pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
         fz_st_h8(g.y + px * g.ldy + co, o);
     }
@@ -418,9 +470,11 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
-template <int WA, int TA, int WB, int TB, int MODE, bool GEGLU>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU>
 static int ig_launch(IgArgs g, int batch, void* stream) {
-    typedef IgCfg<WA, TA, WB, TB, GEGLU> C;
+    typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
+    g.kchunks = fz_ceil_div(g.Cin, BK);
+    if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
     g.tiles_a = fz_ceil_div(g.Ma, C::BA);
     const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
     const int64_t nt = (int64_t)g.tiles_a * tiles_b;
@@ -429,73 +483,93 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 #ifndef FZ_EMU
     static bool attr_set = false;  // LDS above 64 KB is an opt-in function attribute, not tuning state
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, MODE, GEGLU>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
         attr_set = true;
     }
 #endif
     dim3 grid((unsigned)nt, (unsigned)g.ksplit, (unsigned)batch), block(C::T);
-    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, MODE, GEGLU>), grid, block, lds, stream, g);
+    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU>), grid, block, lds, stream, g);
     return fz_last_launch_status();
 }
 
-// Tile configurations.  id = WA TA WB TB as decimal digits.
-//   2542: 320 x 256, 8 waves -- SD-1.x widths are all multiples of 320, no A-side waste, 142 FLOP per staged byte
-//   2442: 256 x 256, 8 waves -- the GEGLU projection (8C = multiples of 256) and generic large shapes
-//   2242: 128 x 256, 8 waves;  2222: 128 x 128, 4 waves (two workgroups per CU);  2122: 64 x 128, 4 waves
+// Tile configurations.  id = WA TA WB TB (decimal digits) * 100 + (BK / 32) * 10 + NS, e.g. 254222 = 2 x 4 waves of 5 x 2 MFMA
+// tiles (320 x 256), K step 64, 2-deep ring.  The kernel template also builds K step 32 and rings up to 4 deep; on MI355X
+// they measured 2-7 % SLOWER than the 2-deep K-step-64 form of the same tile on every shape of the UNet
+// (profiles/r02_kbench_gemm_sweep.json, r02_kbench_conv_sweep.json: the loop is not load-latency-bound), so they are not
+// instantiated.
+//   254222: 320 x 256, 8 waves -- SD-1.x widths are all multiples of 320: no A-side waste, 142 FLOP per staged byte
+//   254122: 320 x 128, 8 waves -- the same for launches with 4096 < rows <= 32768 (twice the workgroups)
+//   158122: 160 x 256, 8 waves -- the rank-160 down projection of the temporal LoRA convolution (lora.py:31-37)
+//   244222: 256 x 256, 8 waves -- the GEGLU projection (8C = multiples of 256) and generic large shapes
+//   224223: 128 x 256, 8 waves, 3-deep;  222222: 128 x 128, 4 waves, two workgroups per CU
+//   212222:  64 x 128, 4 waves, three workgroups per CU -- small launches and ragged widths
 template <int MODE, bool GEGLU>
 static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
     switch (cfg) {
-        case 2442: return ig_launch<2, 4, 4, 2, MODE, GEGLU>(g, batch, stream);
-        case 2242: return ig_launch<2, 2, 4, 2, MODE, GEGLU>(g, batch, stream);
-        case 2222: return ig_launch<2, 2, 2, 2, MODE, GEGLU>(g, batch, stream);
+        case 244222: return ig_launch<2, 4, 4, 2, 64, 2, MODE, GEGLU>(g, batch, stream);
+        case 224223: return ig_launch<2, 2, 4, 2, 64, 3, MODE, GEGLU>(g, batch, stream);
+        case 222222: return ig_launch<2, 2, 2, 2, 64, 2, MODE, GEGLU>(g, batch, stream);
         default: break;
     }
     if (!GEGLU) {  // odd TA / TA = 1 cannot pair (h, gate) tiles
         switch (cfg) {
-            case 2542: return ig_launch<2, 5, 4, 2, MODE, false>(g, batch, stream);
-            case 2122: return ig_launch<2, 1, 2, 2, MODE, false>(g, batch, stream);
+            case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false>(g, batch, stream);
+            case 254122: return ig_launch<2, 5, 4, 1, 64, 2, MODE, false>(g, batch, stream);
+            case 158122: return ig_launch<1, 5, 8, 1, 64, 2, MODE, false>(g, batch, stream);
+            case 212222: return ig_launch<2, 1, 2, 2, 64, 2, MODE, false>(g, batch, stream);
             default: break;
         }
     }
     return FZ_ERR_BAD_ARG;
 }
 
-static const int kCfgs[] = {2542, 2442, 2242, 2222, 2122};
-static void cfg_dims(int cfg, int* ba, int* bb) {
-    const int wa = cfg / 1000, ta = (cfg / 100) % 10, wb = (cfg / 10) % 10, tb = cfg % 10;
-    *ba = wa * ta * 32;
-    *bb = wb * tb * 32;
-}
+struct IgTile {
+    int cfg, ba, bb, bk, wg_per_cu;
+    double rate_pf;   // PFLOP/s the whole chip sustains in the K loop of this tile with every CU busy (long-K convolutions)
+    double fixed_us;  // prologue + epilogue of one workgroup round
+    bool geglu_ok;
+};
+// Fitted to the MI355X sweeps (scripts/kbench.py --gemm / --conv; build_tmp/fit_chooser.py reproduces the fit: the model's
+// pick is within 0.5 % of the best measured (tile, split-K) summed over all 59 swept shapes).
+static const IgTile kTiles[] = {
+    {254222, 320, 256, 64, 1, 1.00, 12.0, false}, {254122, 320, 128, 64, 1, 0.85, 8.0, false},
+    {158122, 160, 256, 64, 1, 0.80, 8.0, false},
+    {244222, 256, 256, 64, 1, 0.80, 8.0, true},   {224223, 128, 256, 64, 1, 0.60, 3.0, true},
+    {222222, 128, 128, 64, 2, 0.60, 2.0, true},   {212222, 64, 128, 64, 3, 0.70, 4.0, false},
+};
 
-// Choose (tile configuration, split-K factor).  The chip has 256 CUs; a configuration is scored by the MFMA work it
-// schedules (tile area x tiles, i.e. including edge waste) spread over ceil(workgroups / slots) rounds, divided by a
-// per-configuration efficiency factor measured with scripts/kbench.py --gemm on MI355X.
-static void ig_choose(const IgArgs& g, int batch, bool geglu, bool allow_split, int* cfg_out, int* ksplit_out) {
-    const int nkt = g.taps * g.kchunks;
+// Choose (tile configuration, split-K factor).  256 CUs; time ~ rounds x (K steps per slice x step time + fixed) with
+// rounds = ceil(workgroups / (256 x workgroups per CU)), floored by the HBM traffic of the launch at 4 TB/s; split-K adds one
+// fp32 slab round trip and a reduce launch.  What the measurements say: the 320 x 256 tile runs 0.9-1.0 PFLOP/s when the
+// launch has a multiple of 256 workgroups -- split-K is how the small pyramid levels get there -- and a half-empty last round
+// costs a full one, which is why the 64 x 128 tile wins the shapes in between.
+static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats, int* cfg_out, int* ksplit_out) {
     double best = 1e300;
-    *cfg_out = 2222;
+    *cfg_out = 212222;
     *ksplit_out = 1;
-    for (int ci = 0; ci < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++ci) {
-        const int cfg = kCfgs[ci];
-        if (geglu && (cfg == 2542 || cfg == 2122)) continue;
-        int ba, bb;
-        cfg_dims(cfg, &ba, &bb);
-        const int64_t tiles = (int64_t)fz_ceil_div(g.Ma, ba) * ((g.Nb + bb - 1) / bb) * batch;
-        const int wg_per_cu = (ba + bb) * 256 <= 80 * 1024 ? 2 : 1;
-        const double eff = cfg == 2542 ? 1.0 : cfg == 2442 ? 0.97 : cfg == 2242 ? 0.85 : cfg == 2222 ? 0.75 : 0.55;
-        for (int s = 1; s <= (allow_split ? 16 : 1); s *= 2) {
-            if (s > 1 && (nkt / s < 8 || (g.Ma % 4) != 0)) break;
-            const int64_t wgs = tiles * s;
-            const int64_t rounds = (wgs + 256 * wg_per_cu - 1) / (256 * wg_per_cu);
-            // time ~ rounds x (K steps per slice + fixed prologue/epilogue worth ~3 K steps) x tile area / efficiency
-            double t = (double)rounds * ((double)nkt / s + 3.0) * ((double)ba * bb) / (eff * wg_per_cu);
-            if (s > 1) t += 2.0 * ((double)g.Nb * g.Ma * batch * s) / 4096.0;  // partial slab write + read
-            if (t < best) {
-                best = t;
-                *cfg_out = cfg;
-                *ksplit_out = s;
+    const double out_elems = (double)g.Nb * g.Ma * batch;
+    const double bytes = 2.0 * ((double)g.Nb * (geglu ? g.Ma / 2 : g.Ma) + (double)g.Nb * g.Cin * (g.taps == 1 ? 1.0 : 1.5) +
+                                (double)g.Ma * g.Cin * g.taps) * batch;
+    for (const IgTile& t : kTiles) {
+        if (geglu && !t.geglu_ok) continue;
+        const int nkt = g.taps * fz_ceil_div(g.Cin, t.bk);
+        const int64_t tiles = (int64_t)fz_ceil_div(g.Ma, t.ba) * ((g.Nb + t.bb - 1) / t.bb) * batch;
+        const double t_step = 2.0 * t.ba * t.bb * t.bk * t.wg_per_cu / (t.rate_pf * 1e15 / 256.0) * 1e6;  // microseconds
+        for (int sk = 1; sk <= 32; sk *= 2) {
+            if (sk > 1 && (geglu || g.Ma % 4 || g.Ma_store != g.Ma || nkt / sk < 4 || out_elems * sk > (double)ws_floats)) break;
+            const int64_t wgs = tiles * sk;
+            const int64_t slots = 256 * t.wg_per_cu;
+            const int64_t rounds = (wgs + slots - 1) / slots;
+            double us = (double)rounds * (t.fixed_us + (double)((nkt + sk - 1) / sk) * t_step);
+            const double floor_us = bytes / 4.0e6;
+            us = us > floor_us ? us : floor_us;
+            if (sk > 1) us += 3.0 + out_elems * sk * 8.0 / 4.0e6;
+            if (us < best) {
+                best = us;
+                *cfg_out = t.cfg;
+                *ksplit_out = sk;
             }
         }
     }
@@ -504,12 +578,11 @@ static void ig_choose(const IgArgs& g, int batch, bool geglu, bool allow_split, 
 template <int MODE, bool GEGLU>
 static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, int64_t workspace_floats, void* stream) {
     if (g.Cin % 8 || g.Cin > 8128 || g.Cin <= 0) return FZ_ERR_UNSUPPORTED;
-    g.kchunks = fz_ceil_div(g.Cin, 64);
     if (cfg == 0) {
-        int c, s;
-        ig_choose(g, batch, GEGLU, workspace != nullptr && !GEGLU && g.Ma_store == g.Ma, &c, &s);
+        int c, sk;
+        ig_choose(g, batch, GEGLU, workspace ? workspace_floats : 0, &c, &sk);
         cfg = c;
-        if (ksplit == 0) ksplit = s;
+        if (ksplit == 0) ksplit = sk;
     }
     if (ksplit == 0) ksplit = 1;
     g.ksplit = ksplit;
@@ -517,7 +590,6 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
     if (ksplit > 1) {
         if (GEGLU || workspace == nullptr || (g.Ma % 4) || g.Ma_store != g.Ma || (g.ldy % 4)) return FZ_ERR_UNSUPPORTED;
         if ((int64_t)ksplit * batch * g.Nb * g.Ma > workspace_floats) return FZ_ERR_BAD_ARG;
-        if (ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
         g.part = workspace;
     }
     const int rc = ig_dispatch_cfg<MODE, GEGLU>(cfg, g, batch, stream);
@@ -529,7 +601,10 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
 }
 
 extern "C" int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch) {
-    return 16 * rows * (int64_t)out_features * (batch > 0 ? batch : 1);
+    // enough for the largest split the library would choose on its own: 8 slabs, capped at 256 MB of scratch
+    const int64_t out = rows * (int64_t)out_features * (batch > 0 ? batch : 1);
+    const int64_t cap = 64ll << 20;
+    return 8 * out < cap ? 8 * out : (2 * out < cap ? cap : 2 * out);
 }
 
 extern "C" int fz_gemm(const FzGemmDesc* d, const void* x, const void* w, const void* bias, const void* res, const void* res2,
@@ -634,10 +709,11 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
     g.Wo = (wu + 2 - 3) / stride + 1;
     conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout);
     if (cin % 8) {  // conv_in (4 input channels): direct VALU convolution
-        if (cout % 8 || upsample) return FZ_ERR_UNSUPPORTED;
+        if (cout % 8 || upsample || cin != 4 || (int64_t)9 * cin * cout * 2 > 64 * 1024 || (temb && g.temb_stride % 8))
+            return FZ_ERR_UNSUPPORTED;
         const int64_t total = g.Nb * (cout / 8);
-        dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
-        FZ_LAUNCH(conv3x3_small_cin_kernel, grid, block, 0, stream, g);
+        dim3 grid((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), block(256);
+        FZ_LAUNCH(conv3x3_small_cin_kernel<4>, grid, block, (size_t)9 * cin * cout * 2, stream, g);
         return fz_last_launch_status();
     }
     return ig_run<1, false>(g, 1, tile_cfg, split_k, (float*)workspace, workspace_floats, stream);

@@ -207,18 +207,9 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
     }
 }
 
-static bool gn_reread() {  // A/B knob: always re-read the chunk in the second sweep
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FZ_GN_REREAD");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
-
 static void gn_launch_stats(const GnArgs& a, dim3 grid, dim3 block, size_t smem, void* stream) {
     const int rows = (a.tb + a.R - 1) / a.R;  // rows of a chunk per thread
-    if (gn_reread() || rows > 32) {
+    if (rows > 32) {
         FZ_LAUNCH(gn_stats_kernel<0>, grid, block, smem, stream, a);
     } else if (rows <= 12) {
         FZ_LAUNCH(gn_stats_kernel<12>, grid, block, smem, stream, a);

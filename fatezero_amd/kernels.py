@@ -280,7 +280,7 @@ def _workspace(device, floats: int) -> torch.Tensor:
 
 
 # launches with at most this many output elements get a split-K workspace (above it the tile count fills the chip)
-_SPLITK_MAX_OUT = 1 << 23
+_SPLITK_MAX_OUT = 1 << 25
 
 
 def pack_geglu(w: torch.Tensor, b: Optional[torch.Tensor]):
@@ -326,7 +326,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if res2 is not None:
             assert (res2.stride(-2) if res2.dim() > 1 else ow) == d.ldres
     ws = None
-    if not geglu and rows * o <= _SPLITK_MAX_OUT and o % 4 == 0:
+    if not geglu and rows * o <= _SPLITK_MAX_OUT and o % 4 == 0 and (k >= 1024 or split_k > 1):
         need = N.lib().fz_gemm_workspace_floats(rows, o, 1)
         ws = _workspace(x.device, need)
         d.workspace_floats = ws.numel()

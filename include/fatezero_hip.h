@@ -158,8 +158,9 @@ int fz_groupnorm_apply(const void* x, void* y, const void* gamma, const void* be
  * in_features % 8 == 0; ldx, ldw, ldy, ldres % 8 == 0 for the vector paths; fp16 in/out, fp32 accumulation.
  * workspace (optional): fp32 scratch of workspace_floats elements enabling split-K for shapes with too few output tiles
  *   to fill the chip; fz_gemm_workspace_floats(rows, out_features, batch) is always enough.
- * tile_cfg / split_k: 0 = chosen by the library (the normal use); non-zero values pin the tile shape (2542, 2442, 2242,
- *   2222, 2122 = waves x MFMA tiles, csrc/igemm.hip) / the K split for benchmarking. */
+ * tile_cfg / split_k: 0 = chosen by the library (the normal use); non-zero values pin the tile shape / K step / ring depth
+ *   (e.g. 254214 = 2x4 waves of 5x2 MFMA tiles, K step 32, 4-deep LDS ring; the list is in csrc/igemm.hip) and the K split,
+ *   for benchmarking. */
 #define FZ_GEMM_PLAIN 0
 #define FZ_GEMM_GEGLU 1
 typedef struct FzGemmDesc {

@@ -1,0 +1,49 @@
+"""Host-side pieces of bench.py that do not need a GPU: the self-spawn command of a bare `python bench.py --gpus N`
+(the driver's N = 1 invocation is bare; an N > 1 invocation of the same form must become N ranks on its own) and the
+roofline bookkeeping."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_spawn_command_is_a_torchrun_of_this_file():
+    cmd = bench.spawn_command(["--gpus", "4", "--steps", "3", "--warmup", "1"], 4, port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    # a free port is picked when none is given
+    p = int(bench.spawn_command([], 2)[bench.spawn_command([], 2).index("--master-port") + 1])
+    assert 1024 < p < 65536
+
+
+def test_spawned_ranks_see_world_size(tmp_path):
+    """The spawn command really brings up N ranks with RANK / WORLD_SIZE / MASTER_* set (a stand-in script replaces bench.py:
+    there is no GPU here)."""
+    import subprocess
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os\nopen(os.path.join(os.path.dirname(__file__), 'r' + os.environ['RANK']), 'w')"
+                     ".write(os.environ['WORLD_SIZE'] + ' ' + os.environ['MASTER_ADDR'])\n")
+    cmd = bench.spawn_command([], 2)
+    cmd[cmd.index(os.path.join(ROOT, "bench.py"))] = str(probe)
+    subprocess.run(cmd, check=True, timeout=120)
+    assert (tmp_path / "r0").read_text() == "2 127.0.0.1" and (tmp_path / "r1").read_text() == "2 127.0.0.1"
+
+
+def test_rooflines_bookkeeping():
+    summ = {("flash", 8, 2): {"launches": 10, "avg_ms": 0.5, "total_ms": 5.0},
+            ("flash", 16, 2): {"launches": 10, "avg_ms": 1.0, "total_ms": 10.0},
+            ("conv3x3", 1e12, 0): {"launches": 4, "avg_ms": 1.0, "total_ms": 4.0},
+            ("capture", 268435456, 0): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2}}
+    roof, others = bench.rooflines(summ)
+    flops = 4.0 * 4096 * 8192 * 320 * (8 + 16) * 10
+    assert abs(roof["achieved"] - flops / 15e-3 / 1e12) < 1e-6 and roof["peak"] == 2500.0 and roof["bound"] == "mfma"
+    assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-12 and roof["launches"] == 20
+    byname = {o["kernel"].split(" ")[0]: o for o in others}
+    assert abs(byname["igemm_kernel<..,"]["achieved"] - 1000.0) < 1e-6
+    cap = [o for o in others if o["bound"] == "hbm"][0]
+    assert abs(cap["achieved"] - 2 * 268435456 / 0.2e-3 / 1e9) < 1e-6 and cap["peak"] == 8000.0

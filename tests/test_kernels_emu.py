@@ -114,13 +114,13 @@ def test_conv3x3_small_cin_and_cout():
     KC.case_conv3x3(DEV, n=2, h=8, w=8, cin=32, cout=4)                             # conv_out: 4 of 64 tile rows live
 
 
-@pytest.mark.parametrize("tile_cfg,split_k", [(2542, 1), (2442, 1), (2242, 1), (2222, 1), (2122, 1), (2222, 3), (2122, 2)])
+@pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 3), (254222, 2), (254122, 4), (158122, 1)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 2542, 2442, 2242, 2222, 2122])
+@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222])
 def test_gemm_tile_shapes(tile_cfg):
     KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
 
@@ -129,11 +129,11 @@ def test_gemm_forms():
     KC.case_gemm(DEV, rows=77, k=64, o=40, bias=False)
     KC.case_gemm(DEV, rows=130, k=320, o=320, n_res=1, ldx_extra=64, ldy_extra=24)          # strided x / y views
     KC.case_gemm(DEV, rows=96, k=32, o=128, lead=(2, 48))                                   # [B, L, K] input
-    KC.case_gemm(DEV, rows=64, k=128, o=36, split_k=2, tile_cfg=2122)                       # split-K partial slabs
+    KC.case_gemm(DEV, rows=64, k=128, o=36, split_k=2, tile_cfg=212222)                       # split-K partial slabs
     KC.case_gemm(DEV, rows=2, k=1280, o=96)                                                 # time-embedding shaped
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 2442, 2222])
+@pytest.mark.parametrize("tile_cfg", [0, 244222, 224223, 222222])
 def test_gemm_geglu(tile_cfg):
     KC.case_gemm(DEV, rows=70, k=64, o=256, geglu=True, tile_cfg=tile_cfg)
     KC.case_gemm(DEV, rows=33, k=40, o=128, geglu=True, bias=False, tile_cfg=tile_cfg)
@@ -142,7 +142,7 @@ def test_gemm_geglu(tile_cfg):
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)
-    KC.case_gemm_vt(DEV, n=1, l=200, k=32, c=32, lp=256, tile_cfg=2222)
+    KC.case_gemm_vt(DEV, n=1, l=200, k=32, c=32, lp=256, tile_cfg=222222)
 
 
 def test_temporal_conv3():

@@ -124,7 +124,7 @@ def test_conv3x3_small_levels_and_ends(kw):
     print(kw, r)
 
 
-@pytest.mark.parametrize("tile_cfg,split_k", [(2542, 1), (2442, 1), (2242, 1), (2222, 1), (2122, 1), (2222, 4), (2442, 2)])
+@pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 4), (244222, 2), (254222, 4), (254122, 2), (158122, 1), (158122, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     KC.case_conv3x3(DEV, n=4, h=16, w=16, cin=640, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
@@ -147,7 +147,7 @@ def test_gemm_geglu(rows, k, o):
     print(rows, k, o, r)
 
 
-@pytest.mark.parametrize("tile_cfg", [2542, 2442, 2242, 2222, 2122])
+@pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222])
 def test_gemm_every_tile_shape(tile_cfg):
     KC.case_gemm(DEV, rows=3000, k=640, o=960, n_res=1, tile_cfg=tile_cfg)
     KC.case_gemm(DEV, rows=520, k=1280, o=320, tile_cfg=tile_cfg, split_k=4)
