@@ -81,7 +81,8 @@ _SIGS = {
                                      C.c_int, C.c_int, _P, _P]),
     "fz_conv3x3": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
-    "fz_temporal_conv3": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "fz_temporal_conv3": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64,
+                                    _P]),
     "fz_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "fz_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "fz_transpose_pad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P]),

@@ -685,14 +685,14 @@ static int conv_common(IgArgs& g, const void* x, const void* wt, const void* bia
 
 extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
                                 int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len,
-                                void* stream) {
+                                void* workspace, int64_t workspace_floats, void* stream) {
     if (!x || !wt || !y || n <= 0 || tokens <= 0 || clip_len <= 0 || n % clip_len) return FZ_ERR_BAD_ARG;
     if (cin % 8) return FZ_ERR_UNSUPPORTED;
     IgArgs g = {};
     g.taps = 3;
     g.N = n; g.Hi = 1; g.Wi = tokens; g.Ho = 1; g.Wo = tokens; g.stride = 1; g.upsample = 0; g.fpb = clip_len;
     conv_common(g, x, wt, nullptr, temb, temb_stride, res, res2, y, cin, cout);
-    return ig_run<2, false>(g, 1, 0, 1, nullptr, 0, stream);
+    return ig_run<2, false>(g, 1, 0, 0, (float*)workspace, workspace_floats, stream);
 }
 
 extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,

@@ -211,25 +211,33 @@ def blend_mask(maps: List[torch.Tensor], alpha: torch.Tensor, th: float, out_hw:
 
 
 _gn_scratch = {}
+_gn_plans = {}
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span: int, groups: int, eps: float,
               silu: bool, out: Optional[torch.Tensor] = None):
     """x: [N, tokens, C] contiguous fp16; statistics shared by `span` consecutive frames."""
-    n, tokens, c = x.shape
-    assert x.is_contiguous()
-    _chk16(x, gamma, beta)
+    key = (x.shape, span, groups, x.device)
+    plan = _gn_plans.get(key)
+    if plan is None:  # first use of this signature: validate, size the scratch
+        n, tokens, c = x.shape
+        assert x.is_contiguous()
+        _chk16(x, gamma, beta)
+        chunks = N.lib().fz_groupnorm_chunks(tokens, c)
+        need = n * chunks * groups * 3 + (n // span) * groups * 2
+        buf = _gn_scratch.get(x.device)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
+            _gn_scratch[x.device] = buf
+            _gn_plans.clear()  # plans hold the scratch pointer
+        plan = _gn_plans[key] = (n, tokens, c, buf.data_ptr(), buf)
+    n, tokens, c, scratch, _ = plan
     if out is None:
         out = torch.empty_like(x)
-    chunks = N.lib().fz_groupnorm_chunks(tokens, c)
-    need = n * chunks * groups * 3 + (n // span) * groups * 2
-    key = (x.device, )
-    buf = _gn_scratch.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=x.device)
-        _gn_scratch[key] = buf
-    N.check(N.lib().fz_groupnorm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), n, span, tokens, c, groups, float(eps),
-                                 1 if silu else 0, _ptr(buf), _stream(x)), "fz_groupnorm")
+    rc = N.lib().fz_groupnorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, span, tokens, c, groups, eps,
+                              1 if silu else 0, scratch, _stream(x))
+    if rc:
+        N.check(rc, "fz_groupnorm")
     return out
 
 
@@ -270,19 +278,6 @@ def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
 _ws = {}
 
 
-def _workspace(device, floats: int) -> torch.Tensor:
-    """fp32 scratch for split-K partial slabs (one per device, grown on demand, never shrunk)."""
-    buf = _ws.get(device)
-    if buf is None or buf.numel() < floats:
-        buf = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
-        _ws[device] = buf
-    return buf
-
-
-# launches with at most this many output elements get a split-K workspace (above it the tile count fills the chip)
-_SPLITK_MAX_OUT = 1 << 25
-
-
 def pack_geglu(w: torch.Tensor, b: Optional[torch.Tensor]):
     """GEGLU projection weight [2*inner, K] (rows [h ; gate], diffusers GEGLU.proj) -> rows regrouped so that every 64-row
     group is 32 h rows followed by the 32 matching gate rows (include/fatezero_hip.h, FZ_GEMM_GEGLU)."""
@@ -296,11 +291,46 @@ def pack_geglu(w: torch.Tensor, b: Optional[torch.Tensor]):
     return wp.contiguous(), (None if bp is None else bp.contiguous())
 
 
+_WS_FLOATS = 64 << 20  # 256 MB of fp32 split-K scratch per device, allocated on first need
+
+
+def _ws_ptr(device):
+    buf = _ws.get(device)
+    if buf is None:
+        buf = _ws[device] = torch.empty(_WS_FLOATS, dtype=torch.float32, device=device)
+    return buf.data_ptr()
+
+
+_gemm_plans = {}
+
+
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
          res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, geglu: bool = False, tile_cfg: int = 0,
          split_k: int = 0):
     """y[..., o] = x[..., :] @ w[o, :] + bias (+ res) (+ res2); x: [..., K] with unit channel stride and ONE row stride
-    (a channel slice of a token-major tensor is fine); w: [O, K] fp16 (GEGLU: packed by pack_geglu); res / out: [..., O']."""
+    (a channel slice of a token-major tensor is fine); w: [O, K] fp16 (GEGLU: packed by pack_geglu); res / out: [..., O'].
+    The descriptor of a call signature (shapes / strides / flags) is validated and built once and then reused: per call only
+    the pointers change."""
+    key = (x.shape, x.stride(), w.shape, w.stride(0), geglu, tile_cfg, split_k, x.device,
+           None if res is None else res.stride(), res2 is not None, None if out is None else (out.shape, out.stride()))
+    plan = _gemm_plans.get(key)
+    if plan is None:
+        plan = _gemm_plans[key] = _gemm_plan(x, w, bias, res, res2, out, geglu, tile_cfg, split_k)
+    d_ref, out_shape, want_ws, _keep = plan
+    if out is None:
+        out = torch.empty(out_shape, dtype=torch.float16, device=x.device)
+    ptrs = x.data_ptr() | w.data_ptr() | out.data_ptr()
+    if (ptrs & 15) or x.dtype != torch.float16 or w.dtype != torch.float16:
+        raise ValueError("fz_gemm operands must be fp16 and 16-byte aligned")
+    rc = N.lib().fz_gemm(d_ref, x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                         None if res is None else res.data_ptr(), None if res2 is None else res2.data_ptr(), out.data_ptr(),
+                         _ws_ptr(x.device) if want_ws else None, _stream(x))
+    if rc:
+        N.check(rc, "fz_gemm")
+    return out
+
+
+def _gemm_plan(x, w, bias, res, res2, out, geglu, tile_cfg, split_k):
     k = x.shape[-1]
     o = w.shape[0]
     ow = o // 2 if geglu else o
@@ -310,45 +340,53 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     for d in range(x.dim() - 2):  # leading dims must collapse onto the row stride
         assert x.stride(d) == x.stride(d + 1) * x.shape[d + 1], "x must have a single row stride"
     _chk16(x, w, bias, res, res2)
-    if out is None:
-        out = torch.empty(*x.shape[:-1], ow, dtype=torch.float16, device=x.device)
-    assert out.stride(-1) == 1 and out.shape[-1] == ow and out.numel() // ow == rows
+    out_shape = tuple(x.shape[:-1]) + (ow,)
+    ldy = ow
+    if out is not None:
+        assert out.stride(-1) == 1 and out.shape[-1] == ow and out.numel() // ow == rows and out.dtype == torch.float16
+        ldy = out.stride(-2) if out.dim() > 1 else ow
     d = N.FzGemmDesc()
     d.rows, d.in_features, d.out_features = rows, k, o
-    d.ldx, d.ldw, d.ldy = ldx, w.stride(0), (out.stride(-2) if out.dim() > 1 else ow)
+    d.ldx, d.ldw, d.ldy = ldx, w.stride(0), ldy
     d.batch, d.epilogue = 1, (N.FZ_GEMM_GEGLU if geglu else N.FZ_GEMM_PLAIN)
     d.tile_cfg, d.split_k = tile_cfg, split_k
     for r in (res, res2):
         if r is not None:
-            assert r.shape[-1] == ow and r.stride(-1) == 1 and r.numel() // ow == rows
+            assert r.shape[-1] == ow and r.stride(-1) == 1 and r.numel() // ow == rows and r.dtype == torch.float16
     if res is not None:
         d.ldres = res.stride(-2) if res.dim() > 1 else ow
         if res2 is not None:
             assert (res2.stride(-2) if res2.dim() > 1 else ow) == d.ldres
-    ws = None
-    if not geglu and rows * o <= _SPLITK_MAX_OUT and o % 4 == 0 and (k >= 1024 or split_k > 1):
-        need = N.lib().fz_gemm_workspace_floats(rows, o, 1)
-        ws = _workspace(x.device, need)
-        d.workspace_floats = ws.numel()
-    N.check(N.lib().fz_gemm(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(res2), _ptr(out), _ptr(ws), _stream(x)),
-            "fz_gemm")
-    return out
+    # split-K scratch only where it can pay: long K and few enough outputs that the fp32 slabs stay small
+    want_ws = (not geglu) and o % 4 == 0 and (k >= 1024 or split_k > 1) and 2 * rows * o <= _WS_FLOATS
+    if want_ws:
+        d.workspace_floats = _WS_FLOATS
+    return (C.byref(d), out_shape, want_ws, d)
+
+
+_vt_plans = {}
 
 
 def gemm_vt(x: torch.Tensor, w: torch.Tensor, lp: int, out: Optional[torch.Tensor] = None, tile_cfg: int = 0):
     """x: [N, L, K] (unit channel stride), w: [C, K] -> V^T [N, C, lp] = w @ x[n]^T, columns [L, lp) zero."""
+    key = (x.shape, x.stride(), w.shape, w.stride(0), lp, tile_cfg, x.device, None if out is None else out.stride())
+    plan = _vt_plans.get(key)
     n, l, k = x.shape
     c = w.shape[0]
-    assert x.stride(2) == 1 and w.stride(1) == 1 and lp >= l and lp % 8 == 0
-    _chk16(x, w)
     if out is None:
         out = torch.empty(n, c, lp, dtype=torch.float16, device=x.device)
-    d = N.FzGemmDesc()
-    d.rows, d.rows_store, d.in_features, d.out_features = l, lp, k, c
-    d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(0), out.stride(1)
-    d.batch, d.x_batch_stride, d.y_batch_stride = n, x.stride(0), out.stride(0)
-    d.transpose_out, d.tile_cfg = 1, tile_cfg
-    N.check(N.lib().fz_gemm(C.byref(d), _ptr(x), _ptr(w), None, None, None, _ptr(out), None, _stream(x)), "fz_gemm(vt)")
+    if plan is None:
+        assert x.stride(2) == 1 and w.stride(1) == 1 and lp >= l and lp % 8 == 0
+        _chk16(x, w, out)
+        d = N.FzGemmDesc()
+        d.rows, d.rows_store, d.in_features, d.out_features = l, lp, k, c
+        d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(0), out.stride(1)
+        d.batch, d.x_batch_stride, d.y_batch_stride = n, x.stride(0), out.stride(0)
+        d.transpose_out, d.tile_cfg = 1, tile_cfg
+        plan = _vt_plans[key] = (C.byref(d), d)
+    rc = N.lib().fz_gemm(plan[0], x.data_ptr(), w.data_ptr(), None, None, None, out.data_ptr(), None, _stream(x))
+    if rc:
+        N.check(rc, "fz_gemm(vt)")
     return out
 
 
@@ -359,10 +397,10 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, 
     n, _, cin = x.shape
     h, w = hw
     cout = wt.shape[0]
-    assert x.is_contiguous() and wt.is_contiguous() and tuple(wt.shape[1:]) == (9, cin)
-    _chk16(x, wt, bias, temb, res)
     hu, wu = (2 * h, 2 * w) if upsample else (h, w)
     ho, wo = (hu - 1) // stride + 1, (wu - 1) // stride + 1
+    if not (x.is_contiguous() and wt.is_contiguous() and wt.shape[1] == 9 and wt.shape[2] == cin and x.dtype == torch.float16):
+        raise ValueError("fz_conv3x3: x [N, H*W, Cin] and wt [Cout, 9, Cin] must be contiguous fp16")
     if out is None:
         out = torch.empty(n, ho * wo, cout, dtype=torch.float16, device=x.device)
     if res is not None:
@@ -371,13 +409,13 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, 
     if temb is not None:
         assert temb.shape == (n // frames_per_batch, cout) and temb.stride(1) == 1
         ts = temb.stride(0)
-    ws, wsn = None, 0
-    if n * ho * wo * cout <= _SPLITK_MAX_OUT and cout % 4 == 0 and cin % 8 == 0:
-        ws = _workspace(x.device, N.lib().fz_gemm_workspace_floats(n * ho * wo, cout, 1))
-        wsn = ws.numel()
-    N.check(N.lib().fz_conv3x3(_ptr(x), _ptr(wt), _ptr(bias), _ptr(temb), ts, _ptr(res), _ptr(out), n, h, w, cin, cout, stride,
-                               1 if upsample else 0, frames_per_batch, _ptr(ws), wsn, tile_cfg, split_k, _stream(x)),
-            "fz_conv3x3")
+    use_ws = cout % 4 == 0 and cin % 8 == 0 and 2 * n * ho * wo * cout <= _WS_FLOATS
+    rc = N.lib().fz_conv3x3(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
+                            None if temb is None else temb.data_ptr(), ts, None if res is None else res.data_ptr(),
+                            out.data_ptr(), n, h, w, cin, cout, stride, 1 if upsample else 0, frames_per_batch,
+                            _ws_ptr(x.device) if use_ws else None, _WS_FLOATS if use_ws else 0, tile_cfg, split_k, _stream(x))
+    if rc:
+        N.check(rc, "fz_conv3x3")
     return out, (ho, wo)
 
 
@@ -386,8 +424,8 @@ def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Opt
     """x: [N, tokens, Cin]; wt: [Cout, 3, Cin] (nn.Conv1d weight [Cout, Cin, 3] permuted); -> [N, tokens, Cout] (+res)."""
     n, tokens, cin = x.shape
     cout = wt.shape[0]
-    assert x.is_contiguous() and wt.is_contiguous() and tuple(wt.shape[1:]) == (3, cin)
-    _chk16(x, wt, res)
+    if not (x.is_contiguous() and wt.is_contiguous() and wt.shape[1] == 3 and wt.shape[2] == cin and x.dtype == torch.float16):
+        raise ValueError("fz_temporal_conv3: x [N, tokens, Cin] and wt [Cout, 3, Cin] must be contiguous fp16")
     if out is None:
         out = torch.empty(n, tokens, cout, dtype=torch.float16, device=x.device)
     for r in (res, res2):
@@ -397,19 +435,24 @@ def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Opt
     if temb is not None:
         assert temb.shape == (n // clip_len, cout) and temb.stride(1) == 1 and temb.dtype == torch.float16
         ts = temb.stride(0)
-    N.check(N.lib().fz_temporal_conv3(_ptr(x), _ptr(wt), _ptr(res), _ptr(res2), _ptr(temb), ts, _ptr(out), n, tokens, cin, cout,
-                                      clip_len, _stream(x)), "fz_temporal_conv3")
+    use_ws = cout % 4 == 0 and 2 * n * tokens * cout <= _WS_FLOATS
+    rc = N.lib().fz_temporal_conv3(x.data_ptr(), wt.data_ptr(), None if res is None else res.data_ptr(),
+                                   None if res2 is None else res2.data_ptr(), None if temb is None else temb.data_ptr(), ts,
+                                   out.data_ptr(), n, tokens, cin, cout, clip_len,
+                                   _ws_ptr(x.device) if use_ws else None, _WS_FLOATS if use_ws else 0, _stream(x))
+    if rc:
+        N.check(rc, "fz_temporal_conv3")
     return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):
     c = x.shape[-1]
-    assert x.is_contiguous()
-    _chk16(x, gamma, beta)
+    assert x.is_contiguous() and x.dtype == torch.float16
     if out is None:
         out = torch.empty_like(x)
-    N.check(N.lib().fz_layernorm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), x.numel() // c, c, float(eps), _stream(x)),
-            "fz_layernorm")
+    rc = N.lib().fz_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.numel() // c, c, eps, _stream(x))
+    if rc:
+        N.check(rc, "fz_layernorm")
     return out
 
 

@@ -190,13 +190,21 @@ class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
         self.last_edit_controller = edit_controller
         sdimage_output = self.sd_ddim_pipeline(controller=edit_controller, **kwargs)
         mask_list = edit_controller.latent_blend.mask_list if hasattr(edit_controller.latent_blend, "mask_list") else None
-        attention_output = None
-        if len(edit_controller.attention_store.keys()) > 0:
-            attention_output = attention_util.show_cross_attention(self.tokenizer, kwargs["prompt"], edit_controller, 16,
-                                                                   ["up", "down"])
+        attention_output = self._attention_strips(kwargs["prompt"], edit_controller)
         dict_output = {"sdimage_output": sdimage_output, "attention_output": attention_output, "mask_list": mask_list}
         attention_util.register_attention_control(self, self.empty_controller)
         return dict_output
+
+    def _attention_strips(self, prompt, controller):
+        """`show_cross_attention(tokenizer, prompt, controller, 16, ["up", "down"])` of the reference
+        (p2p_ddim_spatial_temporal.py:211-215).  The reference crashes there when no 16x16 cross map exists (any input that
+        is not 512x512: `torch.cat` of an empty list); here that case yields None."""
+        if len(controller.attention_store.keys()) == 0:
+            return None
+        try:
+            return attention_util.show_cross_attention(self.tokenizer, prompt, controller, 16, ["up", "down"])
+        except ValueError:
+            return None
 
     @torch.no_grad()
     def __call__(self, **kwargs):
@@ -209,8 +217,7 @@ class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
             self.store_controller = attention_util.AttentionStore()
             attention_util.register_attention_control(self, self.store_controller)
             sdimage_output = self.sd_ddim_pipeline(controller=self.store_controller, **kwargs)
-            attention_output = attention_util.show_cross_attention(self.tokenizer, kwargs["prompt"], self.store_controller,
-                                                                   16, ["up", "down"])
+            attention_output = self._attention_strips(kwargs["prompt"], self.store_controller)
             dict_output = {"sdimage_output": sdimage_output, "attention_output": attention_output, "mask_list": None}
             attention_util.register_attention_control(self, self.empty_controller)
             return dict_output

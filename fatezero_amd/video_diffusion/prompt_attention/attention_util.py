@@ -47,9 +47,7 @@ class EmptyControl:
         return AttnPlan(n_frames)
 
 
-def show_cross_attention(*args, **kwargs):
-    """Visualisation of averaged cross maps (visualization.py) is out of scope; the key is kept, the value is None."""
-    return None
+from .visualization import show_cross_attention  # noqa: E402,F401  (attention_util.py:18 of the reference re-exports it)
 
 
 class AttentionControlEdit(AttentionStore, abc.ABC):
@@ -71,8 +69,12 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
         self.prev_attention_key_name = 0
         self.use_inversion_attention = use_inversion_attention
         self.attention_position_counter_dict = {k: 0 for k in KEYS}
-        # the live cross maps are only kept (and summed) when something consumes them
+        # The reference stores EVERY live (un-edited) map of the edit pass (`super().forward`, attention_util.py:103) although
+        # only two things ever read them: the latent blend (all cross maps <= 32x32) and `show_cross_attention(..., 16,
+        # ["up", "down"])` at the end of the edit (p2p_ddim_spatial_temporal.py:211-215: the 16x16 cross maps).  Here a live
+        # cross map is written (and summed) only when one of them will consume it.
         self.track_cross_attention = latent_blend is not None
+        self.visualize_res = 16  # None: no `attention_output` (nothing tracked for it)
         self._coef_cache = {}
         self._mapper_t_dev = None
 
@@ -124,7 +126,7 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
         if is_cross:
             mapper_t, coef = self.cross_constants(self.cur_step, device)
             plan.mode, plan.p, plan.mapper_t, plan.coef = K.FZ_ATTN_INJECT, base.storage, mapper_t, coef
-            if self.track_cross_attention:
+            if self.track_cross_attention or (self.visualize_res is not None and lq == self.visualize_res ** 2):
                 plan.cur_out = self.new_slot(key, n_ctrl, heads, lq, lk, True, device).storage
             return plan
         if self.save_self_attention:  # only outside the 'swap' flow of the reference's validation loop

@@ -198,9 +198,12 @@ int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb
  * '(b h w) c f'): y[n][tok][co] = sum_{t=0..2, ci} x[n - f + (f+t-1)][tok][ci] * wt[co][t][ci] (+ res), zero padded at the
  * clip ends (f = n % clip_len).  x: [n][tokens][cin]; wt: [cout][3][cin]; y/res/res2: [n][tokens][cout];
  * temb (optional): [n/clip_len] rows of cout values, temb_stride elements apart (ResnetBlock's time embedding add,
- * resnet.py:366-376, fused behind the temporal conv). */
+ * resnet.py:366-376, fused behind the temporal conv).
+ * workspace / workspace_floats: optional split-K scratch as for fz_gemm (the rank-160 projection at the small levels has too
+ * few output tiles to fill the chip otherwise). */
 int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
-                      int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len, void* stream);
+                      int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len, void* workspace,
+                      int64_t workspace_floats, void* stream);
 
 /* LayerNorm over channels, rows = tokens (attention.py:193-233). gamma/beta fp16. */
 int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,
