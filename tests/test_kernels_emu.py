@@ -43,6 +43,14 @@ def test_self_flash_log2_folded_q(lq, qk_scale, shape):
                       qk_scale=qk_scale, shape=shape, fold=True)
 
 
+@pytest.mark.parametrize("lq,index_list,shape", [(576, ["mid"], "ramp"), (600, ["mid"], None), (640, [-1, "mid", 1], "ramp")])
+def test_self_flash_pair_ring_odd_tiles(lq, index_list, shape):
+    # the d=40 log2-domain variant meets at a barrier every SECOND 64-key tile (4-stage K/V ring): odd tile counts (9, 10
+    # with a ragged last tile whose padded keys are neutralised in the stash, 30 over three kv slots)
+    KC.case_attn_self(DEV, batch=1, clip=3, heads=1, d=40, lq=lq, index_list=index_list, mode=K.FZ_ATTN_FLASH,
+                      qk_scale=3.0, shape=shape, fold=True)
+
+
 def test_self_capture_and_inject_log2_folded_q():
     KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=64, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE,
                       fold=True)
