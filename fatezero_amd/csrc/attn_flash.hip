@@ -449,7 +449,8 @@ static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, c
 #ifndef FZ_FLASH_NO_DISPATCH
 // called by fz_attn_self (attn_self.hip) for mode == FZ_ATTN_FLASH
 int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream) {
-    // Variant choice is fixed by measurements (profiles/r01_kbench_v0.json, profiles/r02_flash_ab.txt):
+    // Variant choice is fixed by measurements (profiles/r01_kbench_v0.json, profiles/r02_flash_ab.txt; the
+    // 4-stage ring with a barrier every second tile measured 0.1-0.7 % SLOWER than the 2-stage one and is not instantiated):
     // two query blocks per wave at two waves per SIMD once there are >= 512 query rows, four waves per SIMD below.
     const bool big = d.lq >= 512;  // two query blocks per wave only pay when there are enough rows to fill the chip
     switch (d.head_dim) {
@@ -459,7 +460,7 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
             if (!d.q_log2_scaled || d.lkf < FKVBLK)  // q as to_q produces it (or a first tile with padded keys, see STASH_MASKS)
                 return big ? launch_flash<40, 2, 2, false>(d, q, k, vt, o, stream)
                            : launch_flash<40, 4, 1, false>(d, q, k, vt, o, stream);
-            return big ? launch_flash<40, 2, 2, true, 4>(d, q, k, vt, o, stream) : launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
+            return big ? launch_flash<40, 2, 2>(d, q, k, vt, o, stream) : launch_flash<40, 4, 1>(d, q, k, vt, o, stream);
         case 64: return launch_flash<64, 2, 1>(d, q, k, vt, o, stream);
         case 80: return launch_flash<80, 2, 1>(d, q, k, vt, o, stream);
         case 128: return launch_flash<128, 1, 1>(d, q, k, vt, o, stream);

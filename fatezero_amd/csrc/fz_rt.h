@@ -15,6 +15,7 @@ typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -77,6 +78,13 @@ FZ_DEVICE void fz_wait_vm() {
 // the caller orders its own LDS traffic -- fz_wait_vm<N>() before it for DMA'd data, and every ds_read of the buffer being
 // recycled already consumed (an MFMA cannot issue before its LDS operands arrived)
 FZ_DEVICE void fz_barrier_nodrain() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS hand-over INSIDE one wave (lane a's ds_write read by lane b of the same wave): the LDS unit executes a wave's
+// instructions in order, so no s_barrier is needed -- only the compiler has to keep the order
+FZ_DEVICE void fz_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #define FZ_DEVICE_GLOBAL __device__
 
 #else
@@ -175,6 +183,10 @@ static inline void fz_wait_vm0() {}
 template <int N>
 static inline void fz_wait_vm() {}
 static inline void fz_barrier_nodrain() { fz_emu::sync_block(); }
+static inline void fz_wave_lds_sync() {  // all 64 lane fibers of the wave meet
+    int mine = 0, all[64];
+    fz_emu::wave_exchange(&mine, all, sizeof(int));
+}
 #define FZ_DEVICE_GLOBAL static
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
@@ -218,6 +230,14 @@ FZ_DEVICE uint32_t fz_mad24(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 FZ_DEVICE void fz_st_h8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
+// streaming 16-byte store (nt: the line is not kept for re-use) for data this GPU job writes once and reads much later
+FZ_DEVICE void fz_st_h8_nt(half_t* p, half8_t v) {
+#ifdef FZ_EMU
+    *reinterpret_cast<half8_t*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<half8_t*>(p));
+#endif
+}
 
 static inline int fz_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int fz_round_up(int a, int b) { return fz_ceil_div(a, b) * b; }
