@@ -16,7 +16,7 @@ FZ_KERNEL void __launch_bounds__(256) geglu_kernel(const half_t* __restrict__ x,
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float g = (float)gv[e];
-            const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
+            const float ge = fz_gelu_erf(g);
             o[e] = (half_t)((float)hv[e] * ge);
         }
         fz_st_h8(y + r * inner + v * 8, o);

@@ -73,7 +73,6 @@ struct IgCfg {
     static FZ_DEVICE int swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
-FZ_DEVICE float ig_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
@@ -306,7 +305,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
                             half4_t v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                v[e] = (half_t)(acc[i][j][4 * gq + e] * ig_gelu(acc[i + 1][j][4 * gq + e]));
+                                v[e] = (half_t)(acc[i][j][4 * gq + e] * fz_gelu_erf(acc[i + 1][j][4 * gq + e]));
                             *reinterpret_cast<half4_t*>(crow + (wa * TA / 2 + i / 2) * 32 + 8 * gq + 4 * hi) = v;
                         }
                 } else {
