@@ -47,6 +47,10 @@ static inline int fz_last_launch_status() { return hipGetLastError() == hipSucce
 FZ_DEVICE f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// a value the program knows to be wave-uniform (e.g. threadIdx.x / 64): tell the compiler, so that what depends on it stays in SGPRs
+FZ_DEVICE int fz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// keeps a rarely taken branch a branch (hipcc otherwise if-converts it into per-use v_cndmask on the common path)
+#define FZ_COLD_PATH() asm volatile("" ::: "memory")
 FZ_DEVICE float fz_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE int fz_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE float fz_shfl(float v, int lane) { return __shfl(v, lane, 64); }
@@ -150,6 +154,8 @@ static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
     }
     return c;
 }
+static inline int fz_uniform(int v) { return v; }
+#define FZ_COLD_PATH() ((void)0)
 static inline float fz_shfl_xor(float v, int mask) {
     float all[64];
     fz_emu::wave_exchange(&v, all, sizeof(float));

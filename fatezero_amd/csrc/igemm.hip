@@ -14,7 +14,10 @@
 //     wait vmcnt(0); barrier;  issue tile t+1 -> buf[~cur];  ds_read_b128 + MFMA on buf[cur]
 // LDS-DMA writes lane-linear, so a tile is [row][8 chunks of 16 B] unpadded; the chunk index is XOR-swizzled with
 // (row >> 1) & 7 on the per-lane SOURCE address and again on the fragment read (conflict-free ds_read_b128, rule 21).
-// Zero padding (image border, clip ends, K tail) = lanes pointing at a device-global page of zeros.
+// Zero padding (image border, clip ends, K tail) = lanes pointing at a device-global page of zeros.  (The same DMA through a
+// buffer descriptor -- buffer_load_dwordx4 ... offen lds with an SGPR K offset and out-of-range lanes as zeros -- needs no
+// VALU at all for addresses but measured 20-40 % SLOWER on MI355X: twice the VMEM instruction count in the counters,
+// profiles/r02_pmc_conv64_bufferdma.json.)
 // Epilogue: + bias (fp32, in registers) [* GEGLU gate] -> fp16 tile through LDS -> (+ temb[b]) (+ res) (+ res2) -> full-row
 // 16-byte stores.  Split-K (small pyramid levels: too few tiles to fill 256 CUs) writes fp32 partial slabs that
 // igemm_reduce_kernel combines with the same tail.
@@ -79,7 +82,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, wave = fz_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wa = wave / WB, wb = wave % WB;
     // ---- tile of this workgroup: XCD-aware (blocks b, b+8, b+16.. share an XCD and get consecutive tiles, which share
     //      their B rows: the activation panel is fetched once per XCD L2), a-tile fastest
@@ -95,8 +98,12 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     const char* zero = reinterpret_cast<const char*>(fz_zero_page);
 
     // ---- per-lane sources.  Instruction (i, wave) of a tile covers rows RPI*(i*NW+wave) .. +RPI, lane -> (row = lane/CPR,
-    //      chunk position lane%CPR); the lane fetches source chunk pos ^ swz(row).
+    //      chunk position lane%CPR); the lane fetches source chunk pos ^ swz(row).  A lane's pointer is fixed for the whole K
+    //      loop of a GEMM and for one tap of a convolution; each K step only adds a wave-uniform byte offset to it (one 64-bit
+    //      add per instruction -- everything else the loop needs is scalar).  Lanes that must read zeros (image border, clip
+    //      ends) point into a device-global page of zeros; the K tail of a ragged Cin takes a separate, rarely executed path.
     const int pos = lane % C::CPR;
+    const int ktail = g.Cin - (g.kchunks - 1) * BK;  // valid halves of the last K chunk of a tap (BK when Cin % BK == 0)
     const char* aptr[C::ACH];
     int asc[C::ACH];
 #pragma unroll
@@ -161,30 +168,32 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
 
     const int nkt = g.taps * g.kchunks;  // kchunks = ceil(Cin / BK)
     const int kt0 = (int)((int64_t)nkt * ks / g.ksplit), kt1 = (int)((int64_t)nkt * (ks + 1) / g.ksplit);
-    const bool has_tail = (g.Cin % BK) != 0;
-    int cur_tap = -1;
-    auto issue = [&](int kt, int buf) {
-        const int tap = kt / g.kchunks, kc = kt - tap * g.kchunks;  // wave-uniform
-        if (MODE != 0 && tap != cur_tap) {
-            retarget(tap);
-            cur_tap = tap;
-        }
-        const int64_t ka = ((int64_t)tap * g.Cin + kc * BK) * 2;
-        const int kb = kc * BK * 2;
-        const bool tailk = has_tail && kc == g.kchunks - 1;
+    // issue cursor: (tap, K chunk) of the next tile to fetch -- advanced incrementally, no division in the loop
+    int itap = kt0 / g.kchunks, ikc = kt0 - itap * g.kchunks;
+    if (MODE != 0) retarget(itap);
+    auto issue = [&](int buf) {
+        const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offsets along K
+        const int kb = ikc * BK * 2;
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
         char* Bb = Ab + C::A_HALVES * 2;
+        if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
+            FZ_COLD_PATH();
 #pragma unroll
-        for (int i = 0; i < C::ACH; ++i) {
-            const char* src = aptr[i] + ka;
-            if (tailk && kc * BK + asc[i] * 8 >= g.Cin) src = zero;
-            fz_glds16(src, Ab + (i * C::NW + wave) * 1024);
+            for (int i = 0; i < C::ACH; ++i)
+                fz_glds16(asc[i] * 8 < ktail ? aptr[i] + ka : zero, Ab + (i * C::NW + wave) * 1024);
+#pragma unroll
+            for (int i = 0; i < C::BCH; ++i)
+                fz_glds16(bsc[i] * 8 < ktail ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::ACH; ++i) fz_glds16(aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
+#pragma unroll
+            for (int i = 0; i < C::BCH; ++i) fz_glds16(bptr[i] + kb, Bb + (i * C::NW + wave) * 1024);
         }
-#pragma unroll
-        for (int i = 0; i < C::BCH; ++i) {
-            const char* src = bptr[i] + kb;
-            if (tailk && kc * BK + bsc[i] * 8 >= g.Cin) src = zero;
-            fz_glds16(src, Bb + (i * C::NW + wave) * 1024);
+        if (++ikc == g.kchunks) {
+            ikc = 0;
+            ++itap;
+            if (MODE != 0 && itap < g.taps) retarget(itap);
         }
     };
 
@@ -206,7 +215,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     const int ntile = kt1 - kt0;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < ntile) issue(kt0 + s, s);
+        if (s < ntile) issue(s);
     int buf = 0;
     for (int it = 0; it < ntile; ++it) {
         if (it + NS - 1 <= ntile) {
@@ -218,7 +227,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         if (it + NS - 1 < ntile) {
             int nb = buf + NS - 1;
             nb = nb >= NS ? nb - NS : nb;
-            issue(kt0 + it + NS - 1, nb);
+            issue(nb);
         }
         const half_t* As = smem + buf * C::STAGE;
         const half_t* Bs = As + C::A_HALVES;

@@ -28,7 +28,7 @@ def main():
     out, cur, label = [], [], "entry"
     for l in lines[start + 1:]:
         s = l.strip()
-        if s.startswith(".Lfunc_end") or s.startswith("s_endpgm"):
+        if s.startswith(".Lfunc_end"):
             break
         if re.match(r"^\.LBB\d+_\d+:", s):
             out.append((label, "".join(cur)))
