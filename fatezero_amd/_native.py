@@ -85,6 +85,7 @@ _SIGS = {
                                     _P]),
     "fz_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "fz_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "fz_softmax_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_float, _P]),
     "fz_transpose_pad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P]),
     "fz_latent_update": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, C.c_int, C.c_int, _P]),
     "fz_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),

@@ -32,6 +32,96 @@ extern "C" int fz_geglu(const void* x, void* y, int64_t rows, int inner, void* s
     return fz_last_launch_status();
 }
 
+// ---- row softmax y = softmax(scale * x) of an fp16 score matrix, fp32 arithmetic (the single-head 512-wide attention of the
+//      VAE mid block, diffusers AttentionBlock [3P]: scores too wide for the head-dim-specialised attention kernels, outside
+//      the timed loop).  One wave per row; the row is read once and kept in registers when it fits (cols <= 64 * 8 * SM_MAXV).
+#define SM_MAXV 16
+FZ_DEVICE float sm_wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, fz_shfl_xor(v, m));
+    return v;
+}
+FZ_DEVICE float sm_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += fz_shfl_xor(v, m);
+    return v;
+}
+FZ_KERNEL void __launch_bounds__(256)
+softmax_rows_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int64_t rows, int cols, int64_t ldx, int64_t ldy,
+                    float scale_log2e) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    const bool rvalid = row < rows;  // every lane stays alive for the shuffles
+    const int V = cols >> 3;
+    const half_t* xr = x + (rvalid ? row : 0) * ldx;
+    if (V <= 64 * SM_MAXV) {
+        half8_t xv[SM_MAXV];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SM_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < V) {
+                xv[i] = fz_ld_h8(xr + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)xv[i][e]);
+            }
+        }
+        mx = sm_wave_max(mx) * scale_log2e;  // scale > 0
+        float sum = 0.0f;
+        float ev[SM_MAXV][8];
+#pragma unroll
+        for (int i = 0; i < SM_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < V) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ev[i][e] = fz_exp2(fmaf((float)xv[i][e], scale_log2e, -mx));
+                    sum += ev[i][e];
+                }
+            }
+        }
+        const float inv = 1.0f / sm_wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < SM_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (rvalid && v < V) {
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)(ev[i][e] * inv);
+                fz_st_h8(y + row * ldy + v * 8, o);
+            }
+        }
+    } else {  // long rows: three sweeps, the re-reads hit L2
+        float mx = -INFINITY;
+        for (int v = lane; v < V; v += 64) {
+            const half8_t t = fz_ld_h8(xr + v * 8);
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)t[e]);
+        }
+        mx = sm_wave_max(mx) * scale_log2e;
+        float sum = 0.0f;
+        for (int v = lane; v < V; v += 64) {
+            const half8_t t = fz_ld_h8(xr + v * 8);
+            for (int e = 0; e < 8; ++e) sum += fz_exp2(fmaf((float)t[e], scale_log2e, -mx));
+        }
+        const float inv = 1.0f / sm_wave_sum(sum);
+        for (int v = lane; v < V; v += 64) {
+            const half8_t t = fz_ld_h8(xr + v * 8);
+            half8_t o;
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(fz_exp2(fmaf((float)t[e], scale_log2e, -mx)) * inv);
+            if (rvalid) fz_st_h8(y + row * ldy + v * 8, o);
+        }
+    }
+}
+
+extern "C" int fz_softmax_rows(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, float scale,
+                               void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || !(scale > 0.0f)) return FZ_ERR_BAD_ARG;
+    if ((cols & 7) || (ldx & 7) || (ldy & 7) || ldx < cols || ldy < cols) return FZ_ERR_UNSUPPORTED;
+    FZ_LAUNCH(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const half_t*)x, (half_t*)y, rows,
+              cols, ldx, ldy, scale * 1.4426950408889634f);
+    return fz_last_launch_status();
+}
+
 // ---- out[n][c][lp] = in[n][l][c]^T, zero padded (the V^T operand of the attention kernels) ------------------
 FZ_KERNEL void __launch_bounds__(256)
 transpose_pad_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int l, int c, int64_t in_frame_stride,

@@ -466,6 +466,19 @@ def geglu(x: torch.Tensor, out=None):
     return out
 
 
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, out=None):
+    """softmax(scale * x) over the last dim of an fp16 matrix [..., cols] (one row stride), fp32 arithmetic (fz_softmax_rows)."""
+    cols = x.shape[-1]
+    assert x.stride(-1) == 1 and x.dtype == torch.float16
+    rows = x.numel() // cols
+    ldx = x.stride(-2) if x.dim() > 1 else cols
+    _chk16(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    N.check(N.lib().fz_softmax_rows(_ptr(x), _ptr(out), rows, cols, ldx, cols, float(scale), _stream(x)), "fz_softmax_rows")
+    return out
+
+
 def transpose_pad(x: torch.Tensor, lp: int, out=None):
     """x: [N, L, >=C view] (unit channel stride) -> [N, C, lp] with zero padding."""
     n, l, c = x.shape

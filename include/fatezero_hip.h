@@ -212,6 +212,11 @@ int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, in
 /* GEGLU gate (diffusers FeedForward): y[r][c] = x[r][c] * gelu_erf(x[r][inner + c]). */
 int fz_geglu(const void* x, void* y, int64_t rows, int inner, void* stream);
 
+/* Row softmax of an fp16 score matrix in fp32 arithmetic: y[r][:cols] = softmax(scale * x[r][:cols]); cols, ldx, ldy multiples
+ * of 8.  Replaces the fp32 softmax of diffusers' AttentionBlock [3P, diffusers 0.11.1 models/attention.py] inside the VAE that
+ * p2p_ddim_spatial_temporal.py:94-96 (encode) and stable_diffusion.py:297-319 (decode) call. */
+int fz_softmax_rows(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, float scale, void* stream);
+
 /* out[n][c][lp] = in[n][l][c] transposed, zero padded l -> lp (V^T operand of the attention kernels). */
 int fz_transpose_pad(const void* in, void* out, int n, int l, int c, int64_t in_frame_stride, int64_t in_row_stride,
                      int lp, void* stream);
