@@ -34,6 +34,24 @@ class DDIMScheduler:
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
         self._ac = self.alphas_cumprod.double().numpy()
 
+    # -- checkpoint format: <path>/scheduler/scheduler_config.json (test_fatezero.py:112-115) ------------------
+    @classmethod
+    def from_config(cls, config: dict):
+        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "set_alpha_to_one", "steps_offset",
+                "prediction_type")
+        kw = {k: config[k] for k in keys if k in config}
+        # clip_sample / steps_offset are forced by the pipeline anyway (stable_diffusion.py:56-81); PNDM-style configs of the
+        # SD checkpoints carry `skip_prk_steps` etc., which DDIM ignores like diffusers' from_config does
+        return cls(**kw)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, **unused):
+        import json
+        import os
+        root = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
+        with open(os.path.join(root, "scheduler_config.json")) as f:
+            return cls.from_config(json.load(f))
+
     def scale_model_input(self, sample, timestep=None):
         return sample
 
