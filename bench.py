@@ -97,14 +97,16 @@ def pmc_traffic_per_launch(frames_per_launch):
     from the separate rocprofv3 --pmc passes of scripts/pmc_flash.sh (same kernel, 8 frames per launch), whose
     summary is committed under profiles/.  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request,
     MI355X_MICROARCH.md, HBM section); both counters are KiB.  Scaled linearly to this run's frames per launch."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_flash_d40_final.json")
-    try:
-        with open(path) as f:
-            pmc = json.load(f)
-        per8 = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        return per8 * frames_per_launch / 8.0, "profiles/r01_pmc_flash_d40_final.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-    except (OSError, KeyError, ValueError):
-        return None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_pmc_flash_d40_final.json", "r01_pmc_flash_d40_final.json"):  # newest measurement of the shipped kernel first
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                pmc = json.load(f)
+            per8 = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            return per8 * frames_per_launch / 8.0, f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def run_job(pipe, z0, ddim_steps, device):

@@ -114,9 +114,19 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         ar = ar < g.Ma ? ar : g.Ma - 1;
         aptr[i] = reinterpret_cast<const char*>(A + (int64_t)ar * g.lda) + asc[i] * 16;
     }
-    const char* bptr[C::BCH];
+    // MODE: 0 = plain rows; 1 = 3x3 conv, K order (tap, Cin chunk); 3 = 3x3 conv, K order (Cin chunk, tap); 2 = temporal
+    // 3-tap conv, K order (tap, Cin chunk) (chunk-outer measured 2-7 % slower there).  Chunk-outer order keeps the input window of a K chunk (a 128-byte slice of every
+    // pixel row the tile and its halo touch) in the XCD's L2 while the taps sweep over it; with taps outermost the 32 tiles
+    // running on an XCD re-read a > 4 MB window from MALL once per tap at 16 frames (profiles/r02_pmc_conv64_globaldma.json:
+    // FETCH_SIZE 9x the input).  The per-tap pointer is then formed every K step from a per-lane centre pointer, six validity
+    // bits and wave-uniform tap offsets (6 VALU per DMA instruction); tap-outer order (kept for the nearest-2x upsampling
+    // conv, whose source pixel is not linear in the tap) recomputes the pointers once per tap.
+    constexpr bool KORD = (MODE == 3);
+    constexpr bool CONV = (MODE == 1 || MODE == 3);
+    const char* bptr[C::BCH];   // !KORD: this tap's source (or the zero page); KORD: the centre tap's source
     int bsc[C::BCH];
     int bn[C::BCH], boy[C::BCH], box[C::BCH];  // conv: (frame, oy, ox) of the lane's pixel
+    int bflag[C::BCH];          // KORD: bit ky = source row oy*stride+ky-1 exists, bit 3+kx = column; temporal: bit t = frame
     bool bok[C::BCH];
 #pragma unroll
     for (int i = 0; i < C::BCH; ++i) {
@@ -125,6 +135,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         int64_t br = b0 + row;
         bok[i] = br < g.Nb;
         br = bok[i] ? br : g.Nb - 1;
+        bflag[i] = 0;
         if (MODE == 0) {
             bptr[i] = reinterpret_cast<const char*>(B + br * g.ldb) + bsc[i] * 16;
             bn[i] = boy[i] = box[i] = 0;
@@ -135,10 +146,17 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             boy[i] = rem / g.Wo;
             box[i] = rem - boy[i] * g.Wo;
             bptr[i] = zero;
+            if (KORD) {
+                const int cy = boy[i] * g.stride, cx = box[i] * g.stride;  // centre tap (always inside the image)
+                bptr[i] = reinterpret_cast<const char*>(B + (((int64_t)bn[i] * g.Hi + cy) * g.Wi + cx) * g.ldb) + bsc[i] * 16;
+                if (bok[i]) {
+                    bflag[i] = (cy > 0 ? 1 : 0) | 2 | (cy + 1 < g.Hi ? 4 : 0) | (cx > 0 ? 8 : 0) | 16 | (cx + 1 < g.Wi ? 32 : 0);
+                }
+            }
         }
     }
     const int Hu = g.upsample ? g.Hi * 2 : g.Hi, Wu = g.upsample ? g.Wi * 2 : g.Wi;
-    auto retarget = [&](int tap) {  // source pixel of every lane's chunk for tap `tap` (or the zero page)
+    auto retarget = [&](int tap) {  // tap-outer order: source pixel of every lane's chunk for tap `tap` (or the zero page)
 #pragma unroll
         for (int i = 0; i < C::BCH; ++i) {
             bool inb;
@@ -169,11 +187,24 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     const int nkt = g.taps * g.kchunks;  // kchunks = ceil(Cin / BK)
     const int kt0 = (int)((int64_t)nkt * ks / g.ksplit), kt1 = (int)((int64_t)nkt * (ks + 1) / g.ksplit);
     // issue cursor: (tap, K chunk) of the next tile to fetch -- advanced incrementally, no division in the loop
-    int itap = kt0 / g.kchunks, ikc = kt0 - itap * g.kchunks;
-    if (MODE != 0) retarget(itap);
+    int itap, ikc;
+    if (KORD) {
+        ikc = kt0 / g.taps;
+        itap = kt0 - ikc * g.taps;
+    } else {
+        itap = kt0 / g.kchunks;
+        ikc = kt0 - itap * g.kchunks;
+    }
+    if (MODE == 1 || MODE == 2) retarget(itap);
     auto issue = [&](int buf) {
         const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offsets along K
-        const int kb = ikc * BK * 2;
+        int64_t kb = ikc * BK * 2;
+        int need = 0;  // KORD: validity bits this tap requires
+        if (KORD) {
+            const int ky = itap / 3, kx = itap - 3 * ky;
+            kb += ((int64_t)(ky - 1) * g.Wi + (kx - 1)) * g.ldb * 2;
+            need = (1 << ky) | (8 << kx);
+        }
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
         char* Bb = Ab + C::A_HALVES * 2;
         if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
@@ -182,18 +213,31 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             for (int i = 0; i < C::ACH; ++i)
                 fz_glds16(asc[i] * 8 < ktail ? aptr[i] + ka : zero, Ab + (i * C::NW + wave) * 1024);
 #pragma unroll
-            for (int i = 0; i < C::BCH; ++i)
-                fz_glds16(bsc[i] * 8 < ktail ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
+            for (int i = 0; i < C::BCH; ++i) {
+                const bool ok = bsc[i] * 8 < ktail && (!KORD || (bflag[i] & need) == need);
+                fz_glds16(ok ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < C::ACH; ++i) fz_glds16(aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
 #pragma unroll
-            for (int i = 0; i < C::BCH; ++i) fz_glds16(bptr[i] + kb, Bb + (i * C::NW + wave) * 1024);
+            for (int i = 0; i < C::BCH; ++i) {
+                if (KORD) {
+                    fz_glds16((bflag[i] & need) == need ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
+                } else {
+                    fz_glds16(bptr[i] + kb, Bb + (i * C::NW + wave) * 1024);
+                }
+            }
         }
-        if (++ikc == g.kchunks) {
+        if (KORD) {
+            if (++itap == g.taps) {
+                itap = 0;
+                ++ikc;
+            }
+        } else if (++ikc == g.kchunks) {
             ikc = 0;
             ++itap;
-            if (MODE != 0 && itap < g.taps) retarget(itap);
+            if ((MODE == 1 || MODE == 2) && itap < g.taps) retarget(itap);
         }
     };
 
@@ -553,6 +597,9 @@ static const IgTile kTiles[] = {
 // fp32 slab round trip and a reduce launch.  What the measurements say: the 320 x 256 tile runs 0.9-1.0 PFLOP/s when the
 // launch has a multiple of 256 workgroups -- split-K is how the small pyramid levels get there -- and a half-empty last round
 // costs a full one, which is why the 64 x 128 tile wins the shapes in between.
+#ifndef FZ_SPLITK_LAUNCH_US
+#define FZ_SPLITK_LAUNCH_US 3.0  /* fitted; 9.0 (reduce run time + inter-kernel gap at face value) chose too few splits: 32^2 conv 728 -> 561 TF/s */
+#endif
 static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats, int* cfg_out, int* ksplit_out) {
     double best = 1e300;
     *cfg_out = 212222;
@@ -573,7 +620,7 @@ static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats,
             double us = (double)rounds * (t.fixed_us + (double)((nkt + sk - 1) / sk) * t_step);
             const double floor_us = bytes / 4.0e6;
             us = us > floor_us ? us : floor_us;
-            if (sk > 1) us += 3.0 + out_elems * sk * 8.0 / 4.0e6;
+            if (sk > 1) us += FZ_SPLITK_LAUNCH_US + out_elems * sk * 8.0 / 4.0e6;  // reduce launch: its own run time + the inter-kernel gap
             if (us < best) {
                 best = us;
                 *cfg_out = t.cfg;
@@ -724,5 +771,12 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
         FZ_LAUNCH(conv3x3_small_cin_kernel<4>, grid, block, (size_t)9 * cin * cout * 2, stream, g);
         return fz_last_launch_status();
     }
-    return ig_run<1, false>(g, 1, tile_cfg, split_k, (float*)workspace, workspace_floats, stream);
+    // K order.  With taps outermost the ~32 tiles running on one XCD read, per tap, a window of 32 x (pixels per tile) x Cin
+    // input values; when that exceeds the XCD's 4 MB L2 (16-frame launches at 64^2, Cin >= 960 at 8 frames) every tap re-reads it
+    // from MALL, and the Cin-chunk-outer order wins (+3 % at 64^2 x 16 f: 901 TF/s); below that, tap-outer is 3 % faster.  The
+    // nearest-2x upsampling conv always runs tap-outer (its source pixel is not linear in the tap).
+    const int64_t rows_per_tile = g.Nb >= 65536 ? 256 : 128;  // what ig_choose picks for launches that fill the chip
+    const bool chunk_outer = !upsample && 32 * rows_per_tile * (int64_t)cin * 2 > (3ll << 20);
+    if (!chunk_outer) return ig_run<1, false>(g, 1, tile_cfg, split_k, (float*)workspace, workspace_floats, stream);
+    return ig_run<3, false>(g, 1, tile_cfg, split_k, (float*)workspace, workspace_floats, stream);
 }

@@ -194,3 +194,19 @@ def test_frame_sharded_clip_matches_single_process(frames, index_list):
     scale = float(ref.float().abs().max())
     assert torch.isfinite(got.float()).all()
     assert err <= 1.5e-2 * scale, (err, scale)
+
+
+def test_frame_sharded_clip_four_ranks_eight_frames():
+    """The teaser clip length on 4 ranks (2 frames each): interior ranks exchange halos with both neighbours, rank 0 serves the
+    'first' anchor to everybody, every GroupNorm merges 4 ranks' partials."""
+    got, n_maps, n_local = _spawn(4, 8, [-1, "first"], True)
+    _, job = _frame_job_factory(8, [-1, "first"])
+    from fatezero_amd import _native
+    try:
+        ref = job()
+    finally:
+        _native.reset_backend()
+    assert n_local == 2 and n_maps and all(n == 2 for n in n_maps), (n_maps, n_local)
+    err = float((got.float() - ref.float()).abs().max())
+    scale = float(ref.float().abs().max())
+    assert torch.isfinite(got.float()).all() and err <= 1.5e-2 * scale, (err, scale)
