@@ -83,29 +83,41 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_kernel(TemporalArgs a) 
 // LDS-staged form (the default whenever the K/V rows of a token group fit): the F key rows and F value rows of
 // `tok_per_block` tokens are copied global -> LDS once, with every lane moving 16 contiguous bytes of a 2C-byte row,
 // instead of being re-read through L1 by each of the F query frames with an 80..320-byte lane stride.
+//   * FT > 0: the clip length is a compile-time constant -- scores and probabilities live in registers (no LDS round trip),
+//     every loop unrolls; FT == 0: any clip length, scores in LDS.
+//   * the rows of odd tokens are stored rotated by 8 chunks (128 B): a 16-lane group of a ds_read_b128 spans two tokens whose
+//     rows are a multiple of 256 B apart, which without the rotation is a 2-way bank conflict on every read.
+//   * no padding: 4 tokens x 8 frames x (K + V) of the 320-channel level are exactly 40 KB, four workgroups per CU, and the
+//     1024 workgroups of a 64x64 frame batch are one full wave of the chip (with the score buffer in LDS three fitted:
+//     1.33 rounds).
+template <int FT>
 FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_lds_kernel(TemporalArgs a) {
     FZ_DYN_SMEM(raw);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int tok0 = blockIdx.x * a.tok_per_block;
+    const int F = FT > 0 ? FT : a.F;
     const int C = a.heads * a.dh, cvec = C >> 3;
     half_t* Ks = reinterpret_cast<half_t*>(raw);                  // [tok_per_block][F][C]
-    half_t* Vs = Ks + (size_t)a.tok_per_block * a.F * C;          // same
-    float* S = reinterpret_cast<float*>(Vs + (size_t)a.tok_per_block * a.F * C);  // [TTHREADS][F]
-    const int rows = a.tok_per_block * a.F;
+    half_t* Vs = Ks + (size_t)a.tok_per_block * F * C;            // same
+    float* S = reinterpret_cast<float*>(Vs + (size_t)a.tok_per_block * F * C);  // FT == 0: [TTHREADS][F]
+    const int rows = a.tok_per_block * F;
+    const int rot = cvec > 8 ? 8 : 0;  // rotation of odd tokens' rows, in 16-byte chunks
     for (int id = tid; id < rows * cvec; id += TTHREADS) {
         const int row = id / cvec, cv = id % cvec;
-        const int tl = row / a.F, j = row % a.F;
+        const int tl = row / F, j = row % F;
         int tok = tok0 + tl;
         tok = tok < a.tokens ? tok : a.tokens - 1;
-        const int64_t g = ((int64_t)(b * a.F + j) * a.tokens + tok) * a.in_stride + cv * 8;
-        fz_st_h8(Ks + (size_t)row * C + cv * 8, fz_ld_h8(a.k + g));
-        fz_st_h8(Vs + (size_t)row * C + cv * 8, fz_ld_h8(a.v + g));
+        const int64_t g = ((int64_t)(b * F + j) * a.tokens + tok) * a.in_stride + cv * 8;
+        int dc = cv + ((tl & 1) ? rot : 0);
+        dc = dc >= cvec ? dc - cvec : dc;
+        fz_st_h8(Ks + (size_t)row * C + dc * 8, fz_ld_h8(a.k + g));
+        fz_st_h8(Vs + (size_t)row * C + dc * 8, fz_ld_h8(a.v + g));
     }
     __syncthreads();
     const int items = a.tok_per_block * a.heads * a.Fq;
     const int nvec = a.dh >> 3;
-    float* myS = S + tid * a.F;
+    float* myS = S + tid * F;
     for (int w = tid; w < items; w += TTHREADS) {
         const int h = w % a.heads;
         const int tl = (w / a.heads) % a.tok_per_block;
@@ -114,43 +126,98 @@ FZ_KERNEL void __launch_bounds__(TTHREADS) attn_temporal_lds_kernel(TemporalArgs
         if (tok >= a.tokens) continue;
         const int col = h * a.dh;
         const half_t* qrow = a.q + ((int64_t)(b * a.Fq + i) * a.tokens + tok) * a.q_stride + col;
-        const half_t* kt = Ks + (size_t)tl * a.F * C + col;
-        const half_t* vtok = Vs + (size_t)tl * a.F * C + col;
-        float mx = -1e30f;
-        for (int j = 0; j < a.F; ++j) {
-            float acc = 0.0f;
-            for (int c = 0; c < nvec; ++c) {
-                const half8_t qv = fz_ld_h8(qrow + 8 * c), kv = fz_ld_h8(kt + (size_t)j * C + 8 * c);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += (float)qv[e] * (float)kv[e];
-            }
-            acc *= a.scale;
-            myS[j] = acc;
-            mx = fmaxf(mx, acc);
-        }
-        float sum = 0.0f;
-        for (int j = 0; j < a.F; ++j) {
-            const float e = __builtin_expf(myS[j] - mx);
-            myS[j] = e;
-            sum += e;
-        }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < a.F; ++j) myS[j] = (float)(half_t)(myS[j] * inv);  // P is cast to fp16 before P.V
+        const half_t* kt = Ks + (size_t)tl * F * C;
+        const half_t* vtok = Vs + (size_t)tl * F * C;
+        const int c0 = (col >> 3) + ((tl & 1) ? rot : 0);  // first (rotated) chunk of this head inside a row
         half_t* orow = a.o + ((int64_t)(b * a.Fq + i) * a.tokens + tok) * a.out_stride + col;
-        for (int c = 0; c < nvec; ++c) {
-            float acc[8];
+        if (FT > 0) {
+            constexpr int FR = FT > 0 ? FT : 1;
+            float s[FR];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
-            for (int j = 0; j < a.F; ++j) {
-                const half8_t vv = fz_ld_h8(vtok + (size_t)j * C + 8 * c);
-                const float pj = myS[j];
+            for (int j = 0; j < FR; ++j) s[j] = 0.0f;
+            for (int c = 0; c < nvec; ++c) {
+                int cc = c0 + c;
+                cc = cc >= cvec ? cc - cvec : cc;
+                const half8_t qv = fz_ld_h8(qrow + 8 * c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+                for (int j = 0; j < FR; ++j) {
+                    const half8_t kv = fz_ld_h8(kt + (size_t)j * C + cc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[j] += (float)qv[e] * (float)kv[e];
+                }
             }
-            half8_t ov;
+            float mx = -1e30f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (half_t)acc[e];
-            fz_st_h8(orow + 8 * c, ov);
+            for (int j = 0; j < FR; ++j) {
+                s[j] *= a.scale;
+                mx = fmaxf(mx, s[j]);
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < FR; ++j) {
+                s[j] = __builtin_expf(s[j] - mx);
+                sum += s[j];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int j = 0; j < FR; ++j) s[j] = (float)(half_t)(s[j] * inv);  // P is cast to fp16 before P.V
+            for (int c = 0; c < nvec; ++c) {
+                int cc = c0 + c;
+                cc = cc >= cvec ? cc - cvec : cc;
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < FR; ++j) {
+                    const half8_t vv = fz_ld_h8(vtok + (size_t)j * C + cc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += s[j] * (float)vv[e];
+                }
+                half8_t ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (half_t)acc[e];
+                fz_st_h8(orow + 8 * c, ov);
+            }
+        } else {
+            float mx = -1e30f;
+            for (int j = 0; j < F; ++j) {
+                float acc = 0.0f;
+                for (int c = 0; c < nvec; ++c) {
+                    int cc = c0 + c;
+                    cc = cc >= cvec ? cc - cvec : cc;
+                    const half8_t qv = fz_ld_h8(qrow + 8 * c), kv = fz_ld_h8(kt + (size_t)j * C + cc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += (float)qv[e] * (float)kv[e];
+                }
+                acc *= a.scale;
+                myS[j] = acc;
+                mx = fmaxf(mx, acc);
+            }
+            float sum = 0.0f;
+            for (int j = 0; j < F; ++j) {
+                const float e = __builtin_expf(myS[j] - mx);
+                myS[j] = e;
+                sum += e;
+            }
+            const float inv = 1.0f / sum;
+            for (int j = 0; j < F; ++j) myS[j] = (float)(half_t)(myS[j] * inv);  // P is cast to fp16 before P.V
+            for (int c = 0; c < nvec; ++c) {
+                int cc = c0 + c;
+                cc = cc >= cvec ? cc - cvec : cc;
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+                for (int j = 0; j < F; ++j) {
+                    const half8_t vv = fz_ld_h8(vtok + (size_t)j * C + cc * 8);
+                    const float pj = myS[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+                }
+                half8_t ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (half_t)acc[e];
+                fz_st_h8(orow + 8 * c, ov);
+            }
         }
     }
 }
@@ -168,14 +235,23 @@ extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, 
     a.in_stride = kv_row_stride; a.q_stride = q_row_stride; a.out_stride = o_row_stride; a.scale = scale;
     int tpb = TTHREADS / (heads * q_frames);
     if (tpb < 1) tpb = 1;
+    const bool fixed = kv_frames == 8 || kv_frames == 16;  // clip lengths with a register-resident instantiation
+    const size_t score_bytes_lds = fixed ? 0 : (size_t)TTHREADS * kv_frames * sizeof(float);
     const size_t score_bytes = (size_t)TTHREADS * kv_frames * sizeof(float);
     const size_t kv_bytes_per_token = (size_t)2 * kv_frames * heads * head_dim * sizeof(half_t);
     int tpb_lds = tpb;
-    while (tpb_lds > 1 && tpb_lds * kv_bytes_per_token + score_bytes > 48 * 1024) tpb_lds >>= 1;
-    if (tpb_lds * kv_bytes_per_token + score_bytes <= 64 * 1024) {
+    while (tpb_lds > 1 && tpb_lds * kv_bytes_per_token + score_bytes_lds > 40 * 1024) tpb_lds >>= 1;  // 40 KB: four per CU
+    if (tpb_lds * kv_bytes_per_token + score_bytes_lds <= 64 * 1024) {
         a.tok_per_block = tpb_lds;
         dim3 grid((tokens + tpb_lds - 1) / tpb_lds, batch), block(TTHREADS);
-        FZ_LAUNCH(attn_temporal_lds_kernel, grid, block, tpb_lds * kv_bytes_per_token + score_bytes, stream, a);
+        const size_t lds = tpb_lds * kv_bytes_per_token + score_bytes_lds;
+        if (kv_frames == 8) {
+            FZ_LAUNCH(attn_temporal_lds_kernel<8>, grid, block, lds, stream, a);
+        } else if (kv_frames == 16) {
+            FZ_LAUNCH(attn_temporal_lds_kernel<16>, grid, block, lds, stream, a);
+        } else {
+            FZ_LAUNCH(attn_temporal_lds_kernel<0>, grid, block, lds, stream, a);
+        }
         return fz_last_launch_status();
     }
     a.tok_per_block = tpb;

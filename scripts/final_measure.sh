@@ -1,19 +1,21 @@
-# Round-end evidence on one MI355X: GPU parity (QUICK=1: conv kernels + the end-to-end scenarios only), the bench line, the
-# rocprofv3 kernel statistics of the same bench command and the conv sweep against MIOpen.  Run through gpurun from the repo
-# root; results land in gpurun_out/ (copy what is judged into profiles/).
-mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
+# Round-end evidence on one MI355X (run through gpurun from the repo root; results land in gpurun_out/final/, copy what is
+# judged into profiles/ as r02_*_final.*):
+#   QUICK=1 : kernel tests only instead of the full -m gpu suite (the full-width oracle comparisons take ~10 min)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O $R/build_tmp
 if [ "$QUICK" = "1" ]; then
-  timeout 200 python -m pytest tests/test_kernels_gpu.py tests/test_pipeline_gpu.py -x -q -k "conv or pipe or scenario or full" > gpurun_out/gpu_tests.log 2>&1
+  (timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_vae_gpu.py tests/test_clip_text_gpu.py tests/test_cli_gpu.py -x -q) > $O/gpu_tests.log 2>&1
 else
-  timeout 400 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1
+  (timeout 1500 python -m pytest tests -x -q -m gpu) > $O/gpu_tests.log 2>&1
 fi
-tail -2 gpurun_out/gpu_tests.log
-timeout 240 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 1200 gpurun_out/bench.json
+tail -2 $O/gpu_tests.log
+(timeout 400 python bench.py) > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/bench_prof.json 2> $R/gpurun_out/bench_prof.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
 cd $R
-f=$(ls gpurun_out/prof/*/bench_kernel_stats.csv gpurun_out/prof/bench_kernel_stats.csv 2>/dev/null | head -1)
-cp "$f" gpurun_out/kernel_stats.csv 2>/dev/null; head -6 gpurun_out/kernel_stats.csv | cut -c1-120
-rm -rf gpurun_out/prof
-timeout 60 python scripts/kbench.py --conv > gpurun_out/kbench_conv.json 2> /dev/null
+f=$(ls $O/prof/*/bench_kernel_stats.csv $O/prof/bench_kernel_stats.csv 2>/dev/null | head -1)
+cp "$f" $O/kernel_stats.csv 2>/dev/null; head -5 $O/kernel_stats.csv | cut -c1-120
+rm -rf $O/prof
+# PMC of the shipped flash variant (index 1 of scripts/flash_ab.hip built with -DFLASH_AB_OLD) + the A/B table itself
+rm -f $R/build_tmp/flash_ab
+bash scripts/pmc_flash.sh 1 flash_d40_final > /dev/null 2>&1; cp $R/gpurun_out/pmc/flash_d40_final.json $O/pmc_flash_d40_final.json 2>/dev/null
+(timeout 120 $R/build_tmp/flash_ab) > $O/flash_ab.txt 2>&1; cat $O/flash_ab.txt

@@ -86,6 +86,9 @@ def test_cross(mode, d):
 
 def test_temporal():
     KC.case_attn_temporal(DEV, batch=2, clip=3, heads=2, d=40, tokens=10)
+    # clip lengths 8 / 16: register-resident scores, odd tokens' rows rotated in LDS (C = 320: 40 chunks per row)
+    KC.case_attn_temporal(DEV, batch=1, clip=8, heads=8, d=40, tokens=7)
+    KC.case_attn_temporal(DEV, batch=1, clip=16, heads=4, d=16, tokens=5)
 
 
 @pytest.mark.parametrize("span,c,groups", [(2, 80, 16), (1, 64, 8), (3, 320, 32)])

@@ -84,6 +84,9 @@ def test_cross(mode, d, lq):
 def test_temporal():
     KC.case_attn_temporal(DEV, batch=2, clip=8, heads=8, d=40, tokens=300)
     KC.case_attn_temporal(DEV, batch=1, clip=3, heads=2, d=160, tokens=17)
+    KC.case_attn_temporal(DEV, batch=1, clip=16, heads=8, d=80, tokens=1024)
+    KC.case_attn_temporal(DEV, batch=2, clip=8, heads=8, d=160, tokens=256)
+    KC.case_attn_temporal(DEV, batch=1, clip=8, heads=8, d=40, tokens=4096)
 
 
 @pytest.mark.parametrize("span,c,groups,tokens", [(8, 320, 32, 4096), (1, 640, 32, 1024), (4, 2560, 32, 64),
