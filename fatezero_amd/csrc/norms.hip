@@ -8,6 +8,9 @@
 //   gn_stats    : per (frame, token chunk) Welford partials (n, mean, M2) for each group      (reads x once)
 //   gn_finalize : deterministic Chan merge of the partials of a span -> (mean, rstd) per (span, group)
 //   gn_apply    : y = silu?((x - mean) * rstd * gamma + beta)                          (reads x once, writes y)
+// (Both ways of saving the finalize launch were measured and lost: the last-arriving statistics workgroup doing the merge --
+// cross-XCD hand-off latency, 2.4x slower -- and every apply workgroup doing it redundantly -- 1.7x slower even with the
+// group-major partial layout.)
 // Split stats/apply is also the form frame-sharded multi-GPU needs: the finalize step is where the per-rank
 // partials are all-reduced.
 #include "fz_rt.h"
@@ -35,7 +38,7 @@ struct GnArgs {
     const half_t* x;
     half_t* y;
     const half_t *gamma, *beta;
-    float* partial;  // [n_frames][chunks][G][3]
+    float* partial;  // [n_frames][G][chunks][3]: the partials of one (frame, group) are contiguous
     float* stats;    // [n_frames/span][G][2]
     int n_frames, span, tokens, C, G, chunks, V, R;
     int tb;          // tokens per chunk
@@ -130,7 +133,7 @@ FZ_KERNEL void gn_stats_kernel(GnArgs a) {
         float m2 = 0.0f;
         for (int rr = 0; rr < a.R; ++rr)
             for (int c = tid * cg; c < (tid + 1) * cg; ++c) m2 += red[rr * a.C + c];
-        float* out = a.partial + (((int64_t)n * a.chunks + chunk) * a.G + tid) * 3;
+        float* out = a.partial + (((int64_t)n * a.G + tid) * a.chunks + chunk) * 3;
         out[0] = cnt;
         out[1] = gmean[tid];
         out[2] = m2;
@@ -147,16 +150,30 @@ FZ_DEVICE void chan_merge(float& cnt, float& mean, float& m2, float nb, float mb
     }
 }
 
-FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
-    // one wave per (span, group): each lane Chan-merges a strided subset of the span's partials, then a fixed
-    // xor-butterfly merges the 64 lane results (deterministic order -> bitwise reproducible statistics)
-    const int idx = blockIdx.x, lane = threadIdx.x;
-    const int sp = idx / a.G, g = idx % a.G;
+// (span sp, group g) -> (mean, rstd): each lane of ONE full wave Chan-merges a strided subset of the span's partials, then a
+// fixed xor-butterfly merges the 64 lane results (deterministic order -> bitwise reproducible statistics, whoever runs it)
+FZ_DEVICE void gn_finalize_group(const GnArgs& a, int sp, int g, int lane, float* mean_out, float* rstd_out) {
     const int total = a.fin_span * a.chunks;
     float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
-    for (int e = lane; e < total; e += 64) {
-        const int f = e / a.chunks, c = e % a.chunks;
-        const float* pp = a.partial + (((int64_t)(sp * a.fin_span + f) * a.chunks + c) * a.G + g) * 3;
+    // partial records of (frame f, group g) are contiguous: consecutive lanes read consecutive 12-byte records; four records
+    // per lane are in flight before the first merge (the merge chain is serial, the loads must not be)
+    auto rec = [&](int e) -> const float* {
+        const int f = e / a.chunks, c = e - f * a.chunks;
+        return a.partial + (((int64_t)(sp * a.fin_span + f) * a.G + g) * a.chunks + c) * 3;
+    };
+    int e = lane;
+    for (; e + 192 < total; e += 256) {
+        float r[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* pp = rec(e + 64 * u);
+            r[u][0] = pp[0]; r[u][1] = pp[1]; r[u][2] = pp[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan_merge(cnt, mean, m2, r[u][0], r[u][1], r[u][2]);
+    }
+    for (; e < total; e += 64) {
+        const float* pp = rec(e);
         chan_merge(cnt, mean, m2, pp[0], pp[1], pp[2]);
     }
 #pragma unroll
@@ -168,10 +185,18 @@ FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
         chan_merge(c0, me0, q0, c1, me1, q1);
         cnt = c0; mean = me0; m2 = q0;
     }
-    if (lane == 0) {
-        const float var = m2 / cnt;  // biased, as torch.nn.GroupNorm
-        a.stats[idx * 2 + 0] = mean;
-        a.stats[idx * 2 + 1] = 1.0f / sqrtf(var + a.eps);
+    const float var = m2 / cnt;  // biased, as torch.nn.GroupNorm
+    *mean_out = mean;
+    *rstd_out = 1.0f / sqrtf(var + a.eps);
+}
+
+FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {  // one wave per (span, group)
+    const int sp = (int)blockIdx.x / a.G, g = (int)blockIdx.x % a.G;
+    float mean, rstd;
+    gn_finalize_group(a, sp, g, (int)threadIdx.x, &mean, &rstd);
+    if (threadIdx.x == 0) {
+        a.stats[(sp * a.G + g) * 2 + 0] = mean;
+        a.stats[(sp * a.G + g) * 2 + 1] = rstd;
     }
 }
 

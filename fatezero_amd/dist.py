@@ -62,14 +62,13 @@ def edit_clips(job: Callable[[int], torch.Tensor], n_clips: int, device) -> Opti
     if world == 1 or not dist.is_initialized():
         return outs
     per = max(len(clips_for_rank(n_clips, world, r)) for r in range(world))
-    shape = None
-    if outs:
-        shape = list(outs[0].shape)
-    shp = [shape]
-    gathered_shapes = [None] * world
-    dist.all_gather_object(gathered_shapes, shp)
-    shape = next(s[0] for s in gathered_shapes if s[0] is not None)
-    dtype = outs[0].dtype if outs else torch.float32
+    # a rank without clips (n_clips < world) learns shape AND dtype of the results from the others: the all_gather below needs
+    # identical buffers on every rank
+    meta = [(list(outs[0].shape), str(outs[0].dtype).replace("torch.", "")) if outs else None]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, meta)
+    shape, dtype_name = next(g[0] for g in gathered if g[0] is not None)
+    dtype = getattr(torch, dtype_name)
     pad = torch.zeros([per] + shape, dtype=dtype, device=device)
     for j, o in enumerate(outs):
         pad[j] = o

@@ -242,12 +242,12 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span:
 
 
 def groupnorm_stats(x: torch.Tensor, *, groups: int) -> torch.Tensor:
-    """Welford partials (count, mean, M2) of this rank's frames: float [N, chunks, G, 3] (fz_groupnorm_stats)."""
+    """Welford partials (count, mean, M2) of this rank's frames: float [N, G, chunks, 3] (fz_groupnorm_stats)."""
     n, tokens, c = x.shape
     assert x.is_contiguous()
     _chk16(x)
     chunks = N.lib().fz_groupnorm_chunks(tokens, c)
-    partial = torch.empty(n, chunks, groups, 3, dtype=torch.float32, device=x.device)
+    partial = torch.empty(n, groups, chunks, 3, dtype=torch.float32, device=x.device)
     N.check(N.lib().fz_groupnorm_stats(_ptr(x), n, tokens, c, groups, _ptr(partial), _stream(x)), "fz_groupnorm_stats")
     return partial
 
@@ -255,11 +255,11 @@ def groupnorm_stats(x: torch.Tensor, *, groups: int) -> torch.Tensor:
 def groupnorm_apply(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, partial_all: torch.Tensor, *, span: int,
                     groups: int, eps: float, silu: bool, out: Optional[torch.Tensor] = None):
     """Normalise the local frames x [N, tokens, C] with statistics merged from partial_all
-    [stat_sets, frames_per_set, chunks, G, 3] (the partials of ALL ranks' frames); frame n uses stat set n // span."""
+    [stat_sets, frames_per_set, G, chunks, 3] (the partials of ALL ranks' frames); frame n uses stat set n // span."""
     n, tokens, c = x.shape
     assert x.is_contiguous() and partial_all.is_contiguous() and partial_all.dtype == torch.float32
     sets, per_set = partial_all.shape[0], partial_all.shape[1]
-    assert n // span == sets and partial_all.shape[2] == N.lib().fz_groupnorm_chunks(tokens, c)
+    assert n // span == sets and partial_all.shape[3] == N.lib().fz_groupnorm_chunks(tokens, c)
     _chk16(x, gamma, beta)
     if out is None:
         out = torch.empty_like(x)

@@ -77,7 +77,10 @@ class UNetPseudo3DConditionModel(nn.Module):
                 add_downsample=not final, resnet_eps=norm_eps, resnet_groups=norm_num_groups,
                 cross_attention_dim=cross_attention_dim, attn_num_head_channels=attention_head_dim[i],
                 model_config=model_config))
-        assert mid_block_type == "UNetMidBlockPseudo3DCrossAttn"
+        # the reference ignores `mid_block_type` (unet_3d_condition.py:167-181 always builds the cross-attention mid block), so a
+        # 2-D config.json of a newer diffusers ("UNetMidBlock2DCrossAttn") loads there -- and here
+        if only_cross_attention not in (False, None) or downsample_padding != 1:
+            raise NotImplementedError("only_cross_attention / downsample_padding != 1 are not used by any SD-1.x checkpoint")
         self.mid_block = UNetMidBlockPseudo3DCrossAttn(
             in_channels=block_out_channels[-1], temb_channels=time_embed_dim, resnet_eps=norm_eps,
             output_scale_factor=mid_block_scale_factor, cross_attention_dim=cross_attention_dim,

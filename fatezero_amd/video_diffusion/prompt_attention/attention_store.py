@@ -274,8 +274,15 @@ class AttentionStore(AttentionControl):
             self.attention_store_all_step = []
             self._all_step_maps = []
             self._step_maps = {k: [] for k in KEYS}
+            self.attention_store = {}
+            self.latents_store = []
+            if hasattr(self, "_sum_storage"):
+                self._sum_storage = None
             arena.cur = None
             arena.release()
+            # tensors handed out earlier (attention_store_all_step views, CapturedMap.storage) alias the released block and are
+            # invalid from here on; a store that is used again reserves a fresh arena instead of allocating per step
+            self.arena = type(arena)()
 
     def __del__(self):
         try:

@@ -136,8 +136,8 @@ int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, in
                  int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream);
 
 /* The two halves of fz_groupnorm for statistics that span frames living on several GPUs:
- *   fz_groupnorm_stats  writes this rank's Welford partials  partial[n_frames][chunks][G][3] = (count, mean, M2);
- *   (the caller all-gathers them over the ranks and orders them [stat_sets][frames_per_set][chunks][G][3])
+ *   fz_groupnorm_stats  writes this rank's Welford partials  partial[n_frames][G][chunks][3] = (count, mean, M2);
+ *   (the caller all-gathers them over the ranks and orders them [stat_sets][frames_per_set][G][chunks][3])
  *   fz_groupnorm_apply  Chan-merges partial_all per (stat set, group) in a fixed order -- bitwise identical on every
  *                       rank -- into stats[stat_sets][G][2] (scratch) and normalises the local frames:
  *                       frame n uses stat set n / span, so n_frames / span must equal stat_sets. */
