@@ -226,6 +226,8 @@ def install_timers(K, timer):
         rows = x.numel() // x.shape[-1]
         if rows < 1024:
             return None
+        if w is None:  # LayerNorm folded into the projection (fz_gemm_ln): the weights travel in `ln`
+            w = kw["ln"].w
         return ("gemm", 2.0 * rows * x.shape[-1] * w.shape[0], 0)
     timer.wrap(K, "gemm", sel_gemm)
 

@@ -59,11 +59,18 @@ class FzGemmDesc(C.Structure):
     ]
 
 
+class FzGemmLn(C.Structure):
+    _fields_ = [("stats_in", C.c_void_p), ("c1", C.c_void_p), ("c0", C.c_void_p), ("eps", C.c_float), ("reserved0", C.c_int32),
+                ("stats_out", C.c_void_p)]
+
+
 FZ_GEMM_PLAIN, FZ_GEMM_GEGLU = 0, 1
+FZ_GEMM_NO_STATS = 1
 
 _P = C.c_void_p
 _SIGS = {
     "fz_gemm": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fz_gemm_ln": (C.c_int, [C.POINTER(FzGemmDesc), C.POINTER(FzGemmLn), _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_gemm_workspace_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "fz_attn_self": (C.c_int, [C.POINTER(FzAttnSelfDesc), _P, _P, _P, _P, _P, _P, _P]),
     "fz_attn_cross": (C.c_int, [C.POINTER(FzAttnCrossDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

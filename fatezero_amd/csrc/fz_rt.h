@@ -51,10 +51,19 @@ FZ_DEVICE f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
 FZ_DEVICE int fz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // keeps a rarely taken branch a branch (hipcc otherwise if-converts it into per-use v_cndmask on the common path)
 #define FZ_COLD_PATH() asm volatile("" ::: "memory")
+#define FZ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* the scheduler moves nothing across: keeps unrolled loads from piling up */
 FZ_DEVICE float fz_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE int fz_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE float fz_shfl(float v, int lane) { return __shfl(v, lane, 64); }
 FZ_DEVICE unsigned long long fz_ballot(int pred) { return __ballot(pred); }
+// sum over each aligned group of 8 lanes, result in all 8, by DPP (VALU only -- no ds_bpermute round trip): quad_perm
+// [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror; a fixed association order
+FZ_DEVICE float fz_sum8(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
 // max over the lane pair (l, l^32) without touching LDS: v_permlane32_swap (gfx950) instead of ds_bpermute
 FZ_DEVICE float fz_pair_max32(float v) {
     const unsigned u = __float_as_uint(v);
@@ -156,6 +165,7 @@ static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
 }
 static inline int fz_uniform(int v) { return v; }
 #define FZ_COLD_PATH() ((void)0)
+#define FZ_SCHED_FENCE() ((void)0)
 static inline float fz_shfl_xor(float v, int mask) {
     float all[64];
     fz_emu::wave_exchange(&v, all, sizeof(float));
@@ -179,6 +189,14 @@ static inline unsigned long long fz_ballot(int pred) {
     return m;
 }
 static inline float fz_pair_max32(float v) { return fmaxf(v, fz_shfl_xor(v, 32)); }
+static inline float fz_sum8(float v) {  // same association order as the DPP form: xor 1, xor 2, mirror within 8
+    v += fz_shfl_xor(v, 1);
+    v += fz_shfl_xor(v, 2);
+    float all[64];
+    fz_emu::wave_exchange(&v, all, sizeof(float));
+    const int l = fz_emu::lane_id();
+    return v + all[(l & ~7) | (7 - (l & 7))];
+}
 static inline float fz_exp2(float x) { return exp2f(x); }
 static inline float fz_rcp(float x) { return 1.0f / x; }
 static inline float fz_rsqrt(float x) { return 1.0f / sqrtf(x); }

@@ -42,6 +42,13 @@ struct IgArgs {
     int Cin, taps, kchunks;
     int N, Hi, Wi, Ho, Wo, stride, upsample, fpb;
     int ksplit, tiles_a;
+    // LayerNorm fused around the GEMM (fz_gemm_ln): the B rows are the RAW LayerNorm input, A holds gamma * W
+    const float* ln_in;   // per B row: ln_blocks x (sum, sum of squares) of its 64-channel blocks, or null
+    const float* ln_c1;   // [Ma]: sum_k (gamma W)[a][k]
+    const float* ln_c0;   // [Ma]: sum_k beta_k W[a][k] + bias[a]
+    float ln_eps;
+    int ln_blocks;
+    float* st_out;        // per output row: (Ma / 64) x (sum, sum of squares) of the STORED values, or null
 };
 
 template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU>
@@ -77,7 +84,9 @@ struct IgCfg {
 };
 
 
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU>
+// LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
+// instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
     FZ_DYN_SMEM(raw);
@@ -314,6 +323,55 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
+    // LN instantiation: LayerNorm of the B rows applied to the products, y = rstd (x . gamma W - mean c1) + c0 (lane <-> B row),
+    // and the plain bias as its degenerate case (mean 0, rstd 1, c1 0) -- ONE straight-line pass over the accumulators: with a
+    // branch per form the 320 live accumulators merge from two paths and the register allocator spills 150-360 of them.
+    if constexpr (LN) {
+        const bool has_ln = g.ln_in != nullptr;
+        float mu[TB], rs[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            int64_t px = b0 + (wb * TB + j) * 32 + l31;
+            px = px < g.Nb ? px : g.Nb - 1;
+            const int nblk = has_ln ? g.ln_blocks : 0;
+            const float* sp = g.ln_in + ((int64_t)z * g.Nb + px) * nblk * 2;
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int t = 0; t < nblk; ++t) {  // fixed order: the statistics do not depend on who produced the partials
+                const f32x2 v = *reinterpret_cast<const f32x2*>(sp + 2 * t);
+                s1 += v[0];
+                s2 += v[1];
+            }
+            const float inv_n = 1.0f / (float)(g.ln_blocks * 64);
+            const float m = s1 * inv_n;
+            const float var = fmaxf(s2 * inv_n - m * m, 0.0f);
+            mu[j] = has_ln ? m : 0.0f;
+            rs[j] = has_ln ? fz_rsqrt(var + g.ln_eps) : 1.0f;
+        }
+        const float* zf = reinterpret_cast<const float*>(fz_zero_page);
+        const float* c1p = has_ln ? g.ln_c1 : zf;
+        const float* c0p = has_ln ? g.ln_c0 : zf;
+        const half_t* bp = (!has_ln && g.bias != nullptr) ? g.bias : fz_zero_page;
+        const int ma_f = has_ln ? g.Ma : 0, ma_b = (!has_ln && g.bias != nullptr) ? g.Ma : 0;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = a0 + (wa * TA + i) * 32 + 8 * gq + 4 * hi;  // Ma % 4 == 0 on this path: whole groups of 4
+                const int cf = co < ma_f ? co : 0, cb = co < ma_b ? co : 0;  // absent / out of range -> the zero page's first words
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(c1p + cf);
+                f32x4 c0 = *reinterpret_cast<const f32x4*>(c0p + cf);
+                const half4_t bv = *reinterpret_cast<const half4_t*>(bp + cb);
+                const bool live_f = co < ma_f, live_b = co < ma_b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c0[e] = (live_f ? c0[e] : 0.0f) + (live_b ? (float)bv[e] : 0.0f);
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][4 * gq + e] = rs[j] * (acc[i][j][4 * gq + e] - (live_f ? mu[j] * c1[e] : 0.0f)) + c0[e];
+                FZ_SCHED_FENCE();  // keeps the TA x 4 coefficient loads from being issued up front (160 VGPRs next to the accumulators)
+            }
+    } else
     // bias in fp32 on the accumulators (lane <-> B row, register group gq <-> 4 consecutive A rows 8*gq + 4*hi)
     if (g.bias != nullptr) {
 #pragma unroll
@@ -375,6 +433,57 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             }
         }
         __syncthreads();
+        if (LN && g.st_out != nullptr) {
+            // Row statistics of what is stored (the next LayerNorm's input): 8 lanes per row, one 64-column block per
+            // iteration, the block's sum / sum of squares reduced over the 8 lanes in a fixed order -> one partial per
+            // (row, 64-column block), independent of the tile shape.  (launcher: plain epilogue, vector path, Ma % 64 == 0)
+            constexpr int NBLK = C::CW / 64;
+            for (int rb = wave; rb * 8 < C::RP; rb += C::NW) {
+                const int pl = rb * 8 + (lane >> 3);
+                const int64_t px = b0 + ps * C::RP + pl;
+                const bool rowok = px < g.Nb;
+                const int64_t pxc = rowok ? px : g.Nb - 1;
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    const int ch = blk * 8 + (lane & 7);
+                    const int co = o0 + ch * 8;
+                    const bool ok = rowok && co < g.Ma;
+                    const int coc = co < g.Ma ? co : 0;
+                    const half8_t v = fz_ld_h8(Cs + pl * C::CSTR + ch * 8);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+                    if (R1 != nullptr) {
+                        const half8_t r = fz_ld_h8(R1 + pxc * g.ldres + coc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+                    }
+                    if (R2 != nullptr) {
+                        const half8_t r = fz_ld_h8(R2 + pxc * g.ldres + coc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+                    }
+                    half8_t o;
+                    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = (half_t)f[e];
+                        const float fr = (float)o[e];  // statistics of the rounded value the consumer will read
+                        s1 += fr;
+                        s2 += fr * fr;
+                    }
+                    if (ok) fz_st_h8(Y + px * g.ldy + co, o);
+                    if (!ok) s1 = s2 = 0.0f;
+                    s1 = fz_sum8(s1);
+                    s2 = fz_sum8(s2);
+                    if ((lane & 7) == 0 && ok) {
+                        float* sp = g.st_out + (((int64_t)z * g.Nb + px) * (g.Ma / 64) + (o0 / 64 + blk)) * 2;
+                        sp[0] = s1;
+                        sp[1] = s2;
+                    }
+                }
+            }
+            continue;
+        }
         for (int id = tid; id < C::RP * OCH; id += C::T) {
             const int pl = id / OCH, ch = id - pl * OCH;
             const int64_t px = b0 + ps * C::RP + pl;
@@ -522,7 +631,7 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false>
 static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
@@ -535,14 +644,14 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 #ifndef FZ_EMU
     static bool attr_set = false;  // LDS above 64 KB is an opt-in function attribute, not tuning state
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
         attr_set = true;
     }
 #endif
     dim3 grid((unsigned)nt, (unsigned)g.ksplit, (unsigned)batch), block(C::T);
-    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU>), grid, block, lds, stream, g);
+    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN>), grid, block, lds, stream, g);
     return fz_last_launch_status();
 }
 
@@ -557,20 +666,20 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 //   244222: 256 x 256, 8 waves -- the GEGLU projection (8C = multiples of 256) and generic large shapes
 //   224223: 128 x 256, 8 waves, 3-deep;  222222: 128 x 128, 4 waves, two workgroups per CU
 //   212222:  64 x 128, 4 waves, three workgroups per CU -- small launches and ragged widths
-template <int MODE, bool GEGLU>
+template <int MODE, bool GEGLU, bool LN = false>
 static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
     switch (cfg) {
-        case 244222: return ig_launch<2, 4, 4, 2, 64, 2, MODE, GEGLU>(g, batch, stream);
-        case 224223: return ig_launch<2, 2, 4, 2, 64, 3, MODE, GEGLU>(g, batch, stream);
-        case 222222: return ig_launch<2, 2, 2, 2, 64, 2, MODE, GEGLU>(g, batch, stream);
+        case 244222: return ig_launch<2, 4, 4, 2, 64, 2, MODE, GEGLU, LN>(g, batch, stream);
+        case 224223: return ig_launch<2, 2, 4, 2, 64, 3, MODE, GEGLU, LN>(g, batch, stream);
+        case 222222: return ig_launch<2, 2, 2, 2, 64, 2, MODE, GEGLU, LN>(g, batch, stream);
         default: break;
     }
     if (!GEGLU) {  // odd TA / TA = 1 cannot pair (h, gate) tiles
         switch (cfg) {
-            case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false>(g, batch, stream);
-            case 254122: return ig_launch<2, 5, 4, 1, 64, 2, MODE, false>(g, batch, stream);
-            case 158122: return ig_launch<1, 5, 8, 1, 64, 2, MODE, false>(g, batch, stream);
-            case 212222: return ig_launch<2, 1, 2, 2, 64, 2, MODE, false>(g, batch, stream);
+            case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false, LN>(g, batch, stream);
+            case 254122: return ig_launch<2, 5, 4, 1, 64, 2, MODE, false, LN>(g, batch, stream);
+            case 158122: return ig_launch<1, 5, 8, 1, 64, 2, MODE, false, LN>(g, batch, stream);
+            case 212222: return ig_launch<2, 1, 2, 2, 64, 2, MODE, false, LN>(g, batch, stream);
             default: break;
         }
     }
@@ -609,11 +718,12 @@ static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats,
                                 (double)g.Ma * g.Cin * g.taps) * batch;
     for (const IgTile& t : kTiles) {
         if (geglu && !t.geglu_ok) continue;
+        if (g.st_out != nullptr && (t.ba % 64)) continue;  // row statistics are per 64-column block
         const int nkt = g.taps * fz_ceil_div(g.Cin, t.bk);
         const int64_t tiles = (int64_t)fz_ceil_div(g.Ma, t.ba) * ((g.Nb + t.bb - 1) / t.bb) * batch;
         const double t_step = 2.0 * t.ba * t.bb * t.bk * t.wg_per_cu / (t.rate_pf * 1e15 / 256.0) * 1e6;  // microseconds
         for (int sk = 1; sk <= 32; sk *= 2) {
-            if (sk > 1 && (geglu || g.Ma % 4 || g.Ma_store != g.Ma || nkt / sk < 4 || out_elems * sk > (double)ws_floats)) break;
+            if (sk > 1 && (geglu || g.ln_in != nullptr || g.Ma % 4 || g.Ma_store != g.Ma || nkt / sk < 4 || out_elems * sk > (double)ws_floats)) break;
             const int64_t wgs = tiles * sk;
             const int64_t slots = 256 * t.wg_per_cu;
             const int64_t rounds = (wgs + slots - 1) / slots;
@@ -640,6 +750,12 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         if (ksplit == 0) ksplit = sk;
     }
     if (ksplit == 0) ksplit = 1;
+    if (g.ln_in != nullptr) ksplit = 1;  // the LayerNorm correction lives in the GEMM's own epilogue
+    bool stats_dropped = false;
+    if (g.st_out != nullptr && ksplit > 1) {  // the split-K tail does not compute row statistics: tell the caller
+        g.st_out = nullptr;
+        stats_dropped = true;
+    }
     g.ksplit = ksplit;
     g.part = nullptr;
     if (ksplit > 1) {
@@ -647,12 +763,20 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         if ((int64_t)ksplit * batch * g.Nb * g.Ma > workspace_floats) return FZ_ERR_BAD_ARG;
         g.part = workspace;
     }
-    const int rc = ig_dispatch_cfg<MODE, GEGLU>(cfg, g, batch, stream);
+    int rc;
+    if constexpr (MODE == 0) {
+        rc = (g.ln_in != nullptr || g.st_out != nullptr) ? ig_dispatch_cfg<0, GEGLU, true>(cfg, g, batch, stream)
+                                                         : ig_dispatch_cfg<0, GEGLU>(cfg, g, batch, stream);
+    } else {
+        if (g.ln_in != nullptr || g.st_out != nullptr) return FZ_ERR_UNSUPPORTED;
+        rc = ig_dispatch_cfg<MODE, GEGLU>(cfg, g, batch, stream);
+    }
     if (rc != FZ_OK || ksplit == 1) return rc;
     const int64_t total = g.Nb * (g.Ma / 4) * batch;
     dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
     FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, batch);
-    return fz_last_launch_status();
+    const int rc2 = fz_last_launch_status();
+    return rc2 != FZ_OK ? rc2 : (stats_dropped ? FZ_GEMM_NO_STATS : FZ_OK);
 }
 
 extern "C" int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch) {
@@ -662,8 +786,22 @@ extern "C" int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int 
     return 8 * out < cap ? 8 * out : (2 * out < cap ? cap : 2 * out);
 }
 
+static int gemm_impl(const FzGemmDesc* d, const FzGemmLn* ln, const void* x, const void* w, const void* bias, const void* res,
+                     const void* res2, void* y, void* workspace, void* stream);
+
 extern "C" int fz_gemm(const FzGemmDesc* d, const void* x, const void* w, const void* bias, const void* res, const void* res2,
                        void* y, void* workspace, void* stream) {
+    return gemm_impl(d, nullptr, x, w, bias, res, res2, y, workspace, stream);
+}
+
+extern "C" int fz_gemm_ln(const FzGemmDesc* d, const FzGemmLn* ln, const void* x, const void* w, const void* bias, const void* res,
+                          const void* res2, void* y, void* workspace, void* stream) {
+    if (!ln) return FZ_ERR_BAD_ARG;
+    return gemm_impl(d, ln, x, w, bias, res, res2, y, workspace, stream);
+}
+
+static int gemm_impl(const FzGemmDesc* d, const FzGemmLn* ln, const void* x, const void* w, const void* bias, const void* res,
+                     const void* res2, void* y, void* workspace, void* stream) {
     if (!d || !x || !w || !y || d->rows <= 0 || d->in_features <= 0 || d->out_features <= 0) return FZ_ERR_BAD_ARG;
     const int batch = d->batch > 0 ? d->batch : 1;
     IgArgs g = {};
@@ -695,6 +833,22 @@ extern "C" int fz_gemm(const FzGemmDesc* d, const void* x, const void* w, const 
         g.bias = (const half_t*)bias;
         const int outw = geglu ? d->out_features / 2 : d->out_features;
         if (d->ldy < outw) return FZ_ERR_BAD_ARG;
+        if (ln != nullptr) {
+            if (ln->stats_in != nullptr) {  // x holds the raw LayerNorm input, w holds gamma * W
+                if (!ln->c1 || !ln->c0 || d->in_features % 64 || d->out_features % 64 || d->x_batch_stride % d->ldx) return FZ_ERR_UNSUPPORTED;
+                g.ln_in = ln->stats_in;
+                g.ln_c1 = ln->c1;
+                g.ln_c0 = ln->c0;
+                g.ln_eps = ln->eps;
+                g.ln_blocks = d->in_features / 64;
+                g.bias = nullptr;  // folded into c0
+            }
+            if (ln->stats_out != nullptr) {
+                if (geglu || d->out_features % 64 || (d->ldy % 8) || (d->y_batch_stride % 8) || (g.ldres % 8) || (g.res_bs % 8))
+                    return FZ_ERR_UNSUPPORTED;
+                g.st_out = ln->stats_out;
+            }
+        }
         if (geglu) {
             if (d->out_features % 64 || res || res2) return FZ_ERR_UNSUPPORTED;
             return ig_run<0, true>(g, batch, d->tile_cfg, 1, nullptr, 0, stream);
@@ -702,7 +856,7 @@ extern "C" int fz_gemm(const FzGemmDesc* d, const void* x, const void* w, const 
         return ig_run<0, false>(g, batch, d->tile_cfg, d->split_k, (float*)workspace, d->workspace_floats, stream);
     }
     // y[b][out][row] (V^T): A = x rows of the batch element (row index contiguous in the output), B = W rows
-    if (geglu || bias || res || res2) return FZ_ERR_UNSUPPORTED;
+    if (geglu || bias || res || res2 || ln) return FZ_ERR_UNSUPPORTED;
     if (d->rows >= (1ll << 31)) return FZ_ERR_UNSUPPORTED;
     g.a = (const half_t*)x;
     g.lda = d->ldx;

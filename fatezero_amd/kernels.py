@@ -304,13 +304,42 @@ def _ws_ptr(device):
 _gemm_plans = {}
 
 
+class LnFold:
+    """A LayerNorm folded into the Linear that consumes it (fz_gemm_ln): w = gamma (.) W in fp16, c1 = row sums of that w,
+    c0 = W beta + bias (fp32), eps.  `pack` (optional) reorders rows / per-row vectors the way the GEMM epilogue expects them
+    (pack_geglu for the GEGLU projection)."""
+    __slots__ = ("w", "c1", "c0", "eps")
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                 device, pack=None):
+        w32 = weight.detach().float().cpu()
+        wg = (w32 * gamma.detach().float().cpu()[None, :]).half()
+        c0 = w32 @ beta.detach().float().cpu()
+        if bias is not None:
+            c0 = c0 + bias.detach().float().cpu()
+        c1 = wg.float().sum(1)  # of the ROUNDED weights: what the MFMA actually sums
+        if pack is not None:
+            _, c0 = pack(wg, c0)
+            wg, c1 = pack(wg, c1)
+        self.w = wg.to(device).contiguous()
+        self.c1 = c1.float().to(device).contiguous()
+        self.c0 = c0.float().to(device).contiguous()
+        self.eps = float(eps)
+
+
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
          res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, geglu: bool = False, tile_cfg: int = 0,
-         split_k: int = 0):
+         split_k: int = 0, ln: Optional[LnFold] = None, ln_stats: Optional[torch.Tensor] = None, want_stats: bool = False):
     """y[..., o] = x[..., :] @ w[o, :] + bias (+ res) (+ res2); x: [..., K] with unit channel stride and ONE row stride
     (a channel slice of a token-major tensor is fine); w: [O, K] fp16 (GEGLU: packed by pack_geglu); res / out: [..., O'].
     The descriptor of a call signature (shapes / strides / flags) is validated and built once and then reused: per call only
-    the pointers change."""
+    the pointers change.
+
+    LayerNorm fusion (fz_gemm_ln):  ln + ln_stats -> x is the RAW LayerNorm input, `ln` the folded weights (w is ignored) and
+    ln_stats the per-row block sums [rows, K / 64, 2] its producer wrote;  want_stats=True -> returns (y, stats) where stats are
+    the block sums of y's rows [rows, O / 64, 2] for the next LayerNorm, or None when the library split K for this shape."""
+    if ln is not None:
+        w = ln.w
     key = (x.shape, x.stride(), w.shape, w.stride(0), geglu, tile_cfg, split_k, x.device,
            None if res is None else res.stride(), res2 is not None, None if out is None else (out.shape, out.stride()))
     plan = _gemm_plans.get(key)
@@ -322,12 +351,32 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     ptrs = x.data_ptr() | w.data_ptr() | out.data_ptr()
     if (ptrs & 15) or x.dtype != torch.float16 or w.dtype != torch.float16:
         raise ValueError("fz_gemm operands must be fp16 and 16-byte aligned")
-    rc = N.lib().fz_gemm(d_ref, x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
-                         None if res is None else res.data_ptr(), None if res2 is None else res2.data_ptr(), out.data_ptr(),
-                         _ws_ptr(x.device) if want_ws else None, _stream(x))
-    if rc:
-        N.check(rc, "fz_gemm")
-    return out
+    if ln is None and not want_stats:
+        rc = N.lib().fz_gemm(d_ref, x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                             None if res is None else res.data_ptr(), None if res2 is None else res2.data_ptr(), out.data_ptr(),
+                             _ws_ptr(x.device) if want_ws else None, _stream(x))
+        if rc:
+            N.check(rc, "fz_gemm")
+        return out
+    lnd = N.FzGemmLn()
+    stats = None
+    if ln is not None:
+        rows = x.numel() // x.shape[-1]
+        assert ln_stats is not None and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous()
+        assert ln_stats.numel() == rows * (x.shape[-1] // 64) * 2, (ln_stats.shape, x.shape)
+        lnd.stats_in, lnd.c1, lnd.c0, lnd.eps = ln_stats.data_ptr(), ln.c1.data_ptr(), ln.c0.data_ptr(), ln.eps
+    if want_stats:
+        rows = out.numel() // out.shape[-1]
+        stats = torch.empty(rows, out.shape[-1] // 64, 2, dtype=torch.float32, device=x.device)
+        lnd.stats_out = stats.data_ptr()
+    rc = N.lib().fz_gemm_ln(d_ref, C.byref(lnd), x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                            None if res is None else res.data_ptr(), None if res2 is None else res2.data_ptr(), out.data_ptr(),
+                            _ws_ptr(x.device) if want_ws else None, _stream(x))
+    if rc == N.FZ_GEMM_NO_STATS:
+        stats = None
+    elif rc:
+        N.check(rc, "fz_gemm_ln")
+    return (out, stats) if want_stats else out
 
 
 def _gemm_plan(x, w, bias, res, res2, out, geglu, tile_cfg, split_k):

@@ -52,6 +52,27 @@ def _plan_for(controller, is_cross, place, n, clip, heads, lq, lk, device):
     return None  # foreign controller: generic path
 
 
+# LayerNorm folded into the GEMMs around it (fz_gemm_ln: row statistics from the producing out-projection, correction in the
+# consuming projection's epilogue).  Correct and tested (kernel cases on MI355X, the pipeline with the switch on in
+# tests/test_pipeline_emu.py) but OFF: same-box A/B (scripts/ab_bench.py, profiles/r02_ab_ln_fusion.txt) shows the job 1.1-1.3 %
+# SLOWER with it -- the 30 LayerNorm launches it removes per forward (C <= 640 levels) cost less than the statistics loop and the
+# per-row correction add to the 60 GEMM epilogues.
+LN_FUSION = False
+LN_FUSION_MAX_C = 640  # wider rows (K = 1280) want split-K in the consuming GEMM, which the fused epilogue excludes
+
+
+def _ln_ready(norm, stats, x):
+    """Can the LayerNorm `norm` of x be folded into the Linear that consumes it?  (statistics from the producing GEMM at hand,
+    64-channel blocks, fp16 engine)"""
+    return (LN_FUSION and norm is not None and stats is not None and x.shape[-1] % 64 == 0 and x.shape[-1] <= LN_FUSION_MAX_C
+            and x.dtype == torch.float16)
+
+
+def layer_norm_tokens(norm, x):
+    g, b = norm.packed(x.device)
+    return K.layernorm(x, g, b, eps=norm.eps)
+
+
 class CrossAttention(nn.Module):
     """Parameter container + executor for diffusers' CrossAttention as used by the reference (to_q/to_k/to_v without
     bias, to_out = [Linear, Dropout]); head count = `heads`, scale = dim_head**-0.5."""
@@ -75,6 +96,7 @@ class CrossAttention(nn.Module):
         self._qk_fold = 1.0
         self._qkv = None
         self._ctx_kv = None
+        self._ln_fold = None  # (id of the norm, LnFold): the consuming projection with its LayerNorm folded in
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _qk_weight(self, dtype, device, q_fold=1.0):
@@ -100,11 +122,22 @@ class CrossAttention(nn.Module):
         run_inject(p)
 
     # -- cross attention (attention_register.py:71-128) ------------------------------------------------------
-    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None):
-        """x.data: LayerNorm'ed hidden states [N, L, C]; ctx: [B, 77, Dctx] fp16.  Returns residual + to_out(attention)
-        (the block's `hidden_states = attn2(...) + hidden_states`, attention.py:303-311, fused into the GEMM epilogue)."""
+    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None, norm=None, stats=None, want_stats=False):
+        """x.data: hidden states [N, L, C] -- LayerNorm'ed, or RAW together with (`norm`, `stats` = the row sums their producer
+        wrote): the LayerNorm then rides in the to_q GEMM (fz_gemm_ln); ctx: [B, 77, Dctx] fp16.  Returns residual +
+        to_out(attention) (the block's `hidden_states = attn2(...) + hidden_states`, attention.py:303-311, fused into the GEMM
+        epilogue), plus that result's row statistics when want_stats."""
         n, lq, c = x.data.shape
-        q = self.to_q.apply(x.data)
+        if norm is not None:
+            if _ln_ready(norm, stats, x.data):
+                if self._ln_fold is None or self._ln_fold[0] is not norm or self._ln_fold[1].w.device != x.data.device:
+                    self._ln_fold = (norm, K.LnFold(self.to_q.weight, self.to_q.bias, norm.weight, norm.bias, norm.eps,
+                                                    x.data.device))
+                q = K.gemm(x.data, None, None, ln=self._ln_fold[1], ln_stats=stats)
+            else:
+                q = self.to_q.apply(layer_norm_tokens(norm, x.data))
+        else:
+            q = self.to_q.apply(x.data)
         # K / V^T of the text context depend only on (ctx, weights): the DDIM loops pass the same embedding tensor at
         # every step, so they are projected once per job instead of once per layer call (16 x 100 times per job)
         kvc = self._ctx_kv
@@ -138,16 +171,25 @@ class CrossAttention(nn.Module):
             if plan.n_plain < n:
                 K.attn_cross(q, kk, vt, out, mode=plan.mode, frame0=plan.n_plain, n_frames=n - plan.n_plain, p=plan.p,
                              mapper_t=plan.mapper_t, coef=plan.coef, cur_out=plan.cur_out, **kw)
-        return self.to_out[0].apply(out, res=residual)
+        return self.to_out[0].apply(out, res=residual, want_stats=want_stats)
 
     # -- temporal attention (attention.py:327-337; never controlled, attention_register.py:242) ---------------
-    def forward_temporal(self, x_norm, batch: int, clip: int, residual=None):
-        """x_norm: [B*F, L, C] LayerNorm'ed; attention over the F frames of every (b, token); + residual in the epilogue."""
+    def forward_temporal(self, x_norm, batch: int, clip: int, residual=None, norm=None, stats=None):
+        """x_norm: [B*F, L, C] LayerNorm'ed -- or RAW with (`norm`, `stats`): the LayerNorm then rides in the fused q/k/v GEMM;
+        attention over the F frames of every (b, token); + residual in the epilogue."""
         n, l, c = x_norm.shape
-        if self._qkv is None or self._qkv.device != x_norm.device:
-            self._qkv = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device),
-                                   self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0).contiguous()
-        qkv = K.gemm(x_norm, self._qkv)
+        if norm is not None and not _ln_ready(norm, stats, x_norm):
+            x_norm, norm = layer_norm_tokens(norm, x_norm), None
+        if norm is not None:
+            if self._ln_fold is None or self._ln_fold[0] is not norm or self._ln_fold[1].w.device != x_norm.device:
+                wcat = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach(), self.to_v.weight.detach()], 0)
+                self._ln_fold = (norm, K.LnFold(wcat, None, norm.weight, norm.bias, norm.eps, x_norm.device))
+            qkv = K.gemm(x_norm, None, None, ln=self._ln_fold[1], ln_stats=stats)
+        else:
+            if self._qkv is None or self._qkv.device != x_norm.device:
+                self._qkv = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device),
+                                       self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0).contiguous()
+            qkv = K.gemm(x_norm, self._qkv)
         inner = self.inner_dim
         out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
         shard = D.active_shard()
@@ -165,6 +207,7 @@ class CrossAttention(nn.Module):
         self._qk = None
         self._qkv = None
         self._ctx_kv = None
+        self._ln_fold = None
         return super().load_state_dict(*a, **k)
 
 
@@ -201,7 +244,7 @@ def _sharded_kv(shard, kk, vt, batch, clip, index_list):
 class SparseCausalAttention(CrossAttention):
     """attention.py:340-422 / attention_register.py:131-218: frame f attends the K/V of frames idx_j(f)."""
 
-    def forward_self(self, x: Tokens, clip: int, index_list, residual=None):
+    def forward_self(self, x: Tokens, clip: int, index_list, residual=None, want_stats=False):
         n, lq, c = x.data.shape
         xn = x.data
         # head dims with a free MFMA contraction slot (SD-1.x: 40): the softmax scale and log2(e) go into Wq, q comes out of
@@ -243,7 +286,7 @@ class SparseCausalAttention(CrossAttention):
                                 row_mask=plan.row_mask, **rest, **kw)
                 elif not (plan.mode == K.FZ_ATTN_FLASH and plan.capture_first is not None):
                     K.attn_self(q, kk, vt, out, mode=plan.mode, p=plan.p, **rest, **kw)
-        return self.to_out[0].apply(out, res=residual)
+        return self.to_out[0].apply(out, res=residual, want_stats=want_stats)
 
 
 class _GEGLU(nn.Module):
@@ -267,22 +310,27 @@ class FeedForward(nn.Module):
     def __init__(self, dim, mult=4):
         super().__init__()
         self.net = nn.ModuleList([_GEGLU(dim, dim * mult), nn.Identity(), _LinearParams(dim * mult, dim)])
+        self._ln_fold = None
 
-    def apply(self, x, res=None):
+    def apply(self, x, res=None, norm=None, stats=None, want_stats=False):
         """res + Linear(h * gelu(gate)): the 8C-wide GEGLU intermediate is never written (gate applied in the epilogue of the
-        projection GEMM), the residual add rides in the epilogue of the output GEMM."""
+        projection GEMM), the residual add rides in the epilogue of the output GEMM.  x: LayerNorm'ed, or RAW with
+        (`norm`, `stats`) -- the LayerNorm then rides in the projection GEMM as well (fz_gemm_ln)."""
         g = self.net[0]
-        if g.proj.weight.shape[0] % 64 == 0:
+        fused = g.proj.weight.shape[0] % 64 == 0
+        if norm is not None and not (fused and _ln_ready(norm, stats, x)):
+            x, norm = layer_norm_tokens(norm, x), None
+        if norm is not None:
+            if getattr(self, "_ln_fold", None) is None or self._ln_fold[0] is not norm or self._ln_fold[1].w.device != x.device:
+                self._ln_fold = (norm, K.LnFold(g.proj.weight, g.proj.bias, norm.weight, norm.bias, norm.eps, x.device,
+                                                pack=K.pack_geglu))
+            h = K.gemm(x, None, None, geglu=True, ln=self._ln_fold[1], ln_stats=stats)
+        elif fused:
             w, b = g.packed(x.dtype, x.device)
             h = K.gemm(x, w, b, geglu=True)
         else:
             h = K.geglu(g.proj.apply(x))
-        return self.net[2].apply(h, res=res)
-
-
-def layer_norm_tokens(norm: _NormParams, x):
-    g, b = norm.packed(x.device)
-    return K.layernorm(x, g, b, eps=norm.eps)
+        return self.net[2].apply(h, res=res, want_stats=want_stats)
 
 
 class SpatioTemporalTransformerBlock(nn.Module):
@@ -312,11 +360,16 @@ class SpatioTemporalTransformerBlock(nn.Module):
     def forward_tokens(self, x: Tokens, ctx):
         hs = x.data
         clip = x.f
-        # every `x = f(norm(x)) + x` of attention.py:295-337 ends in a GEMM: the residual add is that GEMM's epilogue
-        hs = self.attn1.forward_self(x.like(layer_norm_tokens(self.norm1, hs)), clip, self.sc_index, residual=hs)
-        hs = self.attn2.forward_cross(x.like(layer_norm_tokens(self.norm2, hs)), ctx, clip, residual=hs)
-        hs = self.ff.apply(layer_norm_tokens(self.norm3, hs), res=hs)
-        hs = self.attn_temporal.forward_temporal(layer_norm_tokens(self.norm_temporal, hs), x.b, clip, residual=hs)
+        # every `x = f(norm(x)) + x` of attention.py:295-337 ends in a GEMM: the residual add is that GEMM's epilogue -- and
+        # so are the row statistics of the result, which let norm2 / norm3 / norm_temporal ride inside the GEMM that consumes
+        # them (fz_gemm_ln; `st` is None where that form does not apply and the LayerNorm kernel runs instead).  norm1 stays a
+        # kernel: its output also feeds the transposed V projection.
+        hs, st = self.attn1.forward_self(x.like(layer_norm_tokens(self.norm1, hs)), clip, self.sc_index, residual=hs,
+                                         want_stats=LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C)
+        want = LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C
+        hs, st = self.attn2.forward_cross(x.like(hs), ctx, clip, residual=hs, norm=self.norm2, stats=st, want_stats=want)
+        hs, st = self.ff.apply(hs, res=hs, norm=self.norm3, stats=st, want_stats=want)
+        hs = self.attn_temporal.forward_temporal(hs, x.b, clip, residual=hs, norm=self.norm_temporal, stats=st)
         return x.like(hs)
 
 

@@ -196,10 +196,15 @@ class _LinearParams(nn.Module):
                             None if self.bias is None else self.bias.detach().to(device=device, dtype=dtype))
         return self._packed
 
-    def apply(self, x, res=None):
-        """x @ W^T + b (+ res) through fz_gemm (csrc/igemm.hip)."""
+    def apply(self, x, res=None, want_stats=None):
+        """x @ W^T + b (+ res) through fz_gemm (csrc/igemm.hip).  want_stats (True / False; None = plain call returning y): returns (y, stats) with the per-row block sums of
+        y for a LayerNorm fused into the NEXT Linear (fz_gemm_ln), or (y, None) where that form does not apply."""
         w, b = self.packed(x.dtype, x.device)
-        return K.gemm(x, w, b, res=res)
+        if want_stats is None:
+            return K.gemm(x, w, b, res=res)
+        if not want_stats or w.shape[0] % 64 or x.dtype != torch.float16:
+            return K.gemm(x, w, b, res=res), None
+        return K.gemm(x, w, b, res=res, want_stats=True)
 
 
 class ResnetBlockPseudo3D(nn.Module):

@@ -115,7 +115,7 @@ class UNetPseudo3DConditionModel(nn.Module):
     def invalidate_packed(self):
         self._temb_pack = None
         for m in self.modules():
-            for a in ("_packed", "_qk", "_qkv", "_ctx_kv"):
+            for a in ("_packed", "_qk", "_qkv", "_ctx_kv", "_ln_fold"):
                 if hasattr(m, a):
                     setattr(m, a, None)
 

@@ -182,6 +182,28 @@ int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch);
 int fz_gemm(const FzGemmDesc* desc, const void* x, const void* w, const void* bias, const void* res, const void* res2,
             void* y, void* workspace, void* stream);
 
+/* LayerNorm fused around fz_gemm (the `norm2 / norm3 / norm_temporal` + Linear pairs of SpatioTemporalTransformerBlock,
+ * attention.py:295-337: `attn(norm(x)) + x`).  Two independent halves:
+ *   stats_out  the GEMM that PRODUCES a LayerNorm input (out-projection + residual) also writes, per output row, the sum and the
+ *              sum of squares of every 64-column block of what it stores: float [batch * rows][out_features / 64][2].
+ *              Plain epilogue, out_features % 64 == 0, 16-byte aligned rows.  When the library splits K for this shape the
+ *              statistics are NOT written and the call returns FZ_GEMM_NO_STATS (> 0; y is complete): run fz_layernorm.
+ *   stats_in   the GEMM that CONSUMES a LayerNorm output reads the RAW input x instead, with w = gamma (.) W (fp16),
+ *              c1[o] = sum_k w[o][k], c0[o] = sum_k beta[k] W[o][k] + bias[o] (float; the `bias` argument is ignored):
+ *              y = rstd (x . w - mean c1) + c0, mean / rstd from stats_in [batch * rows][in_features / 64][2] summed in a
+ *              fixed order.  Plain or GEGLU epilogue (c1 / c0 in the packed row order), in_features and out_features % 64 == 0. */
+#define FZ_GEMM_NO_STATS 1
+typedef struct FzGemmLn {
+    const float* stats_in;
+    const float* c1;
+    const float* c0;
+    float eps;
+    int32_t reserved0;
+    float* stats_out;
+} FzGemmLn;
+int fz_gemm_ln(const FzGemmDesc* desc, const FzGemmLn* ln, const void* x, const void* w, const void* bias, const void* res,
+               const void* res2, void* y, void* workspace, void* stream);
+
 /* 3x3 convolution (pad 1) of PseudoConv3d's spatial part (resnet.py:57-64) on token-major activations, as an MFMA
  * implicit GEMM with the elementwise tail fused: y = conv(x) + bias (+ temb[n / frames_per_batch]) (+ res).
  * x: [n][hi][wi][cin]; wt: weights packed [cout][3*3][cin]; y / res: [n][ho][wo][cout]; temb: n/frames_per_batch rows of

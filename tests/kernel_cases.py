@@ -452,6 +452,54 @@ def case_gemm(device, *, rows, k, o, bias=True, n_res=0, geglu=False, ldx_extra=
     return {"max_err": err}
 
 
+def case_gemm_ln(device, *, rows, c, o, geglu=False, n_res=1, tile_cfg=0, seed=0, mean_shift=0.0):
+    """LayerNorm fused around fz_gemm (fz_gemm_ln): a producer GEMM (out-projection + residual) that also emits the row
+    statistics of what it stores, and a consumer GEMM that reads the RAW rows with the LayerNorm folded into its weights and
+    epilogue -- against fp32 torch  LN(y1) @ W^T + b  on the fp16 y1 the producer stored."""
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(rows, c, generator=g).half().to(device)
+    w0 = (torch.randn(c, c, generator=g) * c ** -0.5).half()
+    b0 = (torch.randn(c, generator=g) * 0.3 + mean_shift).half()
+    res = [torch.randn(rows, c, generator=g).half().to(device) for _ in range(n_res)]
+    y1, st = K.gemm(x0, w0.to(device), b0.to(device), res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None,
+                    want_stats=True, tile_cfg=tile_cfg)
+    ref1 = x0.float().cpu() @ w0.float().t() + b0.float()
+    for r in res:
+        ref1 = ref1 + r.float().cpu()
+    e1 = (y1.float().cpu() - ref1).abs().max().item()
+    assert e1 < 4e-3 * max(1.0, float(ref1.abs().max())), e1
+    # consumer
+    gamma = 1.0 + 0.2 * torch.randn(c, generator=g)
+    beta = 0.1 * torch.randn(c, generator=g)
+    w1 = (torch.randn(o, c, generator=g) * c ** -0.5).half()
+    b1 = (torch.randn(o, generator=g) * 0.3).half()
+    eps = 1e-5
+    ow = o // 2 if geglu else o
+    if st is None:
+        # the library split K for the producer (long K, few rows; only with a GPU workspace): no statistics, y1 complete --
+        # the host then runs the LayerNorm kernel and the plain GEMM (models/attention.py does exactly this)
+        assert c >= 1024, "statistics may only be dropped for split-K shapes"
+        xn_dev = K.layernorm(y1, gamma.half().to(device), beta.half().to(device), eps=eps)
+        wd, bd = K.pack_geglu(w1, b1) if geglu else (w1, b1)
+        y2 = K.gemm(xn_dev, wd.to(device), bd.to(device), geglu=geglu)
+    else:
+        assert st.shape == (rows, c // 64, 2)
+        blocks = y1.float().cpu().view(rows, c // 64, 64)
+        assert torch.allclose(st[..., 0].cpu(), blocks.sum(-1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(st[..., 1].cpu(), (blocks * blocks).sum(-1), rtol=1e-5, atol=1e-3)
+        ln = K.LnFold(w1, b1, gamma, beta, eps, device, pack=K.pack_geglu if geglu else None)
+        y2 = K.gemm(y1, None, None, geglu=geglu, ln=ln, ln_stats=st)
+    xn = F.layer_norm(y1.float().cpu(), (c,), gamma, beta, eps)
+    ref2 = xn @ w1.float().t() + b1.float()
+    if geglu:
+        ref2 = ref2[:, :ow] * F.gelu(ref2[:, ow:])
+    e2 = (y2.float().cpu() - ref2).abs().max().item()
+    assert y2.shape == (rows, ow) and torch.isfinite(y2.float()).all()
+    # the reference rounds LN(x) to fp16 before the GEMM; here x and gamma*W are the fp16 operands: same size of error
+    assert e2 < 6e-3 * max(1.0, float(ref2.abs().max())), (e2, float(ref2.abs().max()))
+    return {"producer_err": e1, "consumer_err": e2, "fused": st is not None}
+
+
 def case_gemm_vt(device, *, n, l, k, c, lp, tile_cfg=0, seed=0):
     """Transposed-output form: V^T[n][c][lp] = w @ x[n]^T with zero padding of columns [l, lp)."""
     g = torch.Generator().manual_seed(seed)

@@ -166,3 +166,9 @@ def test_temporal_conv3():
 def test_frame_shard_kernel_forms(lo, hi):
     # what a rank owning frames [lo, hi) of a 5-frame clip launches, against the single-GPU kernels on the whole clip
     KC.case_sharded_pieces(DEV, batch=2, clip=5, lo=lo, hi=hi, heads=2, d=40, tokens=64, groups=8)
+
+
+@pytest.mark.parametrize("kw", [dict(rows=70, c=64, o=128), dict(rows=200, c=320, o=320, n_res=2),
+                                dict(rows=96, c=128, o=256, geglu=True), dict(rows=130, c=320, o=640, tile_cfg=212222, mean_shift=2.0)])
+def test_gemm_layernorm_fusion(kw):
+    KC.case_gemm_ln(DEV, **kw)

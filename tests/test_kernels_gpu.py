@@ -183,3 +183,10 @@ def test_temporal_conv3():
 def test_frame_shard_kernel_forms(lo, hi):
     # what a rank owning frames [lo, hi) of a 5-frame clip launches, against the single-GPU kernels on the whole clip
     KC.case_sharded_pieces(DEV, batch=2, clip=5, lo=lo, hi=hi, heads=2, d=40, tokens=256, groups=8)
+
+
+@pytest.mark.parametrize("kw", [dict(rows=32768, c=320, o=320), dict(rows=8192, c=640, o=5120, geglu=True), dict(rows=2048, c=1280, o=3840),
+                                dict(rows=4100, c=320, o=2560, geglu=True, n_res=2, mean_shift=2.0), dict(rows=512, c=1280, o=1280),
+                                dict(rows=1000, c=640, o=640, tile_cfg=212222), dict(rows=1000, c=640, o=640, tile_cfg=244222)])
+def test_gemm_layernorm_fusion(kw):
+    print(KC.case_gemm_ln(DEV, **kw))
