@@ -659,7 +659,9 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 // tiles (320 x 256), K step 64, 2-deep ring.  The kernel template also builds K step 32 and rings up to 4 deep; on MI355X
 // they measured 2-7 % SLOWER than the 2-deep K-step-64 form of the same tile on every shape of the UNet
 // (profiles/r02_kbench_gemm_sweep.json, r02_kbench_conv_sweep.json: the loop is not load-latency-bound), so they are not
-// instantiated.
+// instantiated.  Neither are 4-wave forms with larger wave tiles (320 x 192 as 2 x 2 waves of 5 x 3, 256 x 256 as 2 x 2 of 4 x 4: 24-29 %
+// fewer LDS fragment reads per FLOP, K loop spill-free): with ONE wave per SIMD nothing covers the ds_read latency after each barrier
+// and they ran 510 vs 860 TFLOP/s on the 16-frame 64^2 convolution (profiles/r02_tile_trial_4wave.txt).
 //   254222: 320 x 256, 8 waves -- SD-1.x widths are all multiples of 320: no A-side waste, 142 FLOP per staged byte
 //   254122: 320 x 128, 8 waves -- the same for launches with 4096 < rows <= 32768 (twice the workgroups)
 //   158122: 160 x 256, 8 waves -- the rank-160 down projection of the temporal LoRA convolution (lora.py:31-37)

@@ -49,8 +49,10 @@ struct GnArgs {
 
 // ROWS > 0: the thread's (<= ROWS) rows of the chunk are loaded ONCE, all loads in flight together, and kept in registers
 // for the second sweep; ROWS == 0: rows are re-read (second sweep hits L2) -- wide channel counts that do not fit.
+// (register-resident forms: <= 512 threads, so that 32 rows x 4 VGPRs fit without scratch -- at the default 1024-thread bound the
+// compiler has 128 VGPRs and spilled 56 of them)
 template <int ROWS>
-FZ_KERNEL void gn_stats_kernel(GnArgs a) {
+FZ_KERNEL void __launch_bounds__(ROWS > 0 ? 512 : 1024) gn_stats_kernel(GnArgs a) {
     // two sweeps over the chunk: exact chunk mean first, then sum (x-mean)^2, so the partial variance never suffers the
     // E[x^2]-E[x]^2 cancellation
     FZ_DYN_SMEM(raw);
@@ -234,7 +236,7 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
 
 static void gn_launch_stats(const GnArgs& a, dim3 grid, dim3 block, size_t smem, void* stream) {
     const int rows = (a.tb + a.R - 1) / a.R;  // rows of a chunk per thread
-    if (rows > 32) {
+    if (rows > 32 || block.x > 512) {
         FZ_LAUNCH(gn_stats_kernel<0>, grid, block, smem, stream, a);
     } else if (rows <= 12) {
         FZ_LAUNCH(gn_stats_kernel<12>, grid, block, smem, stream, a);
