@@ -1,6 +1,6 @@
 // fz_emu.cpp -- CPU emulation of the HIP execution model (TEST INFRASTRUCTURE ONLY, see fz_rt.h).
 //
-// One OS thread runs one workgroup at a time; every lane of the workgroup is a fiber with its own
+// A persistent pool of OS threads, each running one workgroup at a time; every lane of the workgroup is a fiber with its own
 // stack, scheduled round-robin and switched only at collectives (__syncthreads, wave exchanges).
 // Deterministic by construction; a missing barrier shows up as a wrong result, not as a flake.
 #ifdef FZ_EMU
@@ -8,8 +8,12 @@
 
 #include <sys/mman.h>
 
+#include <unistd.h>
+
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -64,15 +68,18 @@ struct Worker {
     int wv_arrived[kMaxThreads / 64];
     unsigned wv_gen[kMaxThreads / 64];
     unsigned char* wv_buf = nullptr;  // [waves][64][kSlot]
+    float* mm_buf = nullptr;          // [waves][2 (ping-pong)][kMmFloats]: MFMA operands as fp32 + the transposed A panels
     const std::function<void()>* body = nullptr;
     std::vector<unsigned char> dyn;
     ~Worker();
 };
 static constexpr size_t kSlot = 256;
+static constexpr size_t kMmFloats = 64 * 8 * 2 + 2 * 16 * 16;  // A, B fragments of 64 lanes; A^T[k][16 rows] per lane half
 static thread_local Worker* t_w = nullptr;
 Worker::~Worker() {
     if (stacks) munmap(stacks, kStack * kMaxThreads);
     free(wv_buf);
+    free(mm_buf);
 }
 
 static void yield_to_sched() {
@@ -140,10 +147,59 @@ void wave_exchange(const void* mine, void* all, size_t bytes) {
     const int wave = tid >> 6, lane = tid & 63;
     const int lanes = (w->n - wave * 64) < 64 ? (w->n - wave * 64) : 64;
     unsigned char* buf = w->wv_buf + (size_t)wave * 64 * kSlot;
-    memcpy(buf + lane * kSlot, mine, bytes);
+    if (bytes == 4) {
+        *(uint32_t*)(buf + lane * kSlot) = *(const uint32_t*)mine;
+    } else {
+        memcpy(buf + lane * kSlot, mine, bytes);
+    }
     wave_barrier(wave, lanes);
-    for (int i = 0; i < 64; ++i) memcpy((unsigned char*)all + i * bytes, buf + (i < lanes ? i : 0) * kSlot, bytes);
+    if (bytes == 4 && lanes == 64) {  // shuffles / ballots: the common case, without 64 libc calls per lane
+        for (int i = 0; i < 64; ++i) ((uint32_t*)all)[i] = *(const uint32_t*)(buf + i * kSlot);
+    } else {
+        for (int i = 0; i < 64; ++i) memcpy((unsigned char*)all + i * bytes, buf + (i < lanes ? i : 0) * kSlot, bytes);
+    }
     wave_barrier(wave, lanes);
+}
+
+// v_mfma_f32_32x32x16_f16 for the calling wave.  Fragment semantics (cdna_hip_programming.md section 3):
+//   A[i][k]: lane = i + 32*(k/8), element k%8;  B[k][n]: lane = n + 32*(k/8), element k%8
+//   C/D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// Every lane converts its own fragments to fp32 once, lanes 0 and 32 lay out the 16 A rows their half of the wave owns as
+// A^T[k][reg], and each lane then runs 16 vector FMAs (k ascending: the same summation order as a scalar loop over k).
+// The scratch ping-pongs on the wave's barrier generation: two MFMAs with no other collective between them use different
+// halves, so a lane that runs ahead never overwrites what a slower lane still reads.
+f32x16 mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
+    Worker* w = t_w;
+    const int tid = linear_tid();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lanes = (w->n - wave * 64) < 64 ? (w->n - wave * 64) : 64;
+    if (lanes != 64) __builtin_trap();  // MFMA kernels launch whole waves
+    float* base = w->mm_buf + ((size_t)wave * 2 + ((w->wv_gen[wave] >> 1) & 1)) * kMmFloats;
+    float* A = base;
+    float* B = base + 64 * 8;
+    float* AT = base + 64 * 16;
+    for (int e = 0; e < 8; ++e) {
+        A[lane * 8 + e] = (float)a[e];
+        B[lane * 8 + e] = (float)b[e];
+    }
+    wave_barrier(wave, 64);
+    if ((lane & 31) == 0) {
+        float* at = AT + (lane >> 5) * 256;
+        for (int k = 0; k < 16; ++k)
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                at[k * 16 + r] = A[(row + 32 * (k >> 3)) * 8 + (k & 7)];
+            }
+    }
+    wave_barrier(wave, 64);
+    const float* at = AT + (lane >> 5) * 256;
+    const int col = lane & 31;
+    for (int k = 0; k < 16; ++k) {
+        const float bv = B[(col + 32 * (k >> 3)) * 8 + (k & 7)];
+        const f32x16 av = *reinterpret_cast<const f32x16*>(at + k * 16);
+        c = __builtin_elementwise_fma(av, (f32x16)(bv), c);
+    }
+    return c;
 }
 
 static Worker* get_worker() {
@@ -152,6 +208,7 @@ static Worker* get_worker() {
         w.stacks = (unsigned char*)mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE,
                                         MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         w.wv_buf = (unsigned char*)malloc((kMaxThreads / 64) * 64 * kSlot);
+        w.mm_buf = (float*)aligned_alloc(64, (kMaxThreads / 64) * 2 * kMmFloats * sizeof(float));
         w.fibers.resize(kMaxThreads);
     }
     return &w;
@@ -194,31 +251,90 @@ static void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t smem, c
     }
 }
 
+// Persistent pool of OS threads: each keeps its Worker (fiber stacks mapped and warm) across launches -- spawning the threads per
+// launch cost ~20 ms (mmap + first-touch faults of every fiber stack) on kernels whose emulated work is microseconds.
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    uint64_t job_id = 0;
+    int pending = 0, size = 0;
+    pid_t pid = 0;
+    // the job being run
+    dim3 grid, block;
+    size_t smem = 0;
+    const std::function<void()>* body = nullptr;
+    long total = 0;
+    int limit = 0;  // pool threads with index < limit take blocks
+    std::atomic<long> next{0};
+};
+static Pool* g_pool = nullptr;     // leaked on purpose: its threads are detached and die with the process
+static std::mutex g_launch_mu;     // one launch at a time
+
+static void drain(Pool* p) {
+    Worker* w = get_worker();
+    for (;;) {
+        const long b = p->next.fetch_add(1);
+        if (b >= p->total) break;
+        const dim3& g = p->grid;
+        dim3 bid((unsigned)(b % g.x), (unsigned)((b / g.x) % g.y), (unsigned)(b / ((long)g.x * g.y)));
+        run_block(w, g, p->block, bid, p->smem, *p->body);
+    }
+}
+
+static void pool_thread(Pool* p, int index) {
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_job.wait(lk, [&] { return p->job_id != seen; });
+            seen = p->job_id;
+        }
+        if (index < p->limit) drain(p);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (--p->pending == 0) p->cv_done.notify_one();
+        }
+    }
+}
+
+static Pool* get_pool(int nthreads) {
+    if (g_pool && g_pool->pid == getpid() && g_pool->size >= nthreads) return g_pool;
+    // first launch, a forked child (the parent's threads do not exist here), or a larger FZ_EMU_THREADS: a fresh pool
+    Pool* p = new Pool();
+    p->pid = getpid();
+    p->size = nthreads;
+    for (int i = 0; i < nthreads; ++i) std::thread(pool_thread, p, i).detach();
+    g_pool = p;
+    return p;
+}
+
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
     const long total = (long)grid.x * grid.y * grid.z;
     unsigned hw = std::thread::hardware_concurrency();
     int nthreads = (int)(hw ? hw : 4);
     const char* env = getenv("FZ_EMU_THREADS");
     if (env) nthreads = atoi(env);
-    if (nthreads > total) nthreads = (int)total;
     if (nthreads < 1) nthreads = 1;
-    std::atomic<long> next(0);
-    auto work = [&]() {
-        Worker* w = get_worker();
-        for (;;) {
-            const long b = next.fetch_add(1);
-            if (b >= total) break;
-            dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
-            run_block(w, grid, block, bid, smem, body);
-        }
-    };
-    if (nthreads == 1) {
-        work();
-    } else {
-        std::vector<std::thread> ts;
-        for (int i = 0; i < nthreads; ++i) ts.emplace_back(work);
-        for (auto& t : ts) t.join();
+    std::lock_guard<std::mutex> launch_lk(g_launch_mu);
+    if (nthreads == 1 || total <= 1) {  // the calling thread alone
+        Pool one;
+        one.grid = grid; one.block = block; one.smem = smem; one.body = &body; one.total = total;
+        drain(&one);
+        return;
     }
+    Pool* p = get_pool(nthreads - 1);  // the calling thread works too
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->grid = grid; p->block = block; p->smem = smem; p->body = &body; p->total = total;
+        p->limit = (int)(total - 1 < nthreads - 1 ? total - 1 : nthreads - 1);
+        p->next.store(0);
+        p->pending = p->size;  // every pool thread acknowledges the job, so the next launch cannot overtake a sleeper
+        p->job_id++;
+    }
+    p->cv_job.notify_all();
+    drain(p);
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->pending == 0; });
 }
 
 }  // namespace fz_emu

@@ -123,6 +123,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 void sync_block();                                  // __syncthreads
 void wave_exchange(const void* mine, void* all, size_t bytes);  // gather `bytes` from each of the wave's 64 lanes
 int lane_id();
+f32x16 mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c);        // one wave-wide MFMA (all 64 lane fibers call it)
 }  // namespace fz_emu
 
 #define threadIdx (fz_emu::t_threadIdx)
@@ -146,23 +147,7 @@ static inline void __syncthreads() { fz_emu::sync_block(); }
 // v_mfma_f32_32x32x16_f16 fragment semantics (cdna_hip_programming.md §3):
 //   A[i][k]: lane = i + 32*(k/8), element k%8;  B[k][n]: lane = n + 32*(k/8), element k%8
 //   C/D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
-    struct Pair { half8_t a, b; } mine = {a, b}, all[64];
-    fz_emu::wave_exchange(&mine, all, sizeof(Pair));
-    const int lane = fz_emu::lane_id();
-    const int col = lane & 31;
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float acc = c[r];
-        for (int k = 0; k < 16; ++k) {
-            const float av = (float)all[row + 32 * (k >> 3)].a[k & 7];
-            const float bv = (float)all[col + 32 * (k >> 3)].b[k & 7];
-            acc += av * bv;
-        }
-        c[r] = acc;
-    }
-    return c;
-}
+static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) { return fz_emu::mfma_32x32x16_f16(a, b, c); }
 static inline int fz_uniform(int v) { return v; }
 #define FZ_COLD_PATH() ((void)0)
 #define FZ_SCHED_FENCE() ((void)0)

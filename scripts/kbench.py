@@ -169,6 +169,11 @@ def norms_bench():
         gm, bt = torch.ones(c).half().to(dev), torch.zeros(c).half().to(dev)
         ms = timeit(lambda: K.groupnorm(x, gm, bt, span=F_, groups=32, eps=1e-5, silu=True))
         res[f"groupnorm_n{n}_T{tokens}_C{c}"] = {"ms": ms, "GBps": x.numel() * 2 * 3 / ms / 1e6}
+    for (rows, c) in [(32768, 320), (65536, 320), (8192, 640), (16384, 640), (2048, 1280), (4096, 1280)]:
+        x = torch.randn(rows, c).half().to(dev)
+        gm, bt = torch.ones(c).half().to(dev), torch.zeros(c).half().to(dev)
+        ms = timeit(lambda: K.layernorm(x, gm, bt, eps=1e-5))
+        res[f"layernorm_r{rows}_C{c}"] = {"ms": ms, "GBps": x.numel() * 2 * 2 / ms / 1e6}
     print(json.dumps(res))
 
 

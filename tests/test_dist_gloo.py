@@ -57,7 +57,7 @@ def _worker(rank, world, port, n_clips, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_clips", [2])  # one clip per rank (a ragged 3-over-2 split is covered by test_clip_partition)
+@pytest.mark.parametrize("n_clips", [2, 3])  # one clip per rank; a ragged 3-over-2 split
 def test_two_ranks_match_single_process(n_clips):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -176,7 +176,7 @@ def test_frame_shard_exchanges_three_ranks_ragged():
     _spawn(3, 7, [-1, "first"], False)   # 3 + 2 + 2 frames: a middle rank with two neighbours, ragged all-gather
 
 
-@pytest.mark.parametrize("frames,index_list", [(4, ["mid", 1])])  # [-1, "first"]: the 4-rank / 8-frame case below
+@pytest.mark.parametrize("frames,index_list", [(4, ["mid", 1]), (5, [-1, "first"])])  # 5 frames: ragged 3 + 2 split
 def test_frame_sharded_clip_matches_single_process(frames, index_list):
     got, n_maps, n_local = _spawn(2, frames, index_list, True)
     _, job = _frame_job_factory(frames, index_list)

@@ -15,8 +15,7 @@ def emu_backend():
     _native.reset_backend()
 
 
-# (pipe_f3_mid_next runs in the oracle and GPU suites only, to keep the CPU suite at a few minutes)
-@pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_f4_prev_first"])  # all 7 scenarios run on MI355X (test_pipeline_gpu.py)
+@pytest.mark.parametrize("name", ["pipe_small_replace", "pipe_small_refine_reweight", "pipe_f3_mid_next", "pipe_f4_prev_first"])  # all 7 scenarios run on MI355X (test_pipeline_gpu.py)
 def test_pipeline_small(name):
     res = PC.run_pipeline_case(name, "cpu")
     print(name, res)
