@@ -10,7 +10,7 @@ fi
 tail -2 $O/gpu_tests.log
 (timeout 400 python bench.py) > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo
 cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline --no-kernel-breakdown > $O/bench_prof.json 2> $O/bench_prof.err
 cd $R
 f=$(ls $O/prof/*/bench_kernel_stats.csv $O/prof/bench_kernel_stats.csv 2>/dev/null | head -1)
 cp "$f" $O/kernel_stats.csv 2>/dev/null; head -5 $O/kernel_stats.csv | cut -c1-120
