@@ -662,6 +662,9 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 // instantiated.  Neither are 4-wave forms with larger wave tiles (320 x 192 as 2 x 2 waves of 5 x 3, 256 x 256 as 2 x 2 of 4 x 4: 24-29 %
 // fewer LDS fragment reads per FLOP, K loop spill-free): with ONE wave per SIMD nothing covers the ds_read latency after each barrier
 // and they ran 510 vs 860 TFLOP/s on the 16-frame 64^2 convolution (profiles/r02_tile_trial_4wave.txt).
+// An explicit register double buffer of the MFMA operand fragments (ds_reads of k sub-step kk+1 issued before the MFMAs of kk, fenced)
+// instead of the compiler's read-4 / wait / MFMA-4 bursts measured 3-6 % SLOWER on every conv / GEMM shape, same box
+// (profiles/r02_tile_trial_frag2.txt), and is not in the kernel either.
 //   254222: 320 x 256, 8 waves -- SD-1.x widths are all multiples of 320: no A-side waste, 142 FLOP per staged byte
 //   254122: 320 x 128, 8 waves -- the same for launches with 4096 < rows <= 32768 (twice the workgroups)
 //   158122: 160 x 256, 8 waves -- the rank-160 down projection of the temporal LoRA convolution (lora.py:31-37)

@@ -6,8 +6,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fatezero_amd import kernels as K
+from fatezero_amd import _native, kernels as K
 from kbench import timeit
+
+if os.environ.get("FZ_TRIAL_LIB"):  # an alternative build of the kernel library (same ABI) for a same-box A/B
+    _native.use_test_backend(os.environ["FZ_TRIAL_LIB"])
+    print("library:", os.environ["FZ_TRIAL_LIB"])
 
 CFGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,254222,252322,242422,244222".split(","))]
 dev = "cuda"
