@@ -189,15 +189,22 @@ def build_ref_unet(kind, model_config, seed=0):
     return unet, shapes
 
 
-def gen_unet():
+def gen_unet(only=None):
     meta = {}
+    meta_path = os.path.join(GOLD, "unet_meta.json")
+    if only and os.path.exists(meta_path):  # partial run: keep the other cases' records
+        meta = json.load(open(meta_path))
     cases = [
         ("unet_tiny16_default", "tiny16", {"lora": 16}, 2, 16),
         ("unet_tiny16_mid", "tiny16", {"lora": 16, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 64}, 3, 16),
         ("unet_tiny16_conv1d", "tiny16", {}, 2, 8),  # no 'lora' key: plain temporal Conv1d with bias
         ("unet_tiny40_default", "tiny40", {"lora": 160}, 2, 16),
+        # 576^2 frames (BASELINE cfg5): 72^2 latents -> 5184 / 1296 / 324 / 81 tokens, none of them a multiple of 64 below the top level
+        ("unet_tiny40_l72", "tiny40", {"lora": 160}, 2, 72),
     ]
     for name, kind, mc, F_, L in cases:
+        if only and name not in only:
+            continue
         unet, shapes = build_ref_unet(kind, mc)
         g = torch.Generator().manual_seed(1234)
         x = torch.randn(2, 4, F_, L, L, generator=g)
@@ -219,9 +226,10 @@ def gen_unet():
         save_npz(name + ".npz", x=x, ctx=ctx, y=y, t=np.int64(481))
         meta[name] = {"kind": kind, "model_config": mc, "F": F_, "L": L, "seconds": dt,
                       "state_dict_shapes": shapes if name.endswith("default") or "conv1d" in name else None,
+                      "shapes_from": "unet_tiny40_default" if kind == "tiny40" else "unet_tiny16_default",
                       "map_shapes": shapes_maps, "map_digests": maps}
         print(f"  {name}: {dt:.1f}s  |y|={float(y.abs().mean()):.4f}")
-    with open(os.path.join(GOLD, "unet_meta.json"), "w") as f:
+    with open(meta_path, "w") as f:
         json.dump(meta, f)
 
 
@@ -456,18 +464,21 @@ def gen_pipeline(tok, only=None):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     args = sys.argv[1:]
-    only = set()
-    for a in list(args):  # "pipeline:name1,name2" records just those pipeline scenarios
+    only, only_unet = set(), set()
+    for a in list(args):  # "pipeline:name1,name2" / "unet:name" record just those scenarios
         if a.startswith("pipeline:"):
             only |= set(a.split(":", 1)[1].split(","))
             args[args.index(a)] = "pipeline"
+        if a.startswith("unet:"):
+            only_unet |= set(a.split(":", 1)[1].split(","))
+            args[args.index(a)] = "unet"
     which = set(args) or {"const", "unet", "controller", "pipeline"}
     rec = RecordingTokenizer(load_bpe_tokenizer())
     torch.set_grad_enabled(False)
     if "const" in which:
         print("[const]"); gen_const(rec)
     if "unet" in which:
-        print("[unet]"); gen_unet()
+        print("[unet]"); gen_unet(only_unet or None)
     if "controller" in which:
         print("[controller]"); gen_controller(rec)
     if "pipeline" in which:

@@ -274,7 +274,7 @@ def run_unet_golden(name, device):
     meta = load_json("unet_meta.json")
     m = meta[name]
     g = load_npz(name + ".npz")
-    shapes = m["state_dict_shapes"] or meta["unet_tiny16_default"]["state_dict_shapes"]
+    shapes = m["state_dict_shapes"] or meta[m.get("shapes_from", "unet_tiny16_default")]["state_dict_shapes"]
     unet = UNetPseudo3DConditionModel(sample_size=g["x"].shape[-1], **TINY[m["kind"]], **m["model_config"])
     unet.load_state_dict(procedural_state_dict([(n, tuple(s)) for n, s in shapes]))
     unet = unet.half().to(device).eval()

@@ -48,11 +48,11 @@ def _oracle_unet(meta_case, shapes):
     return O.OracleUNet(procedural_state_dict([(n, tuple(s)) for n, s in shapes]), cfg)
 
 
-@pytest.mark.parametrize("name", ["unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d", "unet_tiny40_default"])
+@pytest.mark.parametrize("name", ["unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d", "unet_tiny40_default", "unet_tiny40_l72"])
 def test_unet_forward_matches_reference(name):
     meta = load_json("unet_meta.json")
     m = meta[name]
-    shapes = m["state_dict_shapes"] or meta["unet_tiny16_default"]["state_dict_shapes"]
+    shapes = m["state_dict_shapes"] or meta[m.get("shapes_from", "unet_tiny16_default")]["state_dict_shapes"]
     unet = _oracle_unet(m, shapes)
     g = load_npz(name + ".npz")
     store = O.StoreController()

@@ -35,7 +35,7 @@ def test_fullwidth_sd15_pipeline_vs_oracle():
     assert _native.loaded_path().endswith("libfatezero_hip.so")
 
 
-@pytest.mark.parametrize("name", ["unet_tiny40_default", "unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d"])
+@pytest.mark.parametrize("name", ["unet_tiny40_default", "unet_tiny40_l72", "unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d"])
 def test_unet_vs_reference_golden(name):
     r = PC.run_unet_golden(name, "cuda")
     print(name, r)
