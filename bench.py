@@ -275,6 +275,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--warmup-ddim-steps", type=int, default=0, help="DDIM steps of the warm-up jobs (0 = same as timed)")
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--latent-size", type=int, default=64,
+                    help="latent height = width (64 = 512^2 frames, the judged configuration; 72 = the 576^2 frames of BASELINE cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", choices=["clips", "frames"], default="clips",
                     help="N > 1: 'clips' = one clip per GPU (weak scaling, latents only on the wire; the default); 'frames' = "
@@ -312,7 +314,8 @@ def main():
     pipe = build_pipeline(device, seed=0)
     by_frames = args.shard == "frames" and world > 1
     g = torch.Generator().manual_seed(1234 + (0 if by_frames else rank))  # frame-sharded: every rank holds the same clip
-    z0 = torch.randn(1, 4, args.frames, 64, 64, generator=g).to(device)
+    L = args.latent_size
+    z0 = torch.randn(1, 4, args.frames, L, L, generator=g).to(device)
     if dist is not None:  # every rank must have built the same model: compare a weight checksum over RCCL
         chk = torch.stack([p.float().sum() for p in list(pipe.unet.parameters())[:8]]).sum().reshape(1)
         ref = chk.clone()
@@ -365,12 +368,15 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = (1 if by_frames else world) * args.frames * args.steps / dt
         roof, others = rooflines(timer.summary())
-        line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)",
+        px = 8 * L
+        judged = args.frames == 8 and L == 64 and args.ddim_steps == 50
+        line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)" if judged else
+                          f"edited frames/sec ({args.frames}f x {px}^2 x {args.ddim_steps} DDIM steps: capture inversion + 1 CFG edit, latents in/out)",
                 "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if by_frames else "weak",
                 "vs_baseline": None,
                 "dtype": "fp16", "data": "synthetic",
-                "config": {"workload": "config/teaser/jeep_posche.yaml shape: 8 x 512x512 (latents 8x64x64x4), "
+                "config": {"workload": f"config/teaser/jeep_posche.yaml shape: {args.frames} x {px}x{px} (latents {args.frames}x{L}x{L}x4), "
                                        f"{args.ddim_steps}-step DDIM inversion with HBM map capture + {args.ddim_steps}-step "
                                        "CFG edit (Replace, blend-masked self-attention), SD-1.x pseudo-3D UNet lora=160, "
                                        "random-init weights",
@@ -380,7 +386,7 @@ def main():
                            "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite,
                            "n_ranks_seen": n_ranks_seen},
                 "roofline": roof, "rooflines": others, "cpu_baseline": None}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and L == 64:  # (the oracle sample is a 512x512 clip)
             try:
                 line["cpu_baseline"] = cpu_baseline(pipe, args.ddim_steps, args.frames)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
@@ -404,7 +410,7 @@ def main():
         fs = None
         try:
             from fatezero_amd import dist as fz_dist
-            zc = torch.randn(1, 4, args.frames, 64, 64, generator=torch.Generator().manual_seed(1234)).to(device)
+            zc = torch.randn(1, 4, args.frames, L, L, generator=torch.Generator().manual_seed(1234)).to(device)
             pipe.frame_shard = fz_dist.FrameShard(args.frames)
             run_job(pipe, zc, 2, device)  # warm-up: RCCL channels, allocator
             barrier()
