@@ -665,6 +665,9 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 // An explicit register double buffer of the MFMA operand fragments (ds_reads of k sub-step kk+1 issued before the MFMAs of kk, fenced)
 // instead of the compiler's read-4 / wait / MFMA-4 bursts measured 3-6 % SLOWER on every conv / GEMM shape, same box
 // (profiles/r02_tile_trial_frag2.txt), and is not in the kernel either.
+// Spreading the LDS-DMA pieces of the next tile over the four MFMA groups of the current one (one basic block, 2 pieces per group)
+// instead of the burst after the barrier: 5-7 % SLOWER on the 5x1 / 2x2 / 1x2 tile kernels, and the second copy of the K-step body
+// spills the 10- and 8-tile waves (profiles/r02_tile_trial_spread_dma.txt).  The burst stays.
 //   254222: 320 x 256, 8 waves -- SD-1.x widths are all multiples of 320: no A-side waste, 142 FLOP per staged byte
 //   254122: 320 x 128, 8 waves -- the same for launches with 4096 < rows <= 32768 (twice the workgroups)
 //   158122: 160 x 256, 8 waves -- the rank-160 down projection of the temporal LoRA convolution (lora.py:31-37)

@@ -45,3 +45,10 @@ for (rows, k, nn) in [(32768, 320, 320), (32768, 320, 1280), (32768, 1280, 320),
         except Exception as e:
             row.append("     err")
     print(f"{rows:6d} {k:5d} {nn:5d} | " + " ".join(row))
+print("temporal conv k=3: frames tokens cin cout | TFLOP/s (library's own choice)")
+for (n, tokens, cin, cout) in [(8, 4096, 320, 160), (8, 4096, 160, 320), (16, 4096, 320, 160), (16, 4096, 160, 320), (8, 1024, 640, 160),
+                                (8, 1024, 160, 640), (16, 256, 1280, 160), (16, 256, 160, 1280)]:
+    x = torch.randn(n, tokens, cin).half().to(dev)
+    wt = (torch.randn(cout, 3, cin) * 0.03).half().to(dev)
+    ms = timeit(lambda: K.temporal_conv3(x, wt, clip_len=8), iters=8, warm=2)
+    print(f"{n:3d} {tokens:5d} {cin:5d} {cout:5d} | {2.0 * n * tokens * cin * cout * 3 / ms / 1e9:8.0f}")
