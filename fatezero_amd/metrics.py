@@ -5,8 +5,12 @@
 * temporal consistency -- mean cosine similarity of the CLIP image embeddings of consecutive frames.
 
 The arithmetic lives here; the encoder is a parameter: anything with `encode_image(list of PIL) -> [F, D]`,
-`encode_text(list of str) -> [P, D]` and a `logit_scale` (the reference uses OpenAI CLIP ViT-B/32, whose weights are not part
-of this repository: `TransformersClipEncoder` wraps a local transformers CLIPModel folder when one is available)."""
+`encode_text(list of str) -> [P, D]` and a `logit_scale`.  `NativeClipEncoder` is the reference's own choice -- OpenAI CLIP
+ViT-B/32 from its `.pt` checkpoint -- on the hand-written kernels (fatezero_amd/clip.py); `TransformersClipEncoder` wraps a local
+transformers CLIPModel folder.  Neither checkpoint is part of this repository (no network here).
+
+    python -m fatezero_amd.metrics --results ./baselines_results/ours --prompts CLIP/bench_clean_prompt.yaml --clip ViT-B-32.pt
+prints what CLIP/frame_acc_tem_con.py:62-94 prints (per-folder rate / consistency, then the dataset averages)."""
 from glob import glob
 from typing import Dict, List, Sequence, Tuple
 
@@ -67,7 +71,7 @@ class TransformersClipEncoder:
         self.model = CLIPModel.from_pretrained(path).eval().to(device)
         self.processor = CLIPProcessor.from_pretrained(path)
         self.device = device
-        self.logit_scale = float(self.model.logit_scale.exp())
+        self.logit_scale = float(self.model.logit_scale.detach().exp())
 
     def encode_image(self, images: List) -> torch.Tensor:
         px = self.processor(images=images, return_tensors="pt")["pixel_values"].to(self.device)
@@ -77,3 +81,58 @@ class TransformersClipEncoder:
         tok = self.processor(text=texts, return_tensors="pt", padding=True)
         return self.model.get_text_features(input_ids=tok["input_ids"].to(self.device),
                                             attention_mask=tok["attention_mask"].to(self.device))
+
+
+class NativeClipEncoder:
+    """OpenAI CLIP on the native kernels (fatezero_amd/clip.py): `clip.load(path)` + `preprocess` + `clip.tokenize`, exactly the
+    calls of CLIP/frame_acc_tem_con.py:8,19-25."""
+
+    def __init__(self, checkpoint: str, device: str = "cuda", bpe_path: str = None):
+        from . import clip
+        self._clip = clip
+        self.model, self.preprocess = clip.load(checkpoint, device=device)
+        self.device, self.bpe_path = device, bpe_path
+        self.logit_scale = float(self.model.logit_scale.detach().exp())
+
+    def encode_image(self, images: List) -> torch.Tensor:
+        return self.model.encode_image(torch.stack([self.preprocess(i) for i in images]).to(self.device))
+
+    def encode_text(self, texts: List[str]) -> torch.Tensor:
+        return self.model.encode_text(self._clip.tokenize(texts, bpe_path=self.bpe_path).to(self.device))
+
+
+def main(argv=None):
+    import argparse
+    import os
+    from .config_driver import load_config
+    ap = argparse.ArgumentParser(description="frame accuracy / temporal consistency of edited clips (CLIP/frame_acc_tem_con.py)")
+    ap.add_argument("--results", default="./baselines_results/ours", help="folder of result folders, one per entry of --prompts")
+    ap.add_argument("--prompts", default="CLIP/bench_clean_prompt.yaml", help="YAML: <folder name>: {source: ..., target: ...}")
+    ap.add_argument("--clip", default="ViT-B/32", help="OpenAI CLIP checkpoint file (or model name under ~/.cache/clip)")
+    ap.add_argument("--bpe", default=None, help="bpe_simple_vocab_16e6.txt.gz (default: FZ_CLIP_BPE or CLIP/clip/ in the working directory)")
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args(argv)
+    prompts = load_config(args.prompts)
+    enc = NativeClipEncoder(args.clip, args.device, args.bpe)
+    folders = sorted(glob(f"{args.results}/*"))
+    rates, cons = [], []
+    for folder in folders:
+        p = prompts[os.path.basename(folder)]
+        rate, con = folder_success(folder, p["source"], p["target"], enc)
+        print(folder)
+        print(f"folder_success_rate {rate}")
+        print(f"folder_temporal_consistency {con}")
+        rates.append(rate)
+        cons.append(con)
+    print("folder_success_rate list :")
+    print(rates)
+    print("folder_temporal_consistency list :")
+    print(cons)
+    n = max(len(rates), 1)
+    print(f"dataset_average_rate {sum(rates) / n}")
+    print(f"dataset_average_tempconst {sum(cons) / n}")
+    return {"dataset_average_rate": sum(rates) / n, "dataset_average_tempconst": sum(cons) / n}
+
+
+if __name__ == "__main__":
+    main()
