@@ -452,6 +452,8 @@ int fz_attn_flash_dispatch(const FzAttnSelfDesc& d, const void* q, const void* k
     // Variant choice is fixed by measurements (profiles/r01_kbench_v0.json, profiles/r02_flash_ab.txt; the
     // 4-stage ring with a barrier every second tile measured 0.1-0.7 % SLOWER than the 2-stage one and is not instantiated):
     // two query blocks per wave at two waves per SIMD once there are >= 512 query rows, four waves per SIMD below.
+    // (s_setprio 1 around the PV -- or the QK and PV -- MFMA clusters: 3 % SLOWER, 764 -> 741 TFLOP/s at 16 frames, same box;
+    // profiles/r02_flash_ab.txt has the numbers.)
     const bool big = d.lq >= 512;  // two query blocks per wave only pay when there are enough rows to fill the chip
     switch (d.head_dim) {
         case 16: return launch_flash<16, 2, 1>(d, q, k, vt, o, stream);
