@@ -369,6 +369,9 @@ def gen_pipeline(tok, only=None):
         ("pipe_f4_prev_first", 0, {"lora": 16}, dict(self_replace_steps=0.5, L=16, no_blend=True, F=4)),
         ("pipe_f3_mid_next", 2, {"lora": 16, "SparseCausalAttention_index": ["mid", 1]},
          dict(self_replace_steps=0.8, L=16, no_blend=True, F=3)),
+        # 576^2 frames (BASELINE cfg5): 72^2 latents.  Only the 18^2 and 9^2 maps are <= 1024 tokens, so `down_cross[2:4]` is EMPTY and
+        # the blend mask comes from three 18^2 maps (spatial_blend.py:78) instead of five 16^2 ones; 36^2 self maps are not replaced
+        ("pipe_l72_replace_blend", 0, {"lora": 16}, dict(self_replace_steps=0.5, blend_self_attention=True, L=72)),
     ]
     for name, ci, mc, ov in scen:
         if only and name not in only:
@@ -446,7 +449,7 @@ def gen_pipeline(tok, only=None):
             ab_frac = float(torch.cat([m.float().flatten() for m in ab.mask_list]).mean())
         # a few captured inversion maps, exactly as stored (step 0 and last), in fp16 to stay small
         m0 = store.attention_store_all_step[0]
-        arrays["inv_step0_down_cross2"] = m0["down_cross"][2].half()
+        arrays["inv_step0_down_cross2"] = m0["down_cross"][min(2, len(m0["down_cross"]) - 1)].half()  # (72^2 latents capture only two)
         arrays["inv_step0_mid_self0"] = m0["mid_self"][0].half()
         save_npz(name + ".npz", **arrays)
         meta[name] = {"F": F_, "L": L, "T": T, "prompt_case": PROMPT_CASES[ci][0], "model_config": mc,

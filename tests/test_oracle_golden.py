@@ -1,6 +1,8 @@
 """Pin oracle/fatezero_oracle.py (the CPU restatement) against vectors produced by the UNMODIFIED
 reference (oracle/gen_golden.py).  CPU only."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -136,7 +138,11 @@ def test_controllers_on_synthetic_maps(tok, case, variant):
 @pytest.mark.slow
 @pytest.mark.parametrize("name", ["pipe_small_replace", "pipe_small_refine_reweight", "pipe_replace_blend",
                                   "pipe_refine_reweight_latentblend", "pipe_refine_noblend", "pipe_f4_prev_first",
-                                  "pipe_f3_mid_next"])
+                                  "pipe_f3_mid_next",
+                                  # 72^2 latents: 80 s of fp32 attention on 8 cores -- run with FZ_FULL_PARITY=1 (green when recorded;
+                                  # the MI355X suite runs this scenario against the same recording AND this oracle every time)
+                                  pytest.param("pipe_l72_replace_blend", marks=pytest.mark.skipif(
+                                      os.environ.get("FZ_FULL_PARITY") != "1", reason="80 s; FZ_FULL_PARITY=1"))])
 def test_pipeline_matches_reference(tok, name):
     meta = load_json("pipeline_meta.json")[name]
     consts = load_json("host_constants.json")[meta["prompt_case"]]

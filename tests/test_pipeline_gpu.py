@@ -16,7 +16,7 @@ def hip_backend():
 
 @pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_small_replace", "pipe_replace_blend",
                                   "pipe_refine_reweight_latentblend", "pipe_refine_noblend", "pipe_f4_prev_first",
-                                  "pipe_f3_mid_next"])
+                                  "pipe_f3_mid_next", "pipe_l72_replace_blend"])
 def test_pipeline(name):
     res = PC.run_pipeline_case(name, "cuda", mixed_oracle=True)
     print(name, res)
