@@ -47,3 +47,35 @@ def test_rooflines_bookkeeping():
     assert abs(byname["igemm_kernel<..,"]["achieved"] - 1000.0) < 1e-6
     cap = [o for o in others if o["bound"] == "hbm"][0]
     assert abs(cap["achieved"] - 2 * 268435456 / 0.2e-3 / 1e9) < 1e-6 and cap["peak"] == 8000.0
+
+
+def _run_bench_ranks(world, extra, timeout=600):
+    """bench.main() under torch.distributed.run with `world` CPU ranks (tests/bench_cpu_harness.py); returns rank 0's JSON line."""
+    import json
+    import subprocess
+    cmd = bench.spawn_command(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--ddim-steps", "2", "--frames", "2",
+                               "--latent-size", "8", "--no-cpu-baseline"] + extra, world)
+    cmd[cmd.index(os.path.join(ROOT, "bench.py"))] = os.path.join(ROOT, "tests", "bench_cpu_harness.py")
+    out = subprocess.run(cmd, check=True, timeout=timeout, capture_output=True, text=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr  # ONE line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_main_two_ranks_clips_and_frame_shard_probe():
+    """Default sharding (one clip per rank, weak scaling) + the opt-in frame-sharded probe, end to end over gloo."""
+    line = _run_bench_ranks(2, ["--frame-shard-probe"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["n_ranks_seen"] == 2
+    assert line["config"]["parallelism"] == "dp2 over clips" and line["config"]["outputs_finite"] is True
+    assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 1 / (line["ms_per_step"] / 1e3)) < 1e-6 * line["value"]  # whole-job frames/s
+    assert line["steps"] == 1 and line["warmup"] == 0 and line["higher_is_better"] is True and line["cpu_baseline"] is None
+    fs = line["frame_sharded"]
+    assert "error" not in fs, fs
+    assert fs["scaling"] == "strong" and fs["outputs_finite"] is True and fs["value"] > 0
+
+
+def test_bench_main_two_ranks_frames_mode():
+    line = _run_bench_ranks(2, ["--shard", "frames", "--no-kernel-breakdown"])
+    assert line["scaling"] == "strong" and line["config"]["parallelism"] == "2-way frame-sharded clip"
+    assert abs(line["value"] - 2 * 1 / (line["ms_per_step"] / 1e3)) < 1e-6 * line["value"]  # ONE clip's frames over the job time
+    assert line["config"]["outputs_finite"] is True
