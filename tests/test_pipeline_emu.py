@@ -15,7 +15,8 @@ def emu_backend():
     _native.reset_backend()
 
 
-@pytest.mark.parametrize("name", ["pipe_small_replace", "pipe_small_refine_reweight", "pipe_f3_mid_next", "pipe_f4_prev_first"])  # all 7 scenarios run on MI355X (test_pipeline_gpu.py)
+# (pipe_small_replace: oracle + MI355X suites only, 37 s here)
+@pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_f3_mid_next", "pipe_f4_prev_first"])  # all 8 scenarios run on MI355X (test_pipeline_gpu.py)
 def test_pipeline_small(name):
     res = PC.run_pipeline_case(name, "cpu")
     print(name, res)
