@@ -161,3 +161,24 @@ def test_reference_prompt_yaml_loads():
     from fatezero_amd.config_driver import load_config
     cfg = load_config(REF_PROMPTS)
     assert cfg["swan_duck"]["source"].startswith("a black swan") and "target" in cfg["swan_cartoon"]
+
+
+def test_reference_import_paths_resolve():
+    """`import clip` with CLIP/ on the path (CLIP/frame_acc_tem_con.py:2) and the script's own file name."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "CLIP"))
+    try:
+        sys.modules.pop("clip", None)
+        clip = importlib.import_module("clip")
+        assert clip.load.__module__ == "fatezero_amd.clip" and "ViT-B/32" in clip.available_models()
+        assert callable(clip.tokenize) and hasattr(clip, "CLIP")
+    finally:
+        sys.path.remove(os.path.join(root, "CLIP"))
+        sys.modules.pop("clip", None)
+    src = open(os.path.join(root, "CLIP", "frame_acc_tem_con.py")).read()
+    assert "fatezero_amd.metrics" in src
+    with pytest.raises(FileNotFoundError):
+        from fatezero_amd import clip as native_clip
+        native_clip.load("ViT-B/32", device="cpu", download_root=os.path.join(root, "no_such_dir"))  # nothing is downloaded here
