@@ -49,10 +49,18 @@ fz_emu_switch:
 static constexpr size_t kStack = 256 * 1024;
 static constexpr int kMaxThreads = 1024;
 
+struct DmaReq {
+    const void* src;
+    void* dst;
+};
+static constexpr int kDmaDepth = 64;  // vmcnt is a 6-bit counter
+
 struct Fiber {
     void* sp = nullptr;
     bool done = false;
     dim3 tid;
+    DmaReq dma[kDmaDepth];  // this lane's LDS-DMA requests in flight, oldest first from dma_head
+    int dma_head = 0, dma_count = 0;
 };
 
 struct Worker {
@@ -110,7 +118,35 @@ static int linear_tid() {
     return (int)((t.z * b.y + t.y) * b.x + t.x);
 }
 
+static bool g_dma_early = false;  // FZ_EMU_DMA=early: requests land at issue (read per launch)
+
+void dma_issue(const void* src16, void* dst16) {
+    Fiber& f = t_w->fibers[t_w->cur];
+    if (g_dma_early) {
+        memcpy(dst16, src16, 16);
+        return;
+    }
+    if (f.dma_count == kDmaDepth) __builtin_trap();  // more than 63 requests outstanding: vmcnt would have wrapped
+    f.dma[(f.dma_head + f.dma_count) % kDmaDepth] = {src16, dst16};
+    f.dma_count++;
+}
+
+void dma_wait(int max_outstanding) {
+    Fiber& f = t_w->fibers[t_w->cur];
+    while (f.dma_count > max_outstanding) {  // requests retire in order
+        const DmaReq& r = f.dma[f.dma_head];
+        memcpy(r.dst, r.src, 16);
+        f.dma_head = (f.dma_head + 1) % kDmaDepth;
+        f.dma_count--;
+    }
+}
+
 void sync_block() {
+    dma_wait(0);
+    sync_block_nodrain();
+}
+
+void sync_block_nodrain() {
     Worker* w = t_w;
     const unsigned gen = w->bar_gen;
     w->bar_arrived++;
@@ -230,6 +266,7 @@ static void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t smem, c
     for (int i = 0; i < n; ++i) {
         Fiber& f = w->fibers[i];
         f.done = false;
+        f.dma_head = f.dma_count = 0;
         f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
         // initial stack: 6 callee-saved slots + return address (fiber_main); keep 16-B alignment at entry
         uintptr_t top = (uintptr_t)(w->stacks + (size_t)(i + 1) * kStack);
@@ -316,6 +353,8 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     if (env) nthreads = atoi(env);
     if (nthreads < 1) nthreads = 1;
     std::lock_guard<std::mutex> launch_lk(g_launch_mu);
+    const char* dma_mode = getenv("FZ_EMU_DMA");
+    g_dma_early = dma_mode && dma_mode[0] == 'e';
     if (nthreads == 1 || total <= 1) {  // the calling thread alone
         Pool one;
         one.grid = grid; one.block = block; one.smem = smem; one.body = &body; one.total = total;

@@ -120,7 +120,10 @@ struct BlockCtx;
 extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local unsigned char* t_dyn_smem;
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
-void sync_block();                                  // __syncthreads
+void sync_block();                                  // __syncthreads (hipcc: waits vmcnt(0) first -> retires the lane's LDS-DMA)
+void sync_block_nodrain();                          // s_barrier alone
+void dma_issue(const void* src16, void* dst16);     // one lane's 16 bytes of an LDS-DMA instruction
+void dma_wait(int max_outstanding);                 // s_waitcnt vmcnt(N) for the calling lane
 void wave_exchange(const void* mine, void* all, size_t bytes);  // gather `bytes` from each of the wave's 64 lanes
 int lane_id();
 f32x16 mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c);        // one wave-wide MFMA (all 64 lane fibers call it)
@@ -185,13 +188,17 @@ static inline float fz_sum8(float v) {  // same association order as the DPP for
 static inline float fz_exp2(float x) { return exp2f(x); }
 static inline float fz_rcp(float x) { return 1.0f / x; }
 static inline float fz_rsqrt(float x) { return 1.0f / sqrtf(x); }
-static inline void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {  // synchronous on the emulator
-    memcpy((unsigned char*)lds_wave_base + 16 * fz_emu::lane_id(), gsrc_lane, 16);
+// LDS-DMA is ASYNCHRONOUS on the emulator too: the 16 bytes are queued per lane and land when the lane's vmcnt wait retires them
+// (the latest moment the hardware allows -- a missing or too-loose fz_wait_vm<N>() reads stale LDS and fails the test); with
+// FZ_EMU_DMA=early in the environment they land at issue (the earliest moment -- a DMA issued before every reader of the recycled
+// buffer passed the barrier corrupts their tile).  Tests run the GEMM / conv cases both ways.
+static inline void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
+    fz_emu::dma_issue(gsrc_lane, (unsigned char*)lds_wave_base + 16 * fz_emu::lane_id());
 }
-static inline void fz_wait_vm0() {}
+static inline void fz_wait_vm0() { fz_emu::dma_wait(0); }
 template <int N>
-static inline void fz_wait_vm() {}
-static inline void fz_barrier_nodrain() { fz_emu::sync_block(); }
+static inline void fz_wait_vm() { fz_emu::dma_wait(N); }
+static inline void fz_barrier_nodrain() { fz_emu::sync_block_nodrain(); }
 static inline void fz_wave_lds_sync() {  // all 64 lane fibers of the wave meet
     int mine = 0, all[64];
     fz_emu::wave_exchange(&mine, all, sizeof(int));

@@ -172,3 +172,16 @@ def test_frame_shard_kernel_forms(lo, hi):
                                 dict(rows=96, c=128, o=256, geglu=True), dict(rows=130, c=320, o=640, tile_cfg=212222, mean_shift=2.0)])
 def test_gemm_layernorm_fusion(kw):
     KC.case_gemm_ln(DEV, **kw)
+
+
+def test_igemm_with_early_landing_dma(monkeypatch):
+    """The emulator's LDS-DMA lands as LATE as the kernel's vmcnt waits allow by default (a too-loose fz_wait_vm<N>() reads stale LDS);
+    FZ_EMU_DMA=early makes it land at issue instead (a DMA issued before every reader of the recycled ring stage passed the barrier
+    corrupts their tile).  Every tile shape and K order of the implicit-GEMM kernel once more under the early model."""
+    monkeypatch.setenv("FZ_EMU_DMA", "early")
+    for tile_cfg, split_k in [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 3), (212222, 1), (158122, 1), (254222, 2)]:
+        KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg, split_k=split_k)
+    for tile_cfg in (0, 254222, 244222, 224223, 212222):
+        KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
+    KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
+    KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)
