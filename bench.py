@@ -15,7 +15,8 @@ N > 1: one rank per GPU over RCCL.  Launched under torch.distributed.run the ran
 weak scaling; RCCL carries only latents: a weights checksum is broadcast-checked and the edited latents are all-gathered
 over xGMI; no collective inside the UNet).  `--shard frames`: ONE clip's frames split over the ranks (strong scaling;
 GroupNorm / K-V / temporal exchanges, fatezero_amd/dist.py).  With N > 1 the clips line carries `n_ranks_seen` from an RCCL
-all-reduce and, with `--frame-shard-probe`, a watchdog-guarded `frame_sharded` measurement (one extra job).
+all-reduce and a watchdog-guarded `frame_sharded` measurement (one extra job after the clips measurement; `--no-frame-shard-probe`
+skips it).
 
 Extra JSON fields: `roofline` for the judged kernel (the 64x64-level fused spatio-temporal flash attention, 4096 x 8192 x
 d=40: algorithmic FLOPs / HIP-event time measured live on the launch stream), `rooflines` = the same for the other
@@ -281,10 +282,9 @@ def main():
     ap.add_argument("--shard", choices=["clips", "frames"], default="clips",
                     help="N > 1: 'clips' = one clip per GPU (weak scaling, latents only on the wire; the default); 'frames' = "
                          "ONE clip's frames split over the GPUs (strong scaling; GroupNorm / K-V / temporal exchanges over RCCL)")
-    ap.add_argument("--frame-shard-probe", action="store_true",
-                    help="N > 1, --shard clips: after the clips measurement, one extra watchdog-guarded frame-sharded job reported under "
-                         "`frame_sharded` (opt-in: the exchange path has never run on a multi-GPU node, and a hard RCCL failure there "
-                         "would take the already-measured clips line down with it)")
+    ap.add_argument("--no-frame-shard-probe", action="store_true",
+                    help="N > 1, --shard clips: skip the extra frame-sharded job reported under `frame_sharded` (it runs AFTER the clips "
+                         "measurement is complete, under a 120 s watchdog that prints the clips line and exits if the exchange path stalls)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # bare `python bench.py --gpus N`: become N ranks
@@ -394,7 +394,7 @@ def main():
 
     # ---- N > 1, clips mode: one more job with ONE clip's frames split over the ranks (SURVEY 8e's natural split), guarded:
     #      if the exchange path stalls the clips line above is still printed (every rank runs the same watchdog)
-    if dist is not None and not by_frames and args.frame_shard_probe and args.frames >= world:
+    if dist is not None and not by_frames and not args.no_frame_shard_probe and args.frames >= world:
         import threading
         done = threading.Lock()
 
@@ -404,7 +404,7 @@ def main():
                     line["frame_sharded"] = {"error": "frame-sharded probe exceeded its time limit"}
                     print(json.dumps(line), flush=True)
                 os._exit(0)
-        dog = threading.Timer(300.0, bail)
+        dog = threading.Timer(120.0, bail)
         dog.daemon = True
         dog.start()
         fs = None
