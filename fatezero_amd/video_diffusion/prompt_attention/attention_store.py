@@ -93,7 +93,14 @@ class MapArena:
         if best is not None:
             return cls._pool.pop(best)
         cls._pool.clear()  # nothing fits: let the allocator have the old blocks back before asking for a bigger one
-        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)
+        except torch.OutOfMemoryError as e:  # e.g. 32 frames x 512^2 x 50 steps with index [-1, 'first']: 299 GB
+            raise RuntimeError(
+                f"the attention-map arena of this job needs {nbytes / 1e9:.1f} GB of HBM in one block and does not fit on {device}: "
+                "the maps are kept on the device by design (the reference's host / disk store is not reproduced) -- use fewer frames or "
+                "DDIM steps, a one-frame SparseCausalAttention_index (e.g. ['mid'] halves the self-attention maps), "
+                "save_self_attention=False, or split the clip's frames over GPUs (fatezero_amd.dist.FrameShard)") from e
 
     def release(self):
         if self.reserved is not None:

@@ -66,3 +66,21 @@ def test_edit_type_none_and_save():
     r = PR.edit_type_none_and_save("cpu")
     print(r)
     PR.check_none_save(r)
+
+
+def test_arena_that_does_not_fit_says_so(monkeypatch):
+    """A job whose map arena exceeds the device memory fails with a message that names the size and the ways out, not a bare OOM."""
+    import torch
+    from fatezero_amd.video_diffusion.prompt_attention.attention_store import MapArena
+    real_empty = torch.empty
+
+    def empty(*a, **k):
+        if k.get("dtype") == torch.uint8 and a and isinstance(a[0], int) and a[0] > 1 << 30:
+            raise torch.OutOfMemoryError("HIP out of memory (simulated)")
+        return real_empty(*a, **k)
+    monkeypatch.setattr(torch, "empty", empty)
+    MapArena._pool.clear()
+    arena = MapArena()
+    arena.first_step_done, arena.step_bytes = True, 6 * (1 << 30)
+    with pytest.raises(RuntimeError, match=r"arena of this job needs 3\d\d\.\d GB"):
+        arena.reserve(49, "cpu")
