@@ -91,6 +91,9 @@ FZ_DEVICE void fz_wait_vm() {
 // the caller orders its own LDS traffic -- fz_wait_vm<N>() before it for DMA'd data, and every ds_read of the buffer being
 // recycled already consumed (an MFMA cannot issue before its LDS operands arrived)
 FZ_DEVICE void fz_barrier_nodrain() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the bare s_barrier: neither vmcnt nor lgkmcnt is drained (gfx950 backs off a barrier with memory operations outstanding), so
+// ds_reads issued before it are still in flight after it -- the compiler's own lgkmcnt wait in front of their first use orders them
+FZ_DEVICE void fz_barrier_raw() { __builtin_amdgcn_s_barrier(); }
 // LDS hand-over INSIDE one wave (lane a's ds_write read by lane b of the same wave): the LDS unit executes a wave's
 // instructions in order, so no s_barrier is needed -- only the compiler has to keep the order
 FZ_DEVICE void fz_wave_lds_sync() {
@@ -199,6 +202,7 @@ static inline void fz_wait_vm0() { fz_emu::dma_wait(0); }
 template <int N>
 static inline void fz_wait_vm() { fz_emu::dma_wait(N); }
 static inline void fz_barrier_nodrain() { fz_emu::sync_block_nodrain(); }
+static inline void fz_barrier_raw() { fz_emu::sync_block_nodrain(); }
 static inline void fz_wave_lds_sync() {  // all 64 lane fibers of the wave meet
     int mine = 0, all[64];
     fz_emu::wave_exchange(&mine, all, sizeof(int));

@@ -24,6 +24,21 @@
 #include "fz_rt.h"
 #include "../../include/fatezero_hip.h"
 
+// trial switches of the ping-pong loop (scripts/build_variant.sh -D...; the shipped library is built without any of them)
+#ifndef FZ_PP_K32
+#define FZ_PP_K32 0
+#endif
+#ifndef FZ_PP_NOSTAGGER
+#define FZ_PP_NOSTAGGER 0
+#endif
+#if defined(FZ_PP_NOPRIO)
+#define FZ_PP_PRIO_HI() ((void)0)
+#define FZ_PP_PRIO_LO() ((void)0)
+#else
+#define FZ_PP_PRIO_HI() fz_setprio_hi()
+#define FZ_PP_PRIO_LO() fz_setprio_lo()
+#endif
+
 FZ_DEVICE_GLOBAL __attribute__((aligned(16))) half_t fz_zero_page[8192];  // 16 KB of zeros (K <= 8128 per tap)
 
 struct IgArgs {
@@ -51,9 +66,12 @@ struct IgArgs {
     float* st_out;        // per output row: (Ma / 64) x (sum, sum of squares) of the STORED values, or null
 };
 
-template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU>
+template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, bool PP = false>
 struct IgCfg {
     static_assert(BK == 32 || BK == 64, "K step of 32 or 64 halves");
+    // PP: the phase-interleaved ("ping-pong") K loop -- two wave groups (wa = 0 / 1: one wave of each per SIMD) staggered by one
+    // barrier, so that one group's MFMA cluster runs while the other group issues fragment reads and LDS-DMA
+    static_assert(!PP || (BK == 32 && NS == 4 && WA == 2 && WA * WB == 8), "ping-pong loop: K step 32, 4 slots, 2 x 4 waves");
     static constexpr int NW = WA * WB, T = 64 * NW;
     static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
     static constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
@@ -86,9 +104,9 @@ struct IgCfg {
 
 // LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
 // instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, bool PP = false>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
-    typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
+    typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
     const int tid = threadIdx.x, wave = fz_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -115,6 +133,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     const int ktail = g.Cin - (g.kchunks - 1) * BK;  // valid halves of the last K chunk of a tap (BK when Cin % BK == 0)
     const char* aptr[C::ACH];
     int asc[C::ACH];
+    bool apad[C::ACH];
 #pragma unroll
     for (int i = 0; i < C::ACH; ++i) {
         const int row = (i * C::NW + wave) * C::RPI + lane / C::CPR;
@@ -122,6 +141,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         int ar = a0 + row;
         ar = ar < g.Ma ? ar : g.Ma - 1;
         aptr[i] = reinterpret_cast<const char*>(A + (int64_t)ar * g.lda) + asc[i] * 16;
+        apad[i] = row >= C::BA;  // an instruction that only pads the wave's count: fetch the (cache-resident) zero page
     }
     // MODE: 0 = plain rows; 1 = 3x3 conv, K order (tap, Cin chunk); 3 = 3x3 conv, K order (Cin chunk, tap); 2 = temporal
     // 3-tap conv, K order (tap, Cin chunk) (chunk-outer measured 2-7 % slower there).  Chunk-outer order keeps the input window of a K chunk (a 128-byte slice of every
@@ -205,8 +225,28 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         ikc = kt0 - itap * g.kchunks;
     }
     if (MODE == 1 || MODE == 2) retarget(itap);
-    auto issue = [&](int buf) {
-        const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offsets along K
+    // one K tile = the A part (weights) + the B part (pixels) + the cursor step; the ring loops issue them together, the
+    // ping-pong loop in different phases (A first: the cursor moves after B)
+    auto issue_a = [&](int buf) {
+        const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offset along K
+        char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
+        if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
+            FZ_COLD_PATH();
+#pragma unroll
+            for (int i = 0; i < C::ACH; ++i)
+                fz_glds16(asc[i] * 8 < ktail && !(PP && apad[i]) ? aptr[i] + ka : zero, Ab + (i * C::NW + wave) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::ACH; ++i) {
+                if (PP && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
+                    fz_glds16(apad[i] ? zero : aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
+                } else {
+                    fz_glds16(aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
+                }
+            }
+        }
+    };
+    auto issue_b = [&](int buf) {
         int64_t kb = ikc * BK * 2;
         int need = 0;  // KORD: validity bits this tap requires
         if (KORD) {
@@ -214,21 +254,15 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             kb += ((int64_t)(ky - 1) * g.Wi + (kx - 1)) * g.ldb * 2;
             need = (1 << ky) | (8 << kx);
         }
-        char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
-        char* Bb = Ab + C::A_HALVES * 2;
-        if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
+        char* Bb = reinterpret_cast<char*>(smem + buf * C::STAGE) + C::A_HALVES * 2;
+        if (ikc == g.kchunks - 1 && ktail < BK) {
             FZ_COLD_PATH();
-#pragma unroll
-            for (int i = 0; i < C::ACH; ++i)
-                fz_glds16(asc[i] * 8 < ktail ? aptr[i] + ka : zero, Ab + (i * C::NW + wave) * 1024);
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
                 const bool ok = bsc[i] * 8 < ktail && (!KORD || (bflag[i] & need) == need);
                 fz_glds16(ok ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < C::ACH; ++i) fz_glds16(aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
                 if (KORD) {
@@ -249,6 +283,10 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             if ((MODE == 1 || MODE == 2) && itap < g.taps) retarget(itap);
         }
     };
+    auto issue = [&](int buf) {
+        issue_a(buf);
+        issue_b(buf);
+    };
 
     f32x16 acc[TA][TB];
 #pragma unroll
@@ -266,6 +304,137 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     //   (tile kt visible to all; everybody is done with tile kt-1, whose buffer is the one refilled next) -> issue tile
     //   kt+NS-1 -> MFMAs on tile kt.  The barrier does not drain vmcnt, so the loads span barriers (T3+T4 of the guide).
     const int ntile = kt1 - kt0;
+    if constexpr (PP) {
+        // ---- phase-interleaved loop (cdna_hip_programming.md "The 256^2 8-phase template", T3+T4+T5) --------------------------------
+        // K tiles of 32 in a 4-slot ring; a PHASE is one k sub-step of 16:   R: { ds_read the phase's fragments, issue a slice of
+        // LDS-DMA }  s_barrier  M: { TA x TB MFMAs at raised priority }  s_barrier.  The waves of group wa = 1 (waves 4-7: the second
+        // wave of every SIMD) pass ONE extra barrier before the loop and so run half a phase behind group 0: while one group's MFMA
+        // cluster occupies the matrix pipe, the other group's wave on the same SIMD issues its fragment reads and DMA.
+        // Tile j lives in slot j % 4 and is read in phases 2j, 2j+1.  Issue order per wave: A0 B0 A1 B1 A2 B2 (prologue), then
+        // A(j+3) in phase 2j+1 and B(j+3) in phase 2j+2.
+        //   RAW: phase 2j+1 waits (counted, before its first barrier) until this wave's part of tile j+1 has landed -- everything
+        //        issued before tile j+2 -- and tile j+1 is first read in phase 2j+2: one phase after the wait, which is what two groups
+        //        staggered by a barrier need (both groups' waits precede barrier 4j+3, both groups' reads follow it).
+        //   WAR: slot (j+3) % 4 held tile j-1, last read in phase 2j-1 (reads retired at the start of M(2j-1), i.e. before barrier
+        //        4j for both groups); it is restaged from phase 2j+1 on: two phases later (R(2j+1) starts after barrier 4j+1).
+        // Up to 2 tiles (72-80 KB) stay in flight across 3-4 phases; vmcnt is never drained in the steady state.
+        static_assert(2 * C::PER < 64, "vmcnt field");
+        const bool late = wa == 1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < ntile) issue(s);
+        if (ntile > 2) {
+            fz_wait_vm<2 * C::PER>();
+        } else if (ntile > 1) {
+            fz_wait_vm<C::PER>();
+        } else {
+            fz_wait_vm0();
+        }
+        fz_barrier_raw();
+#if !FZ_PP_NOSTAGGER
+        if (late) fz_barrier_raw();
+#endif
+        int slot = 0;
+#if FZ_PP_K32
+        // trial form: a phase is a whole K tile of 32 (two k sub-steps: twice the MFMAs per barrier pair).  Tile j is read in phase j;
+        // tile j+2 is issued in phase j into slot (j+2) % 4 (tile j-2: last read two phases ago) after the counted wait for tile j+1
+        for (int j = 0; j < ntile; ++j) {
+            const half_t* As = smem + slot * C::STAGE;
+            const half_t* Bs = As + C::A_HALVES;
+            half8_t af[2][TA], bf[2][TB];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
+#pragma unroll
+                for (int q = 0; q < TB; ++q) bf[kk][q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) af[kk][i] = fz_ld_h8(As + arow + i * 32 * BK + co);
+            }
+            if (j >= 1 && j + 2 < ntile) issue(slot ^ 2);
+            if (j + 1 < ntile) {  // tile j+1 (read in the next phase) has landed; tile j+2 stays in flight
+                if (j + 2 < ntile) {
+                    fz_wait_vm<C::PER>();
+                } else {
+                    fz_wait_vm0();
+                }
+            }
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            FZ_PP_PRIO_HI();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[kk][i], bf[kk][q], acc[i][q]);
+            FZ_PP_PRIO_LO();
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            slot = (slot + 1) & 3;
+        }
+#else
+        for (int j = 0; j < ntile; ++j) {
+            const half_t* As = smem + slot * C::STAGE;
+            const half_t* Bs = As + C::A_HALVES;
+            half8_t af[TA], bf[TB];
+            // ---------------- phase 2j: k sub-step 0 ----------------
+            {
+                const int co = (hi ^ fsw) * 8;
+#pragma unroll
+                for (int q = 0; q < TB; ++q) bf[q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
+            }
+            if (j >= 1 && j + 2 < ntile) issue_b(slot ^ 2);  // B(j+2) -> slot (j+2) % 4
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            FZ_PP_PRIO_HI();
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+            FZ_PP_PRIO_LO();
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            // ---------------- phase 2j+1: k sub-step 1 ----------------
+            if (j + 1 < ntile) {  // tile j+1 (first read in the next phase) has landed; tile j+2 may stay in flight
+                if (j + 2 < ntile) {
+                    fz_wait_vm<C::PER>();
+                } else {
+                    fz_wait_vm0();
+                }
+            }
+            {
+                const int co = ((2 + hi) ^ fsw) * 8;
+#pragma unroll
+                for (int q = 0; q < TB; ++q) bf[q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
+            }
+            if (j + 3 < ntile) issue_a((slot + 3) & 3);      // A(j+3) -> slot (j+3) % 4
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            FZ_PP_PRIO_HI();
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+            FZ_PP_PRIO_LO();
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            slot = (slot + 1) & 3;
+        }
+#endif
+#if !FZ_PP_NOSTAGGER
+        if (!late) fz_barrier_raw();  // every wave passes the same number of barriers
+#endif
+    } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < ntile) issue(s);
@@ -298,6 +467,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
                 for (int j = 0; j < TB; ++j) acc[i][j] = fz_mfma_32x32x16_f16(af[i], bf[j], acc[i][j]);
         }
         buf = buf + 1 == NS ? 0 : buf + 1;
+    }
     }
 
     // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
@@ -631,9 +801,9 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, bool PP = false>
 static int ig_launch(IgArgs g, int batch, void* stream) {
-    typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU> C;
+    typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
     if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
     g.tiles_a = fz_ceil_div(g.Ma, C::BA);
@@ -644,14 +814,14 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 #ifndef FZ_EMU
     static bool attr_set = false;  // LDS above 64 KB is an opt-in function attribute, not tuning state
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
         attr_set = true;
     }
 #endif
     dim3 grid((unsigned)nt, (unsigned)g.ksplit, (unsigned)batch), block(C::T);
-    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN>), grid, block, lds, stream, g);
+    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP>), grid, block, lds, stream, g);
     return fz_last_launch_status();
 }
 
@@ -676,6 +846,10 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 //   212222:  64 x 128, 4 waves, three workgroups per CU -- small launches and ragged widths
 template <int MODE, bool GEGLU, bool LN = false>
 static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
+    if constexpr (!LN) {  // ping-pong K loop (last digit 8): K step 32, 4-slot ring, two wave groups half a phase apart
+        if (cfg == 244218) return ig_launch<2, 4, 4, 2, 32, 4, MODE, GEGLU, false, true>(g, batch, stream);
+        if (!GEGLU && cfg == 254218) return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, true>(g, batch, stream);
+    }
     switch (cfg) {
         case 244222: return ig_launch<2, 4, 4, 2, 64, 2, MODE, GEGLU, LN>(g, batch, stream);
         case 224223: return ig_launch<2, 2, 4, 2, 64, 3, MODE, GEGLU, LN>(g, batch, stream);

@@ -20,7 +20,7 @@ import torch
 from ... import dist as fz_dist
 from ... import kernels as K
 from ..models.resnet import Tokens
-from ..prompt_attention import attention_util
+from ..prompt_attention import attention_util, spatial_blend
 from .stable_diffusion import SpatioTemporalStableDiffusionPipeline, StableDiffusionPipelineOutput
 
 
@@ -189,6 +189,7 @@ class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
         attention_util.register_attention_control(self, edit_controller)
         self.last_edit_controller = edit_controller
         sdimage_output = self.sd_ddim_pipeline(controller=edit_controller, **kwargs)
+        spatial_blend.flush_mask_dumps()  # the blend-mask PNGs (save_path) were queued off-loop: all on disk from here on
         mask_list = edit_controller.latent_blend.mask_list if hasattr(edit_controller.latent_blend, "mask_list") else None
         attention_output = self._attention_strips(kwargs["prompt"], edit_controller)
         dict_output = {"sdimage_output": sdimage_output, "attention_output": attention_output, "mask_list": mask_list}

@@ -287,16 +287,19 @@ def make_controller(tokenizer, prompts: List[str], is_replace_controller: bool, 
                     additional_attention_store=None, use_inversion_attention=False, blend_th=(0.3, 0.3),
                     NUM_DDIM_STEPS=None, blend_latents=False, blend_self_attention=False, save_path=None,
                     save_self_attention=True, disk_store=False) -> AttentionControlEdit:
-    """attention_util.py:320-387. `save_path` only ever fed the blend-mask PNG dumps, which are not reproduced (so,
-    unlike the reference, `save_path=None` together with `blend_words` is accepted)."""
+    """attention_util.py:320-387.  `save_path` feeds the blend-mask PNG dumps (`<save_path>/latent_blend_mask`,
+    `<save_path>/attention_blend_mask`, written off the hot loop: spatial_blend.py); unlike the reference, `save_path=None`
+    together with `blend_words` is accepted and simply dumps nothing."""
     latent_blend = attention_blend = None
     if not ((blend_words is None) or (blend_words == "None")):
         if blend_latents:
             latent_blend = SpatialBlender(prompts, blend_words, start_blend=0.2, end_blend=0.8, tokenizer=tokenizer,
-                                          th=blend_th, NUM_DDIM_STEPS=NUM_DDIM_STEPS, prompt_choose="both")
+                                          th=blend_th, NUM_DDIM_STEPS=NUM_DDIM_STEPS, prompt_choose="both",
+                                          save_path=None if save_path is None else save_path + "/latent_blend_mask")
         if blend_self_attention:
             attention_blend = SpatialBlender(prompts, blend_words, start_blend=0.0, end_blend=2, tokenizer=tokenizer,
-                                             th=blend_th, NUM_DDIM_STEPS=NUM_DDIM_STEPS, prompt_choose="source")
+                                             th=blend_th, NUM_DDIM_STEPS=NUM_DDIM_STEPS, prompt_choose="source",
+                                             save_path=None if save_path is None else save_path + "/attention_blend_mask")
     common = dict(cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps, latent_blend=latent_blend,
                   tokenizer=tokenizer, additional_attention_store=additional_attention_store,
                   use_inversion_attention=use_inversion_attention, attention_blend=attention_blend,

@@ -5,9 +5,19 @@
 (sum over blend words -> mean over heads x layers -> 3x3 max-pool -> nearest resize -> per-(prompt, frame) max
 normalisation -> threshold) is one HIP kernel (`fz_blend_mask`) reading the fp16 maps straight out of the HBM
 arena, and the result is cached per (inversion step, resolution): the reference recomputes the very same mask for
-each of the 11 self-attention layers of a step.  PNG dumps of the masks (`save_path`) are host I/O
-inside the hot loop in the reference and are not reproduced.
+each of the 11 self-attention layers of a step.
+
+PNG dumps of the masks (`save_path`, spatial_blend.py:43-55): same directory layout, same file-name pattern
+(`{save_path}/{prompt_choose}/step_in_store_{step:04d}/mask_{timestamp}_{count:02d}.png`), same picture
+(`torchvision.utils.save_image(..., normalize=True)` of the frames as a grid: 8 per row, 2 pixels of padding) -- but
+moved OFF the hot loop: the mask of a (step, resolution) is copied device -> pinned host memory once, asynchronously
+on a side stream, and a writer thread encodes the files after the copy's event; the denoise loop never waits for it.
+`flush_mask_dumps()` (called by the pipeline after the edit) joins the outstanding writes.
 """
+import datetime
+import os
+import queue
+import threading
 from typing import List
 
 import numpy as np
@@ -18,13 +28,110 @@ from . import ptp_utils
 from .attention_store import CapturedMap
 
 
+def mask_grid_image(mask: np.ndarray, nrow: int = 8, padding: int = 2) -> np.ndarray:
+    """What `tvu.save_image(rearrange(mask, "c p h w -> p c h w"), path, normalize=True)` writes for a 0/1 mask [F, h, w]
+    (torchvision.utils.make_grid + save_image [3P torchvision]): min-max normalisation over the whole batch
+    ((x - min) / (max - min + 1e-5): a constant mask comes out black), grey -> RGB, frames on a grid of `nrow` columns with
+    `padding` black pixels around each (one frame: no grid, no padding), x 255 + 0.5 truncated to uint8.  Returns uint8
+    [H, W, 3]."""
+    m = mask.astype(np.float32)
+    lo, hi = float(m.min()), float(m.max())
+    m = (np.clip(m, lo, hi) - lo) / max(hi - lo, 1e-5)
+    f, h, w = m.shape
+    if f == 1:
+        grid = m[0]
+    else:
+        xmaps = min(nrow, f)
+        ymaps = -(-f // xmaps)
+        hh, ww = h + padding, w + padding
+        grid = np.zeros((hh * ymaps + padding, ww * xmaps + padding), np.float32)
+        for k in range(f):
+            y, x = divmod(k, xmaps)
+            grid[y * hh + padding: y * hh + padding + h, x * ww + padding: x * ww + padding + w] = m[k]
+    img = np.clip(grid * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    return np.repeat(img[:, :, None], 3, axis=2)
+
+
+class _MaskDumper:
+    """Writer thread for the blend-mask PNGs: jobs are (event or None, host uint8 tensor [F, h, w], list of paths)."""
+
+    def __init__(self):
+        self.q = queue.Queue()
+        self.thread = None
+        self.lock = threading.Lock()
+        self.streams = {}
+        self.errors = []
+
+    def _run(self):
+        from PIL import Image
+        while True:
+            job = self.q.get()
+            try:
+                if job is None:
+                    return
+                ev, host, paths = job
+                if ev is not None:
+                    ev.synchronize()
+                img = Image.fromarray(mask_grid_image(host.numpy()))
+                for path in paths:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    img.save(path)
+            except Exception as e:  # reported by flush(); a failed dump must not kill the edit
+                self.errors.append(repr(e))
+            finally:
+                self.q.task_done()
+
+    def _ensure_thread(self):
+        with self.lock:
+            if self.thread is None or not self.thread.is_alive():
+                self.thread = threading.Thread(target=self._run, name="fz-mask-dump", daemon=True)
+                self.thread.start()
+
+    def stage(self, mask: torch.Tensor):
+        """Start the device -> host copy of a 0/1 mask [F, h, w]; returns (event, host tensor) for `write`."""
+        m8 = mask.to(torch.uint8)
+        if not m8.is_cuda:
+            return None, m8.contiguous().clone()
+        dev = m8.device
+        side = self.streams.get(dev)
+        if side is None:
+            side = self.streams[dev] = torch.cuda.Stream(device=dev)
+        host = torch.empty(m8.shape, dtype=torch.uint8, pin_memory=True)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            host.copy_(m8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        m8.record_stream(side)
+        return ev, host
+
+    def write(self, staged, paths):
+        self._ensure_thread()
+        self.q.put((staged[0], staged[1], list(paths)))
+
+    def flush(self):
+        if self.thread is not None:
+            self.q.join()
+        errs, self.errors = self.errors, []
+        if errs:
+            raise RuntimeError("blend-mask PNG dump failed: " + "; ".join(errs))
+
+
+_DUMPER = _MaskDumper()
+
+
+def flush_mask_dumps():
+    """Wait until every blend-mask PNG queued so far is on disk (the pipeline calls it once after the denoise loop)."""
+    _DUMPER.flush()
+
+
 class SpatialBlender:
     def __init__(self, prompts: List[str], words, substruct_words=None, start_blend=0.2, end_blend=0.8,
                  th=(0.9, 0.9), tokenizer=None, NUM_DDIM_STEPS=None, save_path=None, prompt_choose="source"):
         self.count = 0
         self.MAX_NUM_WORDS = 77
         self.NUM_DDIM_STEPS = NUM_DDIM_STEPS
-        self.save_path = None  # mask PNG dumps are not reproduced (see module docstring)
+        self.save_path = save_path  # mask PNG dumps: written off-loop (module docstring)
         assert prompt_choose in ["source", "both"], \
             "choose to generate the mask by only source prompt or both the source and target"
         if substruct_words is not None:
@@ -46,6 +153,7 @@ class SpatialBlender:
         self.mask_list = []
         self._alpha_dev = {}
         self._cache = {}
+        self._staged = {}
 
     def _alpha80(self, n_prompts, device):
         key = (n_prompts, str(device))
@@ -71,6 +179,22 @@ class SpatialBlender:
         return K.blend_mask(maps5, alpha, float(self.th[0]), (target_h, target_w),
                             or_with_first=(self.prompt_choose == "both"))
 
+    def _dump(self, mask, step_in_store, cache_key):
+        """spatial_blend.py:43-55: one PNG per get_mask call (the last prompt's mask when there are two), numbered by
+        `self.count`.  The D2H copy of a cached mask is staged once; every call only queues a file name."""
+        now = datetime.datetime.now().strftime("%Y-%m-%dT%H-%M-%S")
+        path = f"{self.save_path}/{self.prompt_choose}/"
+        if step_in_store is not None:
+            path += f"step_in_store_{step_in_store:04d}"
+        path += f"/mask_{now}_{self.count:02d}.png"
+        self.count += 1
+        staged = self._staged.get(cache_key) if cache_key is not None else None
+        if staged is None:
+            staged = _DUMPER.stage(mask[-1])
+            if cache_key is not None:
+                self._staged[cache_key] = staged
+        _DUMPER.write(staged, [path])
+
     def __call__(self, attention_store, step_in_store: int = None, target_h=None, target_w=None, x_t=None):
         """attention_store: dict of lists of maps ([F,heads,r*r,77] or [P,F,heads,r*r,77] tensors, or CapturedMap)."""
         if target_h is None and target_w is None and x_t is not None:
@@ -87,7 +211,10 @@ class SpatialBlender:
             if cache_key is not None:
                 if len(self._cache) > 8:
                     self._cache.clear()
+                    self._staged.clear()
                 self._cache[cache_key] = mask
+        if self.save_path is not None:
+            self._dump(mask, step_in_store, cache_key)
         # mask is one: use generated information; zero: use inverted information (spatial_blend.py:113-115)
         self.mask_list.append(mask[0][:, None, :, :])
         if x_t is not None:

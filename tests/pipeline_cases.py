@@ -59,7 +59,46 @@ def _mask_flips(native_list, oracle_list):
     return flips, total
 
 
-def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False):
+def check_mask_dumps(save_path, ctrl):
+    """Row (f)-3: the blend-mask PNGs the reference writes from inside its hot loop (spatial_blend.py:43-55) -- here queued
+    off-loop.  File k of a blender (`..._{k:02d}.png`, k = its call count) must decode to exactly the picture
+    torchvision.utils.save_image(normalize=True) draws from the k-th native mask: frames on a grid of 8 columns, 2 px padding,
+    white where the mask is 1.  The grid is rebuilt here independently with torch ops."""
+    import glob
+    import numpy as np
+    from PIL import Image
+    n_checked = 0
+    for sub, blender in (("attention_blend_mask", ctrl.attention_blend), ("latent_blend_mask", ctrl.latent_blend)):
+        if blender is None:
+            continue
+        files = sorted(glob.glob(f"{save_path}/{sub}/{blender.prompt_choose}/**/mask_*.png", recursive=True),
+                       key=lambda f: int(f.rsplit("_", 1)[1].split(".")[0]))
+        assert len(files) == len(blender.mask_list) == blender.count, (sub, len(files), len(blender.mask_list), blender.count)
+        for k, f in enumerate(files):
+            assert int(f.rsplit("_", 1)[1].split(".")[0]) == k
+            if blender.prompt_choose == "source":
+                assert "/step_in_store_" in f
+            m = blender.mask_list[k].float().cpu()[:, 0]          # [F, h, w] of 0 / 1
+            fr, h, w = m.shape
+            lo, hi = float(m.min()), float(m.max())
+            mn = (m - lo) / max(hi - lo, 1e-5)
+            if fr == 1:
+                grid = mn[0]
+            else:
+                cols = min(8, fr)
+                rows = (fr + cols - 1) // cols
+                grid = torch.zeros(rows * (h + 2) + 2, cols * (w + 2) + 2)
+                for i in range(fr):
+                    grid[(i // cols) * (h + 2) + 2:(i // cols) * (h + 2) + 2 + h, (i % cols) * (w + 2) + 2:(i % cols) * (w + 2) + 2 + w] = mn[i]
+            want = grid.mul(255).add(0.5).clamp(0, 255).to(torch.uint8).numpy()
+            got = np.asarray(Image.open(f))
+            assert got.shape == want.shape + (3,), (f, got.shape, want.shape)
+            assert (got == want[:, :, None]).all(), f
+            n_checked += 1
+    return n_checked
+
+
+def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_path=None):
     meta = load_json("pipeline_meta.json")[name]
     consts = load_json("host_constants.json")[meta["prompt_case"]]
     gz = load_npz(name + ".npz")
@@ -91,6 +130,8 @@ def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False):
 
     kw = dict(meta["kwargs"])
     kw.pop("save_path", None)
+    if save_path is not None:
+        kw["save_path"] = save_path
     pipe._encode_prompt = lambda *a, **k: emb_tgt
     # start the edit from the reference's own inverted latent so that the two halves are checked independently
     out = pipe(latents=zT_ref.to(device), output_type="latent", **kw)
@@ -102,6 +143,8 @@ def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False):
     # fp16 noise of the threshold flips and moves that latent pixel by |x - inverted| (order of the latent scale itself)
     res["edit_err_q99"] = float(torch.quantile((edited - ref).abs().flatten(), 0.99))
     ctrl = pipe.last_edit_controller
+    if save_path is not None:
+        res["mask_pngs_checked"] = check_mask_dumps(save_path, ctrl)
     if ctrl.attention_blend is not None:
         packed = {}
         for m in ctrl.attention_blend.mask_list:
@@ -179,14 +222,33 @@ FULL_SRC = "a silver jeep driving down a curvy road in the countryside,"
 FULL_TGT = "a Porsche car driving down a curvy road in the countryside,"
 
 
-def run_fullwidth_case(device, F=2, T=2, pure_edit=False, seed=11):
+FULL_VARIANTS = {
+    # BASELINE cfg2 (config/teaser/jeep_posche.yaml): default model config, Replace + blend-masked self-attention
+    "replace_blend": dict(
+        model_config={"lora": 160}, prompts=(FULL_SRC, FULL_TGT), is_replace=True, cross_replace={"default_": 0.5},
+        self_replace=1.0, blend_words=[["silver", "jeep"], ["Porsche", "car"]], eq_params=None),
+    # BASELINE cfg1 / cfg3 model config (config/style/sun_flower_van_gogh.yaml:69-73): K/V from the middle frame only, and
+    # only where the width reaches 640 (the 320-wide level runs per-frame attention); Refine + Reweight (x10), no mask
+    "refine_reweight_mid": dict(
+        model_config={"lora": 160, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 640},
+        prompts=("a sunflower in a vase on a table", "a sunflower in a vase on a table, van gogh style"), is_replace=False,
+        cross_replace={"default_": 0.5}, self_replace=0.5, blend_words=None,
+        eq_params={"words": ["van", "gogh"], "values": [10, 10]}),
+}
+
+
+def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="replace_blend"):
     """Native pipeline vs the fp32 CPU oracle (oracle.OracleUNet / ddim_inversion / ddim_edit) at REAL width with the same
-    procedural weights: F frames, T inversion steps with capture + T CFG edit steps with the bench's controller (Replace +
-    blend-masked self-attention, unet_3d_condition.py:307-446 / attention_register.py:23-218 end to end).  This is the only
-    place where the d = 40 log2-folded flash path, the native / library conv routing, the batched time-embedding projection
-    and the level-adapted GroupNorm chunks are compared with the oracle as an assembled UNet."""
+    procedural weights: F frames, T inversion steps with capture + T CFG edit steps (unet_3d_condition.py:307-446 /
+    attention_register.py:23-218 end to end).  F = 3 keeps the frame axis non-degenerate: with [-1, 'first'] the two K/V
+    slots of frame 2 are frames 1 and 0 (attention.py:374-388), with ['mid'] every frame reads frame 1, and the 5-D
+    GroupNorm spans three frames.  This is the only place where the d = 40 log2-folded flash path, the conv / GEMM tile
+    routing, the batched time-embedding projection and the level-adapted GroupNorm chunks are compared with the oracle as
+    an assembled UNet.  `variant` picks the model config + controller (FULL_VARIANTS)."""
     from oracle import fatezero_oracle as O
-    mc = {"lora": 160}
+    V = FULL_VARIANTS[variant]
+    mc = dict(V["model_config"])
+    src, tgt = V["prompts"]
     unet = UNetPseudo3DConditionModel(sample_size=64, **SD15, **mc)
     shapes = [(k, tuple(v.shape)) for k, v in unet.state_dict().items()]
     sd = procedural_state_dict(shapes)
@@ -201,7 +263,7 @@ def run_fullwidth_case(device, F=2, T=2, pure_edit=False, seed=11):
     z0 = torch.randn(1, 4, F, 64, 64, generator=g)
     emb_src = torch.randn(2, 77, 768, generator=g) * 0.5
     emb_tgt = emb_src + 0.25 * torch.randn(2, 77, 768, generator=g)
-    res = {}
+    res = {"variant": variant, "frames": F}
     # single UNet forward first (inversion mode, no controller side effects on the result)
     lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1,
                                              text_embeddings=emb_src.to(device), store_attention=True, LOW_RESOURCE=True,
@@ -223,19 +285,22 @@ def run_fullwidth_case(device, F=2, T=2, pure_edit=False, seed=11):
             else:
                 worst_self = max(worst_self, e)
     res["map_err"], res["self_map_err"] = worst_cross, worst_self
-    kw = dict(prompt=FULL_TGT, source_prompt=FULL_SRC, num_inference_steps=T, cross_replace_steps={"default_": 0.5},
-              self_replace_steps=1.0, use_inversion_attention=True, is_replace_controller=True,
-              blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_self_attention=True, blend_th=[0.3, 0.3],
-              save_self_attention=False, guidance_scale=7.5)
+    kw = dict(prompt=tgt, source_prompt=src, num_inference_steps=T, cross_replace_steps=dict(V["cross_replace"]),
+              self_replace_steps=V["self_replace"], use_inversion_attention=True, is_replace_controller=V["is_replace"],
+              blend_th=[0.3, 0.3], save_self_attention=False, guidance_scale=7.5)
+    if V["blend_words"] is not None:
+        kw.update(blend_words=V["blend_words"], blend_self_attention=True)
+    if V["eq_params"] is not None:
+        kw.update(eq_params=V["eq_params"])
     pipe._encode_prompt = lambda *a, **k: emb_tgt.to(device)
     zT = lat[-1]
     edited = pipe(latents=zT, edit_type="swap", output_type="latent", **kw)["sdimage_output"].images.float().cpu()
     ctrl = pipe.last_edit_controller
 
     def oracle_edit(ost, z):
-        c = O.make_edit_controller(tok, [FULL_SRC, FULL_TGT], ost, T, True, {"default_": 0.5}, 1.0,
-                                   blend_words=kw["blend_words"], blend_th=(0.3, 0.3), blend_self_attention=True,
-                                   save_self_attention=False)
+        c = O.make_edit_controller(tok, [src, tgt], ost, T, V["is_replace"], dict(V["cross_replace"]), V["self_replace"],
+                                   blend_words=V["blend_words"], eq_params=V["eq_params"], blend_th=(0.3, 0.3),
+                                   blend_self_attention=V["blend_words"] is not None, save_self_attention=False)
         return O.ddim_edit(ounet, O.DDIMSchedule(T), z, emb_tgt, c, guidance_scale=7.5), c
     # oracle edit on the natively captured maps, from the native inverted latent: isolates the edit pass; masks bit-exact
     ost = O.StoreController()
@@ -246,15 +311,17 @@ def run_fullwidth_case(device, F=2, T=2, pure_edit=False, seed=11):
     res["edit_scale"] = float(o_edit.abs().max())
     res["edit_err_vs_oracle_on_native_maps"] = float((edited - o_edit).abs().max())
     res["edit_err_vs_oracle_on_native_maps_q99"] = float(torch.quantile((edited - o_edit).abs().flatten(), 0.99))
-    res["attn_mask_flips_same_maps"], res["attn_mask_total"] = _mask_flips(ctrl.attention_blend.mask_list,
-                                                                            o_ctrl.attention_blend.mask_list)
-    res["mask_ones"] = int(sum(int(m.bool().sum()) for m in ctrl.attention_blend.mask_list))
+    if V["blend_words"] is not None:
+        res["attn_mask_flips_same_maps"], res["attn_mask_total"] = _mask_flips(ctrl.attention_blend.mask_list,
+                                                                                o_ctrl.attention_blend.mask_list)
+        res["mask_ones"] = int(sum(int(m.bool().sum()) for m in ctrl.attention_blend.mask_list))
     if pure_edit:  # the all-fp32 run: oracle edit on the ORACLE's maps from the oracle's inverted latent
         native2 = pipe(latents=olat[-1].to(device), edit_type="swap", output_type="latent", **kw)["sdimage_output"].images
         p_edit, p_ctrl = oracle_edit(ostore, olat[-1])
         res["edit_err"] = float((native2.float().cpu() - p_edit).abs().max())
-        res["attn_mask_flips"], _ = _mask_flips(pipe.last_edit_controller.attention_blend.mask_list,
-                                                p_ctrl.attention_blend.mask_list)
+        if V["blend_words"] is not None:
+            res["attn_mask_flips"], _ = _mask_flips(pipe.last_edit_controller.attention_blend.mask_list,
+                                                    p_ctrl.attention_blend.mask_list)
     return res
 
 
@@ -262,11 +329,13 @@ def check_fullwidth(res):
     assert res["inv_err"] <= LATENT_TOL * res["inv_scale"], res
     assert res["map_err"] <= MAP_TOL and res["self_map_err"] <= MAP_TOL, res
     assert res["edit_err_vs_oracle_on_native_maps"] <= EDIT_TOL_SAME_MAPS * res["edit_scale"], res
-    assert res["attn_mask_flips_same_maps"] == 0, res
-    assert 0 < res["mask_ones"] < res["attn_mask_total"], res   # a degenerate (all-0 / all-1) mask would test nothing
+    if "attn_mask_flips_same_maps" in res:
+        assert res["attn_mask_flips_same_maps"] == 0, res
+        assert 0 < res["mask_ones"] < res["attn_mask_total"], res   # a degenerate (all-0 / all-1) mask would test nothing
     if "edit_err" in res:
         assert res["edit_err"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
-        assert res["attn_mask_flips"] <= MASK_FLIP_TOL * res["attn_mask_total"], res
+        if "attn_mask_flips" in res:
+            assert res["attn_mask_flips"] <= MASK_FLIP_TOL * res["attn_mask_total"], res
 
 
 def run_unet_golden(name, device):

@@ -12,7 +12,9 @@ import kernel_cases as KC
 
 @pytest.fixture(scope="module", autouse=True)
 def emu_backend():
-    _native.use_test_backend(build.build_emu())
+    import os
+    # FZ_EMU_LIB: an emulator build of a trial variant of the kernels (scripts/emu_variant.sh), validated before it costs GPU time
+    _native.use_test_backend(os.environ.get("FZ_EMU_LIB") or build.build_emu())
     yield
     _native.reset_backend()
 
@@ -65,6 +67,14 @@ def test_self_own_frame_only():
 @pytest.mark.parametrize("d,lq", [(40, 64), (80, 144), (160, 36)])
 def test_self_capture(d, lq):
     KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=d, lq=lq, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE)
+
+
+@pytest.mark.parametrize("d,lq,index_list", [(80, 72, [-1, "first"]), (160, 36, ["mid"])])
+def test_self_capture_inject_three_frames(d, lq, index_list):
+    # clip = 3: distinct source frames per K/V slot at the head dims of the 32^2 / 16^2 levels
+    KC.case_attn_self(DEV, batch=1, clip=3, heads=1, d=d, lq=lq, index_list=index_list, mode=K.FZ_ATTN_CAPTURE, seed=3)
+    KC.case_attn_self(DEV, batch=2, clip=3, heads=1, d=d, lq=lq, index_list=index_list, mode=K.FZ_ATTN_INJECT,
+                      mask_kind="random", seed=4)
 
 
 @pytest.mark.parametrize("mask_kind", [None, "random", "rows"])
@@ -125,15 +135,23 @@ def test_conv3x3_small_cin_and_cout():
     KC.case_conv3x3(DEV, n=2, h=8, w=8, cin=32, cout=4)                             # conv_out: 4 of 64 tile rows live
 
 
-@pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 3), (254222, 2), (254122, 4), (158122, 1)])
+@pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 3), (254222, 2), (254122, 4), (158122, 1),
+                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222])
+@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218])
 def test_gemm_tile_shapes(tile_cfg):
     KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
+
+
+@pytest.mark.parametrize("k", [32, 40, 64, 128, 136, 160])
+def test_gemm_pingpong_tile_counts(k):
+    # 1 .. 5 K tiles of the ping-pong loop (prologue / tail forms of its ring), ragged last tile; both tile widths
+    KC.case_gemm(DEV, rows=70, k=k, o=72, tile_cfg=254218)
+    KC.case_gemm(DEV, rows=300, k=k, o=264, n_res=1, tile_cfg=244218)
 
 
 def test_gemm_forms():
@@ -144,7 +162,7 @@ def test_gemm_forms():
     KC.case_gemm(DEV, rows=2, k=1280, o=96)                                                 # time-embedding shaped
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 244222, 224223, 222222])
+@pytest.mark.parametrize("tile_cfg", [0, 244222, 224223, 222222, 244218])
 def test_gemm_geglu(tile_cfg):
     KC.case_gemm(DEV, rows=70, k=64, o=256, geglu=True, tile_cfg=tile_cfg)
     KC.case_gemm(DEV, rows=33, k=40, o=128, geglu=True, bias=False, tile_cfg=tile_cfg)
@@ -179,9 +197,12 @@ def test_igemm_with_early_landing_dma(monkeypatch):
     FZ_EMU_DMA=early makes it land at issue instead (a DMA issued before every reader of the recycled ring stage passed the barrier
     corrupts their tile).  Every tile shape and K order of the implicit-GEMM kernel once more under the early model."""
     monkeypatch.setenv("FZ_EMU_DMA", "early")
-    for tile_cfg, split_k in [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 3), (212222, 1), (158122, 1), (254222, 2)]:
+    for tile_cfg, split_k in [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 3), (212222, 1), (158122, 1), (254222, 2),
+                              (254218, 1), (244218, 1), (254218, 4), (244218, 2)]:
         KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg, split_k=split_k)
-    for tile_cfg in (0, 254222, 244222, 224223, 212222):
+    for tile_cfg in (0, 254222, 244222, 224223, 212222, 254218, 244218):
         KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
+    for k in (32, 40, 64, 128, 136, 160):  # 1 .. 5 K tiles of the ping-pong loop (prologue / tail forms), ragged last tile
+        KC.case_gemm(DEV, rows=70, k=k, o=72, tile_cfg=254218)
     KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)

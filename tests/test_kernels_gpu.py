@@ -68,6 +68,22 @@ def test_self_capture(d, lq):
     print("capture", d, lq, r)
 
 
+@pytest.mark.parametrize("index_list", [[-1, "first"], ["mid"], [-1, "mid", 1]])
+@pytest.mark.parametrize("d,lq", [(80, 1024), (160, 256), (160, 64)])
+def test_self_capture_three_frames(d, lq, index_list):
+    # clip = 3: the K/V slots of a frame are DISTINCT frames (with clip = 2 and [-1, 'first'] both resolve to frame 0)
+    r = KC.case_attn_self(DEV, batch=1, clip=3, heads=2, d=d, lq=lq, index_list=index_list, mode=K.FZ_ATTN_CAPTURE, seed=3)
+    print("capture clip3", d, lq, index_list, r)
+
+
+@pytest.mark.parametrize("mask_kind", [None, "random"])
+@pytest.mark.parametrize("d,lq,index_list", [(80, 1024, [-1, "first"]), (160, 256, [-1, "first"]), (80, 1024, ["mid"]),
+                                             (160, 64, [-1, "mid", 1])])
+def test_self_inject_three_frames(mask_kind, d, lq, index_list):
+    KC.case_attn_self(DEV, batch=2, clip=3, heads=2, d=d, lq=lq, index_list=index_list, mode=K.FZ_ATTN_INJECT,
+                      mask_kind=mask_kind, seed=4)
+
+
 @pytest.mark.parametrize("mask_kind", [None, "random", "rows"])
 @pytest.mark.parametrize("d,lq", [(80, 1024), (160, 256), (32, 81)])
 def test_self_inject(mask_kind, d, lq):
@@ -136,7 +152,8 @@ def test_conv3x3_small_levels_and_ends(kw):
     print(kw, r)
 
 
-@pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 4), (244222, 2), (254222, 4), (254122, 2), (158122, 1), (158122, 2)])
+@pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 4), (244222, 2), (254222, 4), (254122, 2), (158122, 1), (158122, 2),
+                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     KC.case_conv3x3(DEV, n=4, h=16, w=16, cin=640, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
@@ -159,10 +176,40 @@ def test_gemm_geglu(rows, k, o):
     print(rows, k, o, r)
 
 
-@pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222])
+@pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218])
 def test_gemm_every_tile_shape(tile_cfg):
     KC.case_gemm(DEV, rows=3000, k=640, o=960, n_res=1, tile_cfg=tile_cfg)
     KC.case_gemm(DEV, rows=520, k=1280, o=320, tile_cfg=tile_cfg, split_k=4)
+
+
+@pytest.mark.parametrize("ring,pp", [(254222, 254218), (244222, 244218)])
+def test_pingpong_loop_bit_equal_to_ring_loop(ring, pp):
+    """The phase-interleaved K loop contracts in the same k order into the same accumulators as the 2-stage ring loop of the
+    same tile: outputs must be BIT-equal (real SD shapes: tap-outer and chunk-outer 3x3 convs, stride 2, nearest-2x, ragged
+    Cin, split-K, a long-K and a short-K GEMM)."""
+    g = torch.Generator().manual_seed(7)
+    # exact = the launch runs tap-outer (K order (tap, k) whatever the K step); the chunk-outer launches (igemm.hip fz_conv3x3:
+    # per-XCD tap window above L2) walk (k chunk, tap) and so contract in a different order with K step 32 than with 64: those
+    # agree to an fp16 rounding of the result
+    for (n, hw, cin, cout, stride, up, sk, exact) in [(8, 64, 320, 320, 1, False, 1, True), (16, 64, 320, 320, 1, False, 1, False),
+                                                      (4, 32, 1920, 640, 1, False, 1, False), (4, 32, 640, 640, 2, False, 1, True),
+                                                      (4, 16, 1280, 1280, 1, True, 1, True), (8, 16, 2560, 1280, 1, False, 4, False),
+                                                      (2, 24, 328, 320, 1, False, 1, True)]:
+        x = torch.randn(n, hw * hw, cin, generator=g).half().to(DEV)
+        wt = K.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3, generator=g) * 0.02).half().to(DEV))
+        b = torch.randn(cout, generator=g).half().to(DEV)
+        ya, _ = K.conv3x3(x, wt, b, hw=(hw, hw), stride=stride, upsample=up, tile_cfg=ring, split_k=sk)
+        yb, _ = K.conv3x3(x, wt, b, hw=(hw, hw), stride=stride, upsample=up, tile_cfg=pp, split_k=sk)
+        assert torch.isfinite(ya.float()).all()
+        if exact:
+            assert torch.equal(ya, yb), (n, hw, cin, cout, stride, up, sk)
+        else:
+            assert float((ya.float() - yb.float()).abs().max()) <= 2.0 ** -9 * float(ya.float().abs().max()), (n, hw, cin, cout)
+    for (rows, k, o) in [(32768, 320, 320), (8192, 2560, 640), (4096, 1280, 3840), (1000, 328, 648)]:
+        x = torch.randn(rows, k, generator=g).half().to(DEV)
+        w = (torch.randn(o, k, generator=g) * 0.03).half().to(DEV)
+        b = torch.randn(o, generator=g).half().to(DEV)
+        assert torch.equal(K.gemm(x, w, b, tile_cfg=ring), K.gemm(x, w, b, tile_cfg=pp)), (rows, k, o)
 
 
 def test_gemm_transposed_output():

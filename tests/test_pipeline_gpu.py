@@ -24,12 +24,26 @@ def test_pipeline(name):
     assert _native.loaded_path().endswith("libfatezero_hip.so")
 
 
-def test_fullwidth_sd15_pipeline_vs_oracle():
-    """BASELINE cfg2 architecture at real width (d = 40 / 80 / 160, lora 160, 64x64 latents), 2 frames, 2 + 2 steps,
-    the bench's controller -- native HIP path vs oracle.OracleUNet / ddim_inversion / ddim_edit (about 3 minutes of CPU
-    oracle time).  FZ_FULL_PARITY=1 adds the all-fp32 edit run (oracle edit on the oracle's own maps)."""
+@pytest.mark.parametrize("name", ["pipe_replace_blend", "pipe_refine_reweight_latentblend"])
+def test_blend_mask_png_dumps(name, tmp_path):
+    """Row (f)-3 (spatial_blend.py:43-55): the edit run with `save_path` leaves one PNG per blender call whose decoded bits
+    equal the native mask drawn the way torchvision's save_image(normalize=True) draws it; the copies and the encoding run off
+    the denoise loop (side stream + writer thread), the parity of the run itself is unchanged."""
+    res = PC.run_pipeline_case(name, "cuda", save_path=str(tmp_path))
+    print(name, res)
+    PC.check(res)
+    assert res["mask_pngs_checked"] > 0
+
+
+@pytest.mark.parametrize("variant", ["replace_blend", "refine_reweight_mid"])
+def test_fullwidth_sd15_pipeline_vs_oracle(variant):
+    """BASELINE architecture at real width (d = 40 / 80 / 160, lora 160, 64x64 latents), THREE frames (two distinct K/V
+    source frames, GroupNorm over three), 2 + 2 steps -- native HIP path vs oracle.OracleUNet / ddim_inversion / ddim_edit:
+    cfg2's model config with the bench's controller (Replace + blend-masked self-attention), and cfg1 / cfg3's model config
+    ({SparseCausalAttention_index: ['mid'], least_sc_channel: 640}) with Refine + Reweight.  About 4-5 minutes of CPU oracle
+    time each.  FZ_FULL_PARITY=1 adds the all-fp32 edit run (oracle edit on the oracle's own maps)."""
     import os
-    res = PC.run_fullwidth_case("cuda", pure_edit=os.environ.get("FZ_FULL_PARITY") == "1")
+    res = PC.run_fullwidth_case("cuda", pure_edit=os.environ.get("FZ_FULL_PARITY") == "1", variant=variant)
     print("fullwidth", res)
     PC.check_fullwidth(res)
     assert _native.loaded_path().endswith("libfatezero_hip.so")

@@ -50,6 +50,31 @@ def test_product_host_constants_exact():
         assert ctrl.num_self_replace == (0, int(T * 0.5)), name
 
 
+@pytest.mark.parametrize("frames", [1, 3, 10])
+def test_blend_mask_png_dumps_off_loop(tmp_path, frames):
+    """Row (f)-3, spatial_blend.py:43-55: with `save_path` every blender call leaves `.../<prompt_choose>/step_in_store_NNNN/
+    mask_<timestamp>_<count>.png` holding torchvision's save_image(normalize=True) picture of the native mask (grid of 8 columns,
+    2 px padding; a single frame is written bare) -- queued to the writer thread, on disk after flush_mask_dumps()."""
+    import pipeline_cases as PC
+    from fatezero_amd.video_diffusion.prompt_attention import spatial_blend
+    tok = ReplayTokenizer()
+    c = load_json("host_constants.json")["teaser_posche"]
+    g = torch.Generator().manual_seed(frames)
+    store = {"down_cross": [(torch.rand(frames, 2, 16, 77, generator=g) ** 6) for _ in range(4)],
+             "up_cross": [(torch.rand(frames, 2, 16, 77, generator=g) ** 6) for _ in range(3)]}
+    att = SpatialBlender(c["prompts"], c["blend_words"], tokenizer=tok, NUM_DDIM_STEPS=4, th=(0.7, 0.7), prompt_choose="source",
+                         save_path=str(tmp_path / "attention_blend_mask"))
+    for step in (0, 1):
+        for hw in (8, 8, 4):   # several layers of one step ask for the same (cached) mask: one D2H copy, one file per call
+            att(store, step_in_store=step, target_h=hw, target_w=hw)
+    spatial_blend.flush_mask_dumps()
+
+    class Ctrl:
+        attention_blend, latent_blend = att, None
+    assert PC.check_mask_dumps(str(tmp_path), Ctrl) == 6
+    assert 0 < sum(float(m.sum()) for m in att.mask_list) < sum(m.numel() for m in att.mask_list)
+
+
 def test_foreign_store_controller_inversion():
     r = PR.foreign_store_inversion("cpu")
     print(r)
