@@ -22,21 +22,34 @@
 // 16-byte stores.  Split-K (small pyramid levels: too few tiles to fill 256 CUs) writes fp32 partial slabs that
 // igemm_reduce_kernel combines with the same tail.
 #include "fz_rt.h"
+#include <type_traits>
 #include "../../include/fatezero_hip.h"
 
-// trial switches of the ping-pong loop (scripts/build_variant.sh -D...; the shipped library is built without any of them)
-#ifndef FZ_PP_K32
-#define FZ_PP_K32 0
-#endif
-#ifndef FZ_PP_NOSTAGGER
-#define FZ_PP_NOSTAGGER 0
-#endif
-#if defined(FZ_PP_NOPRIO)
-#define FZ_PP_PRIO_HI() ((void)0)
-#define FZ_PP_PRIO_LO() ((void)0)
+// PP (template parameter of the kernel): 0 = ring loop; bit 0 = phase-interleaved ("ping-pong") loop, and its trial forms (only
+// instantiated with -DFZ_IGEMM_TRIALS, scripts/igemm_ab.py): bit 1 = no s_setprio around the MFMA clusters, bit 2 = the two wave
+// groups NOT staggered, bit 3 = a phase is a whole K tile of 32 (two k sub-steps per barrier pair)
+#define FZ_PP_ON 1
+#define FZ_PP_NOPRIO 2
+#define FZ_PP_NOSTAGGER 4
+#define FZ_PP_K32 8
+#ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
+__device__ long long fz_igemm_timing[2][8];
+#define FZ_TK_DECL() long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FZ_TK(i)                              \
+    __builtin_amdgcn_sched_barrier(0);        \
+    const long long tk##i = clock64();        \
+    __builtin_amdgcn_sched_barrier(0)
+#define FZ_TK_ADD(slot, a, b) tacc_[slot] += (b) - (a)
+#define FZ_TK_FLUSH()                                                                                      \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (tid & 255) == 0)                     \
+            for (int s_ = 0; s_ < 8; ++s_) fz_igemm_timing[tid >> 8][s_] = tacc_[s_];                       \
+    } while (0)
 #else
-#define FZ_PP_PRIO_HI() fz_setprio_hi()
-#define FZ_PP_PRIO_LO() fz_setprio_lo()
+#define FZ_TK_DECL() ((void)0)
+#define FZ_TK(i) ((void)0)
+#define FZ_TK_ADD(slot, a, b) ((void)0)
+#define FZ_TK_FLUSH() ((void)0)
 #endif
 
 FZ_DEVICE_GLOBAL __attribute__((aligned(16))) half_t fz_zero_page[8192];  // 16 KB of zeros (K <= 8128 per tap)
@@ -66,7 +79,7 @@ struct IgArgs {
     float* st_out;        // per output row: (Ma / 64) x (sum, sum of squares) of the STORED values, or null
 };
 
-template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, bool PP = false>
+template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, int PP = 0>
 struct IgCfg {
     static_assert(BK == 32 || BK == 64, "K step of 32 or 64 halves");
     // PP: the phase-interleaved ("ping-pong") K loop -- two wave groups (wa = 0 / 1: one wave of each per SIMD) staggered by one
@@ -104,7 +117,7 @@ struct IgCfg {
 
 // LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
 // instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, bool PP = false>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
@@ -304,6 +317,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     //   (tile kt visible to all; everybody is done with tile kt-1, whose buffer is the one refilled next) -> issue tile
     //   kt+NS-1 -> MFMAs on tile kt.  The barrier does not drain vmcnt, so the loads span barriers (T3+T4 of the guide).
     const int ntile = kt1 - kt0;
+    FZ_TK_DECL();
     if constexpr (PP) {
         // ---- phase-interleaved loop (cdna_hip_programming.md "The 256^2 8-phase template", T3+T4+T5) --------------------------------
         // K tiles of 32 in a 4-slot ring; a PHASE is one k sub-step of 16:   R: { ds_read the phase's fragments, issue a slice of
@@ -331,11 +345,9 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             fz_wait_vm0();
         }
         fz_barrier_raw();
-#if !FZ_PP_NOSTAGGER
-        if (late) fz_barrier_raw();
-#endif
+        if (!(PP & FZ_PP_NOSTAGGER) && late) fz_barrier_raw();
         int slot = 0;
-#if FZ_PP_K32
+        if constexpr ((PP & FZ_PP_K32) != 0) {
         // trial form: a phase is a whole K tile of 32 (two k sub-steps: twice the MFMAs per barrier pair).  Tile j is read in phase j;
         // tile j+2 is issued in phase j into slot (j+2) % 4 (tile j-2: last read two phases ago) after the counted wait for tile j+1
         for (int j = 0; j < ntile; ++j) {
@@ -361,96 +373,103 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             FZ_SCHED_FENCE();
             fz_barrier_raw();
             FZ_SCHED_FENCE();
-            FZ_PP_PRIO_HI();
+            if (!(PP & FZ_PP_NOPRIO)) fz_setprio_hi();
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < TA; ++i)
 #pragma unroll
                     for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[kk][i], bf[kk][q], acc[i][q]);
-            FZ_PP_PRIO_LO();
+            if (!(PP & FZ_PP_NOPRIO)) fz_setprio_lo();
             FZ_SCHED_FENCE();
             fz_barrier_raw();
             FZ_SCHED_FENCE();
             slot = (slot + 1) & 3;
         }
-#else
+        } else {
+        // one phase: [counted wait] -> fragment reads of k sub-step KK + a slice of LDS-DMA -> barrier -> MFMA cluster -> barrier
+        auto pp_phase = [&](auto KK, const half_t* As, const half_t* Bs, int wait_kind, auto&& issue_slice) {
+            constexpr int kk = decltype(KK)::value;
+            half8_t af[TA], bf[TB];
+            FZ_TK(0);
+            if (wait_kind == 1) {
+                fz_wait_vm<C::PER>();
+            } else if (wait_kind == 2) {
+                fz_wait_vm0();
+            }
+            FZ_TK(1);
+            const int co = ((2 * kk + hi) ^ fsw) * 8;
+#pragma unroll
+            for (int q = 0; q < TB; ++q) bf[q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
+#pragma unroll
+            for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
+            issue_slice();
+            FZ_TK(2);
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            FZ_TK(3);
+#ifdef FZ_IGEMM_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // timing build only: the fragment reads' own latency, apart from the MFMAs
+            FZ_SCHED_FENCE();
+#endif
+            FZ_TK(4);
+            if (!(PP & FZ_PP_NOPRIO)) fz_setprio_hi();
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+            if (!(PP & FZ_PP_NOPRIO)) fz_setprio_lo();
+            FZ_TK(5);
+            FZ_SCHED_FENCE();
+            fz_barrier_raw();
+            FZ_SCHED_FENCE();
+            FZ_TK(6);
+            FZ_TK_ADD(0, tk0, tk1);
+            FZ_TK_ADD(1, tk1, tk2);
+            FZ_TK_ADD(2, tk2, tk3);
+            FZ_TK_ADD(3, tk3, tk4);
+            FZ_TK_ADD(4, tk4, tk5);
+            FZ_TK_ADD(5, tk5, tk6);
+            FZ_TK_ADD(6, 0, 1);
+        };
         for (int j = 0; j < ntile; ++j) {
             const half_t* As = smem + slot * C::STAGE;
             const half_t* Bs = As + C::A_HALVES;
-            half8_t af[TA], bf[TB];
-            // ---------------- phase 2j: k sub-step 0 ----------------
-            {
-                const int co = (hi ^ fsw) * 8;
-#pragma unroll
-                for (int q = 0; q < TB; ++q) bf[q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
-            }
-            if (j >= 1 && j + 2 < ntile) issue_b(slot ^ 2);  // B(j+2) -> slot (j+2) % 4
-            FZ_SCHED_FENCE();
-            fz_barrier_raw();
-            FZ_SCHED_FENCE();
-            FZ_PP_PRIO_HI();
-#pragma unroll
-            for (int i = 0; i < TA; ++i)
-#pragma unroll
-                for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
-            FZ_PP_PRIO_LO();
-            FZ_SCHED_FENCE();
-            fz_barrier_raw();
-            FZ_SCHED_FENCE();
-            // ---------------- phase 2j+1: k sub-step 1 ----------------
-            if (j + 1 < ntile) {  // tile j+1 (first read in the next phase) has landed; tile j+2 may stay in flight
-                if (j + 2 < ntile) {
-                    fz_wait_vm<C::PER>();
-                } else {
-                    fz_wait_vm0();
-                }
-            }
-            {
-                const int co = ((2 + hi) ^ fsw) * 8;
-#pragma unroll
-                for (int q = 0; q < TB; ++q) bf[q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
-            }
-            if (j + 3 < ntile) issue_a((slot + 3) & 3);      // A(j+3) -> slot (j+3) % 4
-            FZ_SCHED_FENCE();
-            fz_barrier_raw();
-            FZ_SCHED_FENCE();
-            FZ_PP_PRIO_HI();
-#pragma unroll
-            for (int i = 0; i < TA; ++i)
-#pragma unroll
-                for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
-            FZ_PP_PRIO_LO();
-            FZ_SCHED_FENCE();
-            fz_barrier_raw();
-            FZ_SCHED_FENCE();
+            // phase 2j: k sub-step 0; B(j+2) -> slot (j+2) % 4
+            pp_phase(std::integral_constant<int, 0>(), As, Bs, 0, [&]() {
+                if (j >= 1 && j + 2 < ntile) issue_b(slot ^ 2);
+            });
+            // phase 2j+1: k sub-step 1; first the counted wait: tile j+1 (first read in the next phase) has landed, tile j+2 may stay
+            // in flight; then A(j+3) -> slot (j+3) % 4
+            pp_phase(std::integral_constant<int, 1>(), As, Bs, j + 1 < ntile ? (j + 2 < ntile ? 1 : 2) : 0, [&]() {
+                if (j + 3 < ntile) issue_a((slot + 3) & 3);
+            });
             slot = (slot + 1) & 3;
         }
-#endif
-#if !FZ_PP_NOSTAGGER
-        if (!late) fz_barrier_raw();  // every wave passes the same number of barriers
-#endif
+        }
+        if (!(PP & FZ_PP_NOSTAGGER) && !late) fz_barrier_raw();  // every wave passes the same number of barriers
     } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < ntile) issue(s);
     int buf = 0;
     for (int it = 0; it < ntile; ++it) {
+        FZ_TK(0);
         if (it + NS - 1 <= ntile) {
             fz_wait_vm<(NS - 2) * C::PER>();  // steady state: NS-2 younger tiles outstanding
         } else {
             fz_wait_vm0();                    // ring tail: fewer tiles were issued, drain
         }
+        FZ_TK(1);
         fz_barrier_nodrain();
+        FZ_TK(2);
         if (it + NS - 1 < ntile) {
             int nb = buf + NS - 1;
             nb = nb >= NS ? nb - NS : nb;
             issue(nb);
         }
+        FZ_TK(3);
         const half_t* As = smem + buf * C::STAGE;
         const half_t* Bs = As + C::A_HALVES;
 #pragma unroll
@@ -466,9 +485,17 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
 #pragma unroll
                 for (int j = 0; j < TB; ++j) acc[i][j] = fz_mfma_32x32x16_f16(af[i], bf[j], acc[i][j]);
         }
+        FZ_TK(4);
+        FZ_TK_ADD(0, tk0, tk1);
+        FZ_TK_ADD(2, tk1, tk2);
+        FZ_TK_ADD(1, tk2, tk3);
+        FZ_TK_ADD(4, tk3, tk4);
+        FZ_TK_ADD(6, 0, 1);
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
     }
+
+    FZ_TK_FLUSH();
 
     // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
     if (g.part != nullptr) {
@@ -801,7 +828,7 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, bool PP = false>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0>
 static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
@@ -847,8 +874,22 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 template <int MODE, bool GEGLU, bool LN = false>
 static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
     if constexpr (!LN) {  // ping-pong K loop (last digit 8): K step 32, 4-slot ring, two wave groups half a phase apart
-        if (cfg == 244218) return ig_launch<2, 4, 4, 2, 32, 4, MODE, GEGLU, false, true>(g, batch, stream);
-        if (!GEGLU && cfg == 254218) return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, true>(g, batch, stream);
+        if (cfg == 244218) return ig_launch<2, 4, 4, 2, 32, 4, MODE, GEGLU, false, 1>(g, batch, stream);
+        if (!GEGLU && cfg == 254218) return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1>(g, batch, stream);
+#ifdef FZ_IGEMM_TRIALS  // trial forms: tile id + 1000000 * (PP bits >> 1)
+        if (!GEGLU && MODE != 2) {
+            switch (cfg) {
+                case 1254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 2>(g, batch, stream);
+                case 2254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 4>(g, batch, stream);
+                case 3254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 2 | 4>(g, batch, stream);
+                case 4254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 8>(g, batch, stream);
+                case 5254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 2 | 8>(g, batch, stream);
+                case 1244218: return ig_launch<2, 4, 4, 2, 32, 4, MODE, false, false, 1 | 2>(g, batch, stream);
+                case 5244218: return ig_launch<2, 4, 4, 2, 32, 4, MODE, false, false, 1 | 2 | 8>(g, batch, stream);
+                default: break;
+            }
+        }
+#endif
     }
     switch (cfg) {
         case 244222: return ig_launch<2, 4, 4, 2, 64, 2, MODE, GEGLU, LN>(g, batch, stream);
@@ -1074,15 +1115,59 @@ static int conv_common(IgArgs& g, const void* x, const void* wt, const void* bia
     return FZ_OK;
 }
 
+// Temporal k=3 convolution with fewer than 8 channels on a side: conv_out's rank-2 LoRA pair (4 -> 2 -> 4, lora.py:26-28 caps the
+// rank at min(in, out) / 2) and the 4 -> 4 Conv1d of conv_out in configs without a `lora` key (resnet.py:42-55).  A few FLOPs per
+// byte: one thread per (frame, token), weights in LDS, plain VALU.
+FZ_KERNEL void __launch_bounds__(256) temporal_conv3_small_kernel(IgArgs g) {
+    FZ_SHARED float wl[3 * 8 * 8];
+    const int cin = g.Cin, cout = g.Ma;
+    for (int id = threadIdx.x; id < cout * 3 * cin; id += 256) wl[id] = (float)g.a[id];  // [cout][3][cin]
+    __syncthreads();
+    const int64_t tokens = g.Wo;
+    const int64_t total = (int64_t)g.N * tokens;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int n = (int)(id / tokens);
+        const int f = n % g.fpb;
+        float xin[3][8];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int fs = f + t - 1;
+            const bool inb = fs >= 0 && fs < g.fpb;
+            const half_t* xs = g.b + (id + (int64_t)(inb ? t - 1 : 0) * tokens) * cin;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) xin[t][ci] = (inb && ci < cin) ? (float)xs[ci < cin ? ci : 0] : 0.0f;
+        }
+        half_t* yo = g.y + id * cout;
+        for (int co = 0; co < cout; ++co) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci)
+                    if (ci < cin) acc += xin[t][ci] * wl[(co * 3 + t) * cin + ci];
+            if (g.temb != nullptr) acc += (float)g.temb[(id / g.temb_group) * g.temb_stride + co];
+            if (g.res != nullptr) acc += (float)g.res[id * cout + co];
+            if (g.res2 != nullptr) acc += (float)g.res2[id * cout + co];
+            yo[co] = (half_t)acc;
+        }
+    }
+}
+
 extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
                                 int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len,
                                 void* workspace, int64_t workspace_floats, void* stream) {
     if (!x || !wt || !y || n <= 0 || tokens <= 0 || clip_len <= 0 || n % clip_len) return FZ_ERR_BAD_ARG;
-    if (cin % 8) return FZ_ERR_UNSUPPORTED;
     IgArgs g = {};
     g.taps = 3;
     g.N = n; g.Hi = 1; g.Wi = tokens; g.Ho = 1; g.Wo = tokens; g.stride = 1; g.upsample = 0; g.fpb = clip_len;
     conv_common(g, x, wt, nullptr, temb, temb_stride, res, res2, y, cin, cout);
+    if (cin % 8 || cout < 8) {  // conv_out's 4 / 2-channel temporal convolutions: direct VALU kernel
+        if (cin > 8 || cout > 8 || cin <= 0 || cout <= 0) return FZ_ERR_UNSUPPORTED;
+        const int64_t total = (int64_t)n * tokens;
+        dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+        FZ_LAUNCH(temporal_conv3_small_kernel, grid, block, 0, stream, g);
+        return fz_last_launch_status();
+    }
     return ig_run<2, false>(g, 1, 0, 0, (float*)workspace, workspace_floats, stream);
 }
 

@@ -76,8 +76,15 @@ class PseudoConv3d(nn.Module):
             bias = self.bias.detach().to(device=device, dtype=dtype)
             wtt = btt = None
             if self.conv_temporal is not None and not isinstance(self.conv_temporal, LoRALinearLayer):
-                wtt = self.conv_temporal.weight.detach().to(device=device, dtype=dtype).permute(2, 1, 0).contiguous()
-                btt = self.conv_temporal.bias.detach().to(device=device, dtype=dtype)
+                # plain nn.Conv1d over the frames (resnet.py:42-55), initialised to the identity: the dirac weight with a zero
+                # bias is an exact no-op and is skipped (wtt None); anything else runs on fz_temporal_conv3, the bias as a row
+                # added per batch element (two rows: the CFG batch)
+                tw, tb = self.conv_temporal.weight.detach(), self.conv_temporal.bias.detach()
+                ident = torch.zeros_like(tw)
+                nn.init.dirac_(ident)
+                if not (bool((tw == ident).all()) and bool((tb == 0).all())):
+                    wtt = pack_temporal_weight(tw, dtype, device)
+                    btt = tb.to(device=device, dtype=dtype)
             self._packed = (w, bias, wtt, btt)
         return self._packed
 
@@ -89,7 +96,7 @@ class PseudoConv3d(nn.Module):
         w, bias, wtt, btt = self._pack(x.data.dtype, x.data.device)
         n, hw, c = x.data.shape
         lora = self.conv_temporal if isinstance(self.conv_temporal, LoRALinearLayer) else None
-        plain_t = self.conv_temporal is not None and lora is None
+        plain_t = self.conv_temporal is not None and lora is None and wtt is not None
         temporal_active = plain_t or (lora is not None and not lora.is_noop(x.data.dtype, x.data.device))
         fuse_tail = not temporal_active  # the elementwise tail commutes with nothing but the last linear op
         if self.kernel_size == 1:
@@ -107,8 +114,17 @@ class PseudoConv3d(nn.Module):
             y = y4.reshape(n, oh * ow, self.out_channels)
             fused = True
         elif plain_t:
-            y4 = temporal_conv_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), wtt, bias=btt)
-            y = y4.reshape(n, oh * ow, self.out_channels)
+            rows = btt[None, :].expand(x.b, -1) if temb is None else temb + btt
+            shard = D.active_shard()
+            y4 = y.view(x.b, x.f, oh * ow, self.out_channels)
+            if shard is not None:  # frames split over ranks: one-frame halo from both neighbours, halo outputs dropped
+                y4 = temporal_conv_tokens(shard.with_halo(y4, 1, 1, zero_outside=True), wtt, rows_add=rows.contiguous())[:, 1:-1]
+                y = y4.reshape(n, oh * ow, self.out_channels)
+                if residual is not None:
+                    y = y + residual
+            else:
+                y = temporal_conv_tokens(y4, wtt, rows_add=rows.contiguous(), residual=residual).reshape(n, oh * ow, self.out_channels)
+            fused = True
         if not fused:
             if temb is not None:
                 y = (y.view(x.b, x.f * oh * ow, self.out_channels) + temb[:, None, :]).view(n, oh * ow, self.out_channels)

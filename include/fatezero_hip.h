@@ -220,7 +220,9 @@ int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb
  * '(b h w) c f'): y[n][tok][co] = sum_{t=0..2, ci} x[n - f + (f+t-1)][tok][ci] * wt[co][t][ci] (+ res), zero padded at the
  * clip ends (f = n % clip_len).  x: [n][tokens][cin]; wt: [cout][3][cin]; y/res/res2: [n][tokens][cout];
  * temb (optional): [n/clip_len] rows of cout values, temb_stride elements apart (ResnetBlock's time embedding add,
- * resnet.py:366-376, fused behind the temporal conv).
+ * resnet.py:366-376, fused behind the temporal conv).  Also the plain nn.Conv1d temporal convolution of configs without a
+ * `lora` key (resnet.py:42-55; its bias rides in `temb`).  cin % 8 == 0 and cout >= 8: MFMA implicit GEMM; cin, cout <= 8
+ * (conv_out: 4 -> 2 -> 4 and 4 -> 4 channels): a direct VALU kernel.
  * workspace / workspace_floats: optional split-K scratch as for fz_gemm (the rank-160 projection at the small levels has too
  * few output tiles to fill the chip otherwise). */
 int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,

@@ -403,17 +403,22 @@ def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_t
     return {"max_err": err}
 
 
-def case_temporal_conv3(device, *, batch, clip, tokens, cin, cout, with_res, seed=0):
+def case_temporal_conv3(device, *, batch, clip, tokens, cin, cout, with_res, seed=0, with_rows=False):
+    """k=3 convolution over the frame axis (lora.py:31-54, resnet.py:42-55); with_rows: one row of cout values per batch element
+    added to every output (the time embedding / the Conv1d bias riding in fz_temporal_conv3's `temb`)."""
     g = torch.Generator().manual_seed(seed)
     n = batch * clip
     x = torch.randn(n, tokens, cin, generator=g).half().to(device)
     w = (torch.randn(cout, cin, 3, generator=g) * (3 * cin) ** -0.5).half()
     res = torch.randn(n, tokens, cout, generator=g).half().to(device) if with_res else None
-    y = K.temporal_conv3(x, w.permute(0, 2, 1).contiguous().to(device), clip_len=clip, res=res)
+    rows = torch.randn(batch, cout, generator=g).half().to(device) if with_rows else None
+    y = K.temporal_conv3(x, w.permute(0, 2, 1).contiguous().to(device), clip_len=clip, res=res, temb=rows)
     xr = x.float().cpu().reshape(batch, clip, tokens, cin).permute(0, 2, 3, 1).reshape(batch * tokens, cin, clip)
     yr = F.conv1d(xr, w.float(), None, padding=1).reshape(batch, tokens, cout, clip).permute(0, 3, 1, 2).reshape(n, tokens, cout)
     if with_res:
         yr = yr + res.float().cpu()
+    if with_rows:
+        yr = yr + rows.float().cpu().repeat_interleave(clip, 0)[:, None, :]
     err = (y.float().cpu() - yr).abs().max().item()
     assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
     return {"max_err": err}

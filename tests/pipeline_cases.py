@@ -173,42 +173,44 @@ def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_
     return (res, pipe) if return_pipe else res
 
 
-# Stated tolerances (fp16 storage/MFMA inputs with fp32 accumulation vs the fp32 reference, 4 DDIM steps each way):
-LATENT_TOL = 2.5e-2      # max |latent error| / max |latent|
-MAP_TOL = 2e-2           # absolute, on probabilities in [0,1], END TO END (fp16 q/k/activations upstream of a peaky
-                         # softmax); given identical q/k the kernels store P within 1.6 fp16 ulp (kernel_cases.py)
+# Stated tolerances (fp16 storage / MFMA inputs with fp32 accumulation vs the fp32 reference, 4 DDIM steps each way).  Re-measured
+# in round 3 on the all-native build (every kernel of the path is our own and bit-deterministic run to run, so the bands only
+# cover the fp16 arithmetic itself -- profiles/r03_parity_numbers*.txt holds the measured values; each bound is ~1.5-2x the worst
+# measured case):
+LATENT_TOL = 1.0e-2      # inversion: max |latent error| / max |latent|          (measured 0.36 - 0.47 % on the 8 recordings)
+EDIT_Q99_TOL = 1.25e-2   # edit vs the reference recording, 99th percentile      (measured 0.49 - 0.77 %)
+EDIT_MAX_TOL = 2.5e-2    # edit vs the reference recording, max, no blend mask   (measured 1.13 - 1.40 %)
+MAP_TOL = 2e-2           # captured cross maps, absolute on probabilities in [0,1], END TO END (fp16 q/k/activations upstream of
+                         # a peaky softmax; measured 0.85e-2 - 1.37e-2); given identical q/k the kernels store P within 1.6 fp16
+                         # ulp (kernel_cases.py)
+SELF_MAP_TOL = 4e-3      # captured self-attention maps, absolute                (measured 0.3e-3 - 1.7e-3)
 MASK_FLIP_TOL = 1.5e-2   # fraction of mask elements that may differ from the all-fp32 reference run: the mask thresholds a
                          # normalised score, and the captured fp16 maps carry ~1e-2 of upstream fp16 noise, so pixels
-                         # sitting within ~1% of the threshold flip.  Given IDENTICAL captured maps (oracle edit run on
-                         # the native inversion maps) the attention-blend masks must be bit-exact: 0 differing elements.
-EDIT_TOL_SAME_MAPS = 2.5e-2
-EDIT_TOL_VS_REFERENCE = 6e-2   # edit pass vs the all-fp32 reference when blend masks are in play (mask flips are discrete)
+                         # sitting within ~1% of the threshold flip (measured 0.06 - 0.98 %).  Given IDENTICAL captured maps
+                         # (oracle edit run on the native inversion maps) the attention-blend masks must be bit-exact: 0 flips.
+EDIT_TOL_SAME_MAPS = 1.5e-2     # edit vs the oracle's edit on the natively captured maps, max   (measured 0.53 - 0.93 %)
+EDIT_TOL_VS_REFERENCE = 6e-2    # edit vs the all-fp32 reference, MAX, when blend masks are in play: a flipped mask pixel moves
+                                # that latent by |x - inverted| -- discrete, of the order of the latent scale (measured 1.7 - 4.7 %)
 
 
 def check(res):
     assert res["inv_err"] <= LATENT_TOL * res["inv_scale"], res
     has_mask = "attn_mask_flips" in res or "latent_mask_flips" in res
     latent_blend = "latent_mask_flips" in res
-    if latent_blend:
-        # the target-prompt half of the latent-blend mask is thresholded from the LIVE cross maps (fp16 noise): isolated
-        # pixel flips are inherent, so the bound is on the 99th percentile of the error, the max is only reported
-        assert res["edit_err_q99"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
-    elif has_mask:
-        assert res["edit_err"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
-    else:
-        # no masks: the bulk of the latents (99th percentile) must sit within the latent tolerance; the max is allowed the
-        # wider band because the reweighted (x10) cross-attention amplifies single fp16 roundings of the library GEMM / conv
-        # kernels into a handful of outlier values that move from run to run (measured 1.5 % .. 2.7 % of the range)
-        assert res["edit_err_q99"] <= LATENT_TOL * res["edit_scale"], res
-        assert res["edit_err"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
+    # the bulk of the latents (99th percentile) sits within the same band in every scenario, masks or not
+    assert res["edit_err_q99"] <= EDIT_Q99_TOL * res["edit_scale"], res
+    # the max: without masks every value is bounded; with masks single flipped pixels (counted and bounded below) may move
+    assert res["edit_err"] <= (EDIT_TOL_VS_REFERENCE if has_mask else EDIT_MAX_TOL) * res["edit_scale"], res
     if "edit_err_vs_oracle_on_native_maps" in res:
-        key = "edit_err_vs_oracle_on_native_maps_q99" if latent_blend else "edit_err_vs_oracle_on_native_maps"
-        assert res[key] <= EDIT_TOL_SAME_MAPS * res["edit_scale"], res
+        # the target-prompt half of a latent-blend mask is thresholded from the LIVE cross maps, which differ between the native
+        # run and the oracle by fp16 noise even on identical inversion maps: the max may contain such a flip there
+        assert res["edit_err_vs_oracle_on_native_maps_q99"] <= EDIT_Q99_TOL * res["edit_scale"], res
+        assert res["edit_err_vs_oracle_on_native_maps"] <= (EDIT_TOL_VS_REFERENCE if latent_blend else EDIT_TOL_SAME_MAPS) * res["edit_scale"], res
     if "attn_mask_flips_same_maps" in res:
         assert res["attn_mask_flips_same_maps"] == 0, res
     if "latent_mask_flips_same_inv_maps" in res:
         assert res["latent_mask_flips_same_inv_maps"] <= MASK_FLIP_TOL * res["latent_mask_total"], res
-    assert res["map_err"] <= MAP_TOL and res["self_map_err"] <= MAP_TOL, res
+    assert res["map_err"] <= MAP_TOL and res["self_map_err"] <= SELF_MAP_TOL, res
     for k in ("attn_mask", "latent_mask"):
         if k + "_flips" in res:
             assert res[k + "_flips"] <= MASK_FLIP_TOL * res[k + "_total"], res
@@ -325,10 +327,17 @@ def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="repl
     return res
 
 
+# full SD-1.x width, 2 + 2 steps, 3 frames (measured: inversion 0.10 - 0.11 %, cross maps 0.6e-2 - 0.7e-2, self maps 1e-3, edit on the
+# natively captured maps 0.72 - 0.74 % max / 0.39 - 0.43 % q99)
+FULL_LATENT_TOL = 4e-3
+FULL_MAP_TOL = 1.2e-2
+
+
 def check_fullwidth(res):
-    assert res["inv_err"] <= LATENT_TOL * res["inv_scale"], res
-    assert res["map_err"] <= MAP_TOL and res["self_map_err"] <= MAP_TOL, res
+    assert res["inv_err"] <= FULL_LATENT_TOL * res["inv_scale"], res
+    assert res["map_err"] <= FULL_MAP_TOL and res["self_map_err"] <= SELF_MAP_TOL, res
     assert res["edit_err_vs_oracle_on_native_maps"] <= EDIT_TOL_SAME_MAPS * res["edit_scale"], res
+    assert res["edit_err_vs_oracle_on_native_maps_q99"] <= EDIT_Q99_TOL * res["edit_scale"], res
     if "attn_mask_flips_same_maps" in res:
         assert res["attn_mask_flips_same_maps"] == 0, res
         assert 0 < res["mask_ones"] < res["attn_mask_total"], res   # a degenerate (all-0 / all-1) mask would test nothing
@@ -408,7 +417,10 @@ def run_drift_case(device, T=50, F=2, L=32, marks=(10, 25, 50), seed=5):
     return res
 
 
+DRIFT_TOL = {"inv": 4e-3, "edit": 1.5e-2}   # measured at steps 10 / 25 / 50: inversion 0.03 / 0.06 / 0.15 %, edit 0.67 / 0.89 / 0.82 %
+
+
 def check_drift(res):
     for part in ("inv", "edit"):
         for m, e in res[part].items():
-            assert e <= LATENT_TOL, (part, m, res)
+            assert e <= DRIFT_TOL[part], (part, m, res)

@@ -172,8 +172,10 @@ def edit_type_none_and_save(device, T=2):
     return res
 
 
-LATENT_TOL = 2.5e-2  # of max |latent| (fp16 storage vs the fp32 oracle), tests/pipeline_cases.py
-MAP_TOL = 2e-2
+# re-measured in round 3 on the all-native build (profiles/r03_parity_numbers*.txt): foreign store 0.12 % / maps 0.54e-2, foreign edit
+# 0.85 - 1.02 %, edit_type None / save 0.56 / 0.61 %, saved maps 0.65e-2 (first step) / 2.8e-2 (last step)
+LATENT_TOL = 1.25e-2  # of max |latent| (fp16 storage vs the fp32 oracle)
+MAP_TOL = 1.2e-2
 
 
 def check_foreign_store(r):
@@ -186,11 +188,11 @@ def check_foreign_store(r):
 def check_foreign_edit(r):
     assert r["calls_per_step"] in (32, 22), r   # 22: the ten 64x64-token layers bypass a foreign controller
     for k in ("foreign_vs_native", "foreign_vs_oracle", "native_vs_oracle"):
-        assert r[k] <= 6e-2 * r["scale"], r   # blend masks in play (tests/pipeline_cases.py: EDIT_TOL_VS_REFERENCE)
+        assert r[k] <= 2.5e-2 * r["scale"], r   # blend masks in play, but no flip moves the max here (measured 1.0 %)
 
 
 def check_none_save(r):
     assert r["none_err"] <= LATENT_TOL * r["scale"] and r["save_err"] <= LATENT_TOL * r["scale"], r
     # step 0 sees identical latents on both sides; after a guidance-7.5 step from pure noise the (deliberately peaky) cross
     # maps carry the amplified fp16 noise of the first step, hence the wider band on the last step
-    assert r["save_map_err"] <= MAP_TOL and r["save_map_err_last"] <= 5 * MAP_TOL and r["mask_list"] is None, r
+    assert r["save_map_err"] <= MAP_TOL and r["save_map_err_last"] <= 5e-2 and r["mask_list"] is None, r

@@ -178,6 +178,11 @@ def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=3, tokens=20, cin=64, cout=32, with_res=False)
     KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
     KC.case_temporal_conv3(DEV, batch=1, clip=1, tokens=16, cin=32, cout=40, with_res=True)
+    # conv_out's channel counts (rank-2 LoRA pair 4 -> 2 -> 4, plain Conv1d 4 -> 4): the direct kernel; rows = bias / time embedding
+    KC.case_temporal_conv3(DEV, batch=2, clip=3, tokens=50, cin=4, cout=2, with_res=False)
+    KC.case_temporal_conv3(DEV, batch=2, clip=3, tokens=50, cin=2, cout=4, with_res=True)
+    KC.case_temporal_conv3(DEV, batch=2, clip=4, tokens=33, cin=4, cout=4, with_res=True, with_rows=True)
+    KC.case_temporal_conv3(DEV, batch=2, clip=2, tokens=40, cin=32, cout=32, with_res=True, with_rows=True)
 
 
 @pytest.mark.parametrize("lo,hi", [(0, 2), (2, 4), (3, 5)])

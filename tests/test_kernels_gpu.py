@@ -192,7 +192,8 @@ def test_pingpong_loop_bit_equal_to_ring_loop(ring, pp):
     # per-XCD tap window above L2) walk (k chunk, tap) and so contract in a different order with K step 32 than with 64: those
     # agree to an fp16 rounding of the result
     for (n, hw, cin, cout, stride, up, sk, exact) in [(8, 64, 320, 320, 1, False, 1, True), (16, 64, 320, 320, 1, False, 1, False),
-                                                      (4, 32, 1920, 640, 1, False, 1, False), (4, 32, 640, 640, 2, False, 1, True),
+                                                      (4, 32, 1920, 640, 1, False, 1, False), (4, 32, 640, 640, 2, False, 1, False),
+                                                      (4, 32, 320, 640, 2, False, 1, True),
                                                       (4, 16, 1280, 1280, 1, True, 1, True), (8, 16, 2560, 1280, 1, False, 4, False),
                                                       (2, 24, 328, 320, 1, False, 1, True)]:
         x = torch.randn(n, hw * hw, cin, generator=g).half().to(DEV)
@@ -224,6 +225,11 @@ def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=160, cout=320, with_res=True)
     KC.case_temporal_conv3(DEV, batch=1, clip=8, tokens=64, cin=160, cout=1280, with_res=True)
     KC.case_temporal_conv3(DEV, batch=1, clip=3, tokens=100, cin=1280, cout=160, with_res=False)
+    # conv_out's channel counts (rank-2 LoRA pair 4 -> 2 -> 4, plain Conv1d 4 -> 4): the direct kernel
+    KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=4, cout=2, with_res=False)
+    KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=2, cout=4, with_res=True)
+    KC.case_temporal_conv3(DEV, batch=1, clip=3, tokens=77, cin=4, cout=4, with_res=True, with_rows=True)
+    KC.case_temporal_conv3(DEV, batch=2, clip=4, tokens=256, cin=320, cout=320, with_res=True, with_rows=True)
 
 
 @pytest.mark.parametrize("lo,hi", [(0, 2), (2, 4), (3, 5)])
