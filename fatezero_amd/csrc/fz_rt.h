@@ -52,6 +52,16 @@ FZ_DEVICE int fz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // keeps a rarely taken branch a branch (hipcc otherwise if-converts it into per-use v_cndmask on the common path)
 #define FZ_COLD_PATH() asm volatile("" ::: "memory")
 #define FZ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* the scheduler moves nothing across: keeps unrolled loads from piling up */
+// the value is materialised in VGPRs HERE: address arithmetic computed ahead of its use is not re-derived (sunk) next to the use
+#define FZ_PIN_V(x) asm volatile("" : "+v"(x))
+// A byte address inside the workgroup's LDS as a plain 32-bit value (the low half of the flat address): survives FZ_PIN_V without
+// the pointer decaying to a flat one (flat_load instead of ds_read), and `fz_lds_ld_h8(a, constant)` folds the constant into the
+// instruction's 16-bit offset field -- a ds_read_b128 with no address arithmetic at the point of use.
+typedef uint32_t fz_lds_addr;
+FZ_DEVICE fz_lds_addr fz_lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)p; }
+FZ_DEVICE half8_t fz_lds_ld_h8(fz_lds_addr a, uint32_t byte_off) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) half8_t*>((uintptr_t)(a + byte_off));
+}
 FZ_DEVICE float fz_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE int fz_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 FZ_DEVICE float fz_shfl(float v, int lane) { return __shfl(v, lane, 64); }
@@ -157,6 +167,9 @@ static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) { retu
 static inline int fz_uniform(int v) { return v; }
 #define FZ_COLD_PATH() ((void)0)
 #define FZ_SCHED_FENCE() ((void)0)
+#define FZ_PIN_V(x) ((void)0)
+typedef uint32_t fz_lds_addr;  // emulation: byte offset from the block's dynamic LDS
+static inline fz_lds_addr fz_lds_addr_of(const void* p) { return (uint32_t)((const unsigned char*)p - fz_emu::t_dyn_smem); }
 static inline float fz_shfl_xor(float v, int mask) {
     float all[64];
     fz_emu::wave_exchange(&v, all, sizeof(float));
@@ -226,6 +239,11 @@ FZ_DEVICE f32x16 fz_zero_f16v() {
     return z;
 }
 FZ_DEVICE half8_t fz_ld_h8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
+#ifdef FZ_EMU
+static inline half8_t fz_lds_ld_h8(fz_lds_addr a, uint32_t byte_off) {
+    return *reinterpret_cast<const half8_t*>(fz_emu::t_dyn_smem + a + byte_off);
+}
+#endif
 // 16-byte load from a wave-uniform base plus a 32-bit per-lane byte offset (the SGPR-base + VGPR-offset global_load form)
 FZ_DEVICE half8_t fz_ld_h8_off(const char* base, uint32_t byte_off) {
     return *reinterpret_cast<const half8_t*>(base + byte_off);

@@ -27,11 +27,12 @@
 
 // PP (template parameter of the kernel): 0 = ring loop; bit 0 = phase-interleaved ("ping-pong") loop, and its trial forms (only
 // instantiated with -DFZ_IGEMM_TRIALS, scripts/igemm_ab.py): bit 1 = no s_setprio around the MFMA clusters, bit 2 = the two wave
-// groups NOT staggered, bit 3 = a phase is a whole K tile of 32 (two k sub-steps per barrier pair)
+// groups NOT staggered, bit 3 = the address VALU of the next phase runs at the START of that phase (in the read half, the round-3
+// v1 form) instead of inside the MFMA cluster before it
 #define FZ_PP_ON 1
 #define FZ_PP_NOPRIO 2
 #define FZ_PP_NOSTAGGER 4
-#define FZ_PP_K32 8
+#define FZ_PP_PREP_IN_R 8
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
 __device__ long long fz_igemm_timing[2][8];
 #define FZ_TK_DECL() long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -238,28 +239,35 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         ikc = kt0 - itap * g.kchunks;
     }
     if (MODE == 1 || MODE == 2) retarget(itap);
-    // one K tile = the A part (weights) + the B part (pixels) + the cursor step; the ring loops issue them together, the
-    // ping-pong loop in different phases (A first: the cursor moves after B)
-    auto issue_a = [&](int buf) {
+    // one K tile = the A part (weights) + the B part (pixels) + the cursor step.  Each part is split into PREP (the per-lane source
+    // addresses of the tile the cursor points at: VALU) and FIRE (the LDS-DMA instructions themselves: M0 + VMEM issue, no VALU); the
+    // ring loops run them back to back, the ping-pong loop preps inside its own MFMA cluster and fires in the next read phase
+    // (A first: the cursor moves with B's prep).
+    const char* asrc[C::ACH];
+    const char* bsrc[C::BCH];
+    auto prep_a = [&]() {
         const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offset along K
-        char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
         if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
             FZ_COLD_PATH();
 #pragma unroll
-            for (int i = 0; i < C::ACH; ++i)
-                fz_glds16(asc[i] * 8 < ktail && !(PP && apad[i]) ? aptr[i] + ka : zero, Ab + (i * C::NW + wave) * 1024);
+            for (int i = 0; i < C::ACH; ++i) asrc[i] = asc[i] * 8 < ktail && !(PP && apad[i]) ? aptr[i] + ka : zero;
         } else {
 #pragma unroll
             for (int i = 0; i < C::ACH; ++i) {
                 if (PP && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
-                    fz_glds16(apad[i] ? zero : aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
+                    asrc[i] = apad[i] ? zero : aptr[i] + ka;
                 } else {
-                    fz_glds16(aptr[i] + ka, Ab + (i * C::NW + wave) * 1024);
+                    asrc[i] = aptr[i] + ka;
                 }
             }
         }
     };
-    auto issue_b = [&](int buf) {
+    auto fire_a = [&](int buf) {
+        char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) fz_glds16(asrc[i], Ab + (i * C::NW + wave) * 1024);
+    };
+    auto prep_b = [&]() {
         int64_t kb = ikc * BK * 2;
         int need = 0;  // KORD: validity bits this tap requires
         if (KORD) {
@@ -267,21 +275,20 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             kb += ((int64_t)(ky - 1) * g.Wi + (kx - 1)) * g.ldb * 2;
             need = (1 << ky) | (8 << kx);
         }
-        char* Bb = reinterpret_cast<char*>(smem + buf * C::STAGE) + C::A_HALVES * 2;
         if (ikc == g.kchunks - 1 && ktail < BK) {
             FZ_COLD_PATH();
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
                 const bool ok = bsc[i] * 8 < ktail && (!KORD || (bflag[i] & need) == need);
-                fz_glds16(ok ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
+                bsrc[i] = ok ? bptr[i] + kb : zero;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
                 if (KORD) {
-                    fz_glds16((bflag[i] & need) == need ? bptr[i] + kb : zero, Bb + (i * C::NW + wave) * 1024);
+                    bsrc[i] = (bflag[i] & need) == need ? bptr[i] + kb : zero;
                 } else {
-                    fz_glds16(bptr[i] + kb, Bb + (i * C::NW + wave) * 1024);
+                    bsrc[i] = bptr[i] + kb;
                 }
             }
         }
@@ -296,9 +303,24 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             if ((MODE == 1 || MODE == 2) && itap < g.taps) retarget(itap);
         }
     };
+    auto fire_b = [&](int buf) {
+        char* Bb = reinterpret_cast<char*>(smem + buf * C::STAGE) + C::A_HALVES * 2;
+#pragma unroll
+        for (int i = 0; i < C::BCH; ++i) fz_glds16(bsrc[i], Bb + (i * C::NW + wave) * 1024);
+    };
     auto issue = [&](int buf) {
-        issue_a(buf);
-        issue_b(buf);
+        prep_a();
+        fire_a(buf);
+        prep_b();
+        fire_b(buf);
+    };
+    auto pin_a = [&]() {  // the prepared addresses exist as registers from here on (not re-derived next to the DMA instruction)
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) FZ_PIN_V(asrc[i]);
+    };
+    auto pin_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::BCH; ++i) FZ_PIN_V(bsrc[i]);
     };
 
     f32x16 acc[TA][TB];
@@ -346,50 +368,19 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         }
         fz_barrier_raw();
         if (!(PP & FZ_PP_NOSTAGGER) && late) fz_barrier_raw();
-        int slot = 0;
-        if constexpr ((PP & FZ_PP_K32) != 0) {
-        // trial form: a phase is a whole K tile of 32 (two k sub-steps: twice the MFMAs per barrier pair).  Tile j is read in phase j;
-        // tile j+2 is issued in phase j into slot (j+2) % 4 (tile j-2: last read two phases ago) after the counted wait for tile j+1
-        for (int j = 0; j < ntile; ++j) {
-            const half_t* As = smem + slot * C::STAGE;
-            const half_t* Bs = As + C::A_HALVES;
-            half8_t af[2][TA], bf[2][TB];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int co = ((2 * kk + hi) ^ fsw) * 8;
-#pragma unroll
-                for (int q = 0; q < TB; ++q) bf[kk][q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) af[kk][i] = fz_ld_h8(As + arow + i * 32 * BK + co);
-            }
-            if (j >= 1 && j + 2 < ntile) issue(slot ^ 2);
-            if (j + 1 < ntile) {  // tile j+1 (read in the next phase) has landed; tile j+2 stays in flight
-                if (j + 2 < ntile) {
-                    fz_wait_vm<C::PER>();
-                } else {
-                    fz_wait_vm0();
-                }
-            }
-            FZ_SCHED_FENCE();
-            fz_barrier_raw();
-            FZ_SCHED_FENCE();
-            if (!(PP & FZ_PP_NOPRIO)) fz_setprio_hi();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TA; ++i)
-#pragma unroll
-                    for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[kk][i], bf[kk][q], acc[i][q]);
-            if (!(PP & FZ_PP_NOPRIO)) fz_setprio_lo();
-            FZ_SCHED_FENCE();
-            fz_barrier_raw();
-            FZ_SCHED_FENCE();
-            slot = (slot + 1) & 3;
-        }
-        } else {
-        // one phase: [counted wait] -> fragment reads of k sub-step KK + a slice of LDS-DMA -> barrier -> MFMA cluster -> barrier
-        auto pp_phase = [&](auto KK, const half_t* As, const half_t* Bs, int wait_kind, auto&& issue_slice) {
-            constexpr int kk = decltype(KK)::value;
+        // One phase:  R: [counted wait] -> the fragment reads of this k sub-step + FIRE of the LDS-DMA slice prepared one phase ago --
+        // LDS / VMEM / scalar instructions only -> barrier ->  M: the TA x TB MFMAs, and between them ALL the VALU of the next phase
+        // (its LDS read addresses `ra` / `rb`, PREP of the next DMA slice, the cursor step) -> barrier.
+        // Why the VALU lives in M (profiles/r03_igemm_timeline_v1.txt): while the other wave of the SIMD runs its MFMA cluster, a
+        // VALU instruction of this wave gets the shared issue port about once per MFMA (~30 cycles each) -- 15 address instructions in
+        // R made the read half of a phase 460-560 cycles long against 320 cycles of MFMA.  Inside its OWN cluster the wave's VALU
+        // rides in the shadow of its MFMAs (each leaves seven free issue quads).
+        const int oa0 = arow + (hi ^ fsw) * 8, oa1 = arow + ((2 + hi) ^ fsw) * 8;   // per-lane halves offsets of k sub-steps 0 / 1
+        const int ob0 = C::A_HALVES + brow + (hi ^ fsw) * 8, ob1 = C::A_HALVES + brow + ((2 + hi) ^ fsw) * 8;
+        fz_lds_addr ra = fz_lds_addr_of(smem + oa0), rb = fz_lds_addr_of(smem + ob0);
+        FZ_PIN_V(ra);
+        FZ_PIN_V(rb);
+        auto pp_phase = [&](int wait_kind, auto&& fire, auto&& prep) {
             half8_t af[TA], bf[TB];
             FZ_TK(0);
             if (wait_kind == 1) {
@@ -398,12 +389,11 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
                 fz_wait_vm0();
             }
             FZ_TK(1);
-            const int co = ((2 * kk + hi) ^ fsw) * 8;
 #pragma unroll
-            for (int q = 0; q < TB; ++q) bf[q] = fz_ld_h8(Bs + brow + q * 32 * BK + co);
+            for (int q = 0; q < TB; ++q) bf[q] = fz_lds_ld_h8(rb, q * 32 * BK * 2);
 #pragma unroll
-            for (int i = 0; i < TA; ++i) af[i] = fz_ld_h8(As + arow + i * 32 * BK + co);
-            issue_slice();
+            for (int i = 0; i < TA; ++i) af[i] = fz_lds_ld_h8(ra, i * 32 * BK * 2);
+            fire();
             FZ_TK(2);
             FZ_SCHED_FENCE();
             fz_barrier_raw();
@@ -416,15 +406,18 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             FZ_TK(4);
             if (!(PP & FZ_PP_NOPRIO)) fz_setprio_hi();
 #pragma unroll
-            for (int i = 0; i < TA; ++i)
+            for (int i = 0; i < TA; ++i) {
 #pragma unroll
                 for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+                if (i == 0 && !(PP & FZ_PP_PREP_IN_R)) prep();  // VALU of the next phase, behind the first MFMAs of this one
+            }
             if (!(PP & FZ_PP_NOPRIO)) fz_setprio_lo();
             FZ_TK(5);
             FZ_SCHED_FENCE();
             fz_barrier_raw();
             FZ_SCHED_FENCE();
             FZ_TK(6);
+            if (PP & FZ_PP_PREP_IN_R) prep();
             FZ_TK_ADD(0, tk0, tk1);
             FZ_TK_ADD(1, tk1, tk2);
             FZ_TK_ADD(2, tk2, tk3);
@@ -433,21 +426,46 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             FZ_TK_ADD(5, tk5, tk6);
             FZ_TK_ADD(6, 0, 1);
         };
-        for (int j = 0; j < ntile; ++j) {
-            const half_t* As = smem + slot * C::STAGE;
-            const half_t* Bs = As + C::A_HALVES;
-            // phase 2j: k sub-step 0; B(j+2) -> slot (j+2) % 4
-            pp_phase(std::integral_constant<int, 0>(), As, Bs, 0, [&]() {
-                if (j >= 1 && j + 2 < ntile) issue_b(slot ^ 2);
+        int slot = 0;
+        // one K tile = two phases.  STEADY: 1 <= j and j + 3 < ntile, every condition below is true -- the loop over those tiles
+        // carries no branch and no flag; the first tile and the last three run the general form
+        auto pp_tile = [&](int j, auto STEADY) {
+            constexpr bool steady = decltype(STEADY)::value;
+            // phase 2j (k sub-step 0): fires B(j+2) -> slot (j+2) % 4; its MFMA cluster prepares phase 2j+1: same slot, sub-step 1,
+            // and A(j+3)
+            pp_phase(0, [&]() {
+                if (steady || (j >= 1 && j + 2 < ntile)) fire_b(slot ^ 2);
+            }, [&]() {
+                ra = fz_lds_addr_of(smem + slot * C::STAGE + oa1);
+                rb = fz_lds_addr_of(smem + slot * C::STAGE + ob1);
+                FZ_PIN_V(ra);
+                FZ_PIN_V(rb);
+                if (steady || j + 3 < ntile) {
+                    prep_a();
+                    pin_a();
+                }
             });
-            // phase 2j+1: k sub-step 1; first the counted wait: tile j+1 (first read in the next phase) has landed, tile j+2 may stay
-            // in flight; then A(j+3) -> slot (j+3) % 4
-            pp_phase(std::integral_constant<int, 1>(), As, Bs, j + 1 < ntile ? (j + 2 < ntile ? 1 : 2) : 0, [&]() {
-                if (j + 3 < ntile) issue_a((slot + 3) & 3);
+            // phase 2j+1 (k sub-step 1): first the counted wait -- tile j+1 (first read in the next phase) has landed, tile j+2 may
+            // stay in flight; fires A(j+3) -> slot (j+3) % 4; its cluster prepares phase 2j+2: next slot, sub-step 0, and B(j+3)
+            pp_phase(steady ? 1 : (j + 1 < ntile ? (j + 2 < ntile ? 1 : 2) : 0), [&]() {
+                if (steady || j + 3 < ntile) fire_a((slot + 3) & 3);
+            }, [&]() {
+                const int ns = (slot + 1) & 3;
+                ra = fz_lds_addr_of(smem + ns * C::STAGE + oa0);
+                rb = fz_lds_addr_of(smem + ns * C::STAGE + ob0);
+                FZ_PIN_V(ra);
+                FZ_PIN_V(rb);
+                if (steady || j + 3 < ntile) {
+                    prep_b();
+                    pin_b();
+                }
             });
             slot = (slot + 1) & 3;
-        }
-        }
+        };
+        pp_tile(0, std::false_type());
+        int j = 1;
+        for (; j + 3 < ntile; ++j) pp_tile(j, std::true_type());
+        for (; j < ntile; ++j) pp_tile(j, std::false_type());
         if (!(PP & FZ_PP_NOSTAGGER) && !late) fz_barrier_raw();  // every wave passes the same number of barriers
     } else {
 #pragma unroll
