@@ -90,6 +90,16 @@ FZ_DEVICE void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with a wave-uniform 64-bit base (kept in scalar registers) plus a per-lane 32-bit byte offset: the SGPR-base addressing
+// form of the instruction -- advancing the base is scalar work, no VALU per issue
+FZ_DEVICE void fz_glds16_so(const char* sbase_uniform, uint32_t lane_byte_off, void* lds_wave_base) {
+    // (hipcc selects only the VGPR-address form for the builtin -- a 64-bit VALU add per issue -- so the instruction is written
+    // out: M0 = LDS base of the wave's 1 KB, then `global_load_lds_dwordx4 voffset, s[base:base+1]`.  M0 is a set-before-use
+    // register for the compiler as well (it rewrites it in front of every LDS-DMA builtin), so clobbering it here is safe.)
+    const uint32_t lds = (uint32_t)(uintptr_t)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_byte_off), "s"(sbase_uniform)
+                 : "memory", "m0");
+}
 FZ_DEVICE void fz_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // counted wait: at most N of this wave's vector-memory operations (LDS-DMA included) still outstanding; they retire in order
 template <int N>
@@ -210,6 +220,9 @@ static inline float fz_rsqrt(float x) { return 1.0f / sqrtf(x); }
 // buffer passed the barrier corrupts their tile).  Tests run the GEMM / conv cases both ways.
 static inline void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
     fz_emu::dma_issue(gsrc_lane, (unsigned char*)lds_wave_base + 16 * fz_emu::lane_id());
+}
+static inline void fz_glds16_so(const char* sbase_uniform, uint32_t lane_byte_off, void* lds_wave_base) {
+    fz_glds16(sbase_uniform + lane_byte_off, lds_wave_base);
 }
 static inline void fz_wait_vm0() { fz_emu::dma_wait(0); }
 template <int N>

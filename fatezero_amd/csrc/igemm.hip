@@ -29,12 +29,17 @@
 // instantiated with -DFZ_IGEMM_TRIALS, scripts/igemm_ab.py): bit 1 = no s_setprio around the MFMA clusters, bit 2 = the two wave
 // groups NOT staggered, bit 3 = the address VALU of the next phase runs at the START of that phase (in the read half, the round-3
 // v1 form) instead of inside the MFMA cluster before it
+#ifdef FZ_IGEMM_TRIALS
+__attribute__((weak)) int fz_igemm_trial_no_pp = 0;
+#endif
 #define FZ_PP_ON 1
 #define FZ_PP_NOPRIO 2
 #define FZ_PP_NOSTAGGER 4
 #define FZ_PP_PREP_IN_R 8
+#define FZ_PP_K32 16  /* a phase is a whole K tile of 32: one barrier pair per tile, the sub-step-1 fragments re-read inside the cluster */
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
 __device__ long long fz_igemm_timing[2][8];
+__device__ long long fz_igemm_timing2[2][2];
 #define FZ_TK_DECL() long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define FZ_TK(i)                              \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -83,9 +88,9 @@ struct IgArgs {
 template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, int PP = 0>
 struct IgCfg {
     static_assert(BK == 32 || BK == 64, "K step of 32 or 64 halves");
-    // PP: the phase-interleaved ("ping-pong") K loop -- two wave groups (wa = 0 / 1: one wave of each per SIMD) staggered by one
+    // PP: the phase-interleaved ("ping-pong") K loop -- two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) staggered by one
     // barrier, so that one group's MFMA cluster runs while the other group issues fragment reads and LDS-DMA
-    static_assert(!PP || (BK == 32 && NS == 4 && WA == 2 && WA * WB == 8), "ping-pong loop: K step 32, 4 slots, 2 x 4 waves");
+    static_assert(!PP || (BK == 32 && NS == 4 && WA * WB == 8), "ping-pong loop: K step 32, 4 slots, 8 waves = two groups of 4");
     static constexpr int NW = WA * WB, T = 64 * NW;
     static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
     static constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
@@ -125,6 +130,9 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     half_t* smem = reinterpret_cast<half_t*>(raw);
     const int tid = threadIdx.x, wave = fz_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wa = wave / WB, wb = wave % WB;
+#ifdef FZ_IGEMM_TIMING
+    const long long tk_entry = clock64();
+#endif
     // ---- tile of this workgroup: XCD-aware (blocks b, b+8, b+16.. share an XCD and get consecutive tiles, which share
     //      their B rows: the activation panel is fetched once per XCD L2), a-tile fastest
     const int nt = gridDim.x, bid = blockIdx.x;
@@ -148,6 +156,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     const char* aptr[C::ACH];
     int asc[C::ACH];
     bool apad[C::ACH];
+    uint32_t aoff[C::ACH], boff[C::BCH];
 #pragma unroll
     for (int i = 0; i < C::ACH; ++i) {
         const int row = (i * C::NW + wave) * C::RPI + lane / C::CPR;
@@ -156,6 +165,10 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         ar = ar < g.Ma ? ar : g.Ma - 1;
         aptr[i] = reinterpret_cast<const char*>(A + (int64_t)ar * g.lda) + asc[i] * 16;
         apad[i] = row >= C::BA;  // an instruction that only pads the wave's count: fetch the (cache-resident) zero page
+        // ping-pong loop: wave-uniform 64-bit base (the tile's first row + the K offset, scalar registers) + this per-lane 32-bit
+        // byte offset -- the SGPR-base form of the LDS-DMA instruction, no address VALU per K tile.  Padding instructions (uniform
+        // per wave: BA is a multiple of the rows per instruction) read the zero page at lane * 16.
+        aoff[i] = apad[i] ? (uint32_t)lane * 16u : (uint32_t)(((int64_t)(ar - a0) * g.lda + asc[i] * 8) * 2);
     }
     // MODE: 0 = plain rows; 1 = 3x3 conv, K order (tap, Cin chunk); 3 = 3x3 conv, K order (Cin chunk, tap); 2 = temporal
     // 3-tap conv, K order (tap, Cin chunk) (chunk-outer measured 2-7 % slower there).  Chunk-outer order keeps the input window of a K chunk (a 128-byte slice of every
@@ -179,8 +192,10 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         bok[i] = br < g.Nb;
         br = bok[i] ? br : g.Nb - 1;
         bflag[i] = 0;
+        boff[i] = 0;
         if (MODE == 0) {
             bptr[i] = reinterpret_cast<const char*>(B + br * g.ldb) + bsc[i] * 16;
+            boff[i] = (uint32_t)(((br - b0) * g.ldb + bsc[i] * 8) * 2);
             bn[i] = boy[i] = box[i] = 0;
         } else {
             const int hw = g.Ho * g.Wo;
@@ -245,8 +260,18 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     // (A first: the cursor moves with B's prep).
     const char* asrc[C::ACH];
     const char* bsrc[C::BCH];
+    // ping-pong loop (Cin % BK == 0, checked by the launcher): scalar bases of the tile the cursor points at
+    const char* const a_tile = reinterpret_cast<const char*>(A + (int64_t)a0 * g.lda);
+    const char* const b_tile = reinterpret_cast<const char*>(B + b0 * g.ldb);
+    const char* a_k = a_tile;
+    const char* b_k = b_tile;
+    constexpr bool B_SADDR = PP && MODE == 0;  // plain B rows: scalar base + per-lane offset as well
     auto prep_a = [&]() {
         const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offset along K
+        if constexpr (PP != 0) {
+            a_k = a_tile + ka;
+            return;
+        }
         if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
             FZ_COLD_PATH();
 #pragma unroll
@@ -265,17 +290,41 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     auto fire_a = [&](int buf) {
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
 #pragma unroll
-        for (int i = 0; i < C::ACH; ++i) fz_glds16(asrc[i], Ab + (i * C::NW + wave) * 1024);
+        for (int i = 0; i < C::ACH; ++i) {
+            if constexpr (PP != 0) {
+                const bool pad = (i + 1) * C::NW * C::RPI > C::BA && (i * C::NW + wave) * C::RPI >= C::BA;  // wave-uniform
+                fz_glds16_so(pad ? zero : a_k, aoff[i], Ab + (i * C::NW + wave) * 1024);
+            } else {
+                fz_glds16(asrc[i], Ab + (i * C::NW + wave) * 1024);
+            }
+        }
+    };
+    auto advance = [&]() {  // cursor -> next K tile
+        if (KORD) {
+            if (++itap == g.taps) {
+                itap = 0;
+                ++ikc;
+            }
+        } else if (++ikc == g.kchunks) {
+            ikc = 0;
+            ++itap;
+            if ((MODE == 1 || MODE == 2) && itap < g.taps) retarget(itap);
+        }
     };
     auto prep_b = [&]() {
         int64_t kb = ikc * BK * 2;
+        if constexpr (B_SADDR) {
+            b_k = b_tile + kb;
+            advance();
+            return;
+        }
         int need = 0;  // KORD: validity bits this tap requires
         if (KORD) {
             const int ky = itap / 3, kx = itap - 3 * ky;
             kb += ((int64_t)(ky - 1) * g.Wi + (kx - 1)) * g.ldb * 2;
             need = (1 << ky) | (8 << kx);
         }
-        if (ikc == g.kchunks - 1 && ktail < BK) {
+        if (!PP && ikc == g.kchunks - 1 && ktail < BK) {
             FZ_COLD_PATH();
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
@@ -292,21 +341,18 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
                 }
             }
         }
-        if (KORD) {
-            if (++itap == g.taps) {
-                itap = 0;
-                ++ikc;
-            }
-        } else if (++ikc == g.kchunks) {
-            ikc = 0;
-            ++itap;
-            if ((MODE == 1 || MODE == 2) && itap < g.taps) retarget(itap);
-        }
+        advance();
     };
     auto fire_b = [&](int buf) {
         char* Bb = reinterpret_cast<char*>(smem + buf * C::STAGE) + C::A_HALVES * 2;
 #pragma unroll
-        for (int i = 0; i < C::BCH; ++i) fz_glds16(bsrc[i], Bb + (i * C::NW + wave) * 1024);
+        for (int i = 0; i < C::BCH; ++i) {
+            if constexpr (B_SADDR) {
+                fz_glds16_so(b_k, boff[i], Bb + (i * C::NW + wave) * 1024);
+            } else {
+                fz_glds16(bsrc[i], Bb + (i * C::NW + wave) * 1024);
+            }
+        }
     };
     auto issue = [&](int buf) {
         prep_a();
@@ -314,13 +360,12 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         prep_b();
         fire_b(buf);
     };
-    auto pin_a = [&]() {  // the prepared addresses exist as registers from here on (not re-derived next to the DMA instruction)
+    auto pin_a = [&]() {};  // (A: scalar base in the ping-pong loop, nothing per lane)
+    auto pin_b = [&]() {  // the prepared addresses exist as registers from here on (not re-derived next to the DMA instruction)
+        if constexpr (!B_SADDR) {
 #pragma unroll
-        for (int i = 0; i < C::ACH; ++i) FZ_PIN_V(asrc[i]);
-    };
-    auto pin_b = [&]() {
-#pragma unroll
-        for (int i = 0; i < C::BCH; ++i) FZ_PIN_V(bsrc[i]);
+            for (int i = 0; i < C::BCH; ++i) FZ_PIN_V(bsrc[i]);
+        }
     };
 
     f32x16 acc[TA][TB];
@@ -340,6 +385,9 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     //   kt+NS-1 -> MFMAs on tile kt.  The barrier does not drain vmcnt, so the loads span barriers (T3+T4 of the guide).
     const int ntile = kt1 - kt0;
     FZ_TK_DECL();
+#ifdef FZ_IGEMM_TIMING
+    const long long tk_loop = clock64();
+#endif
     if constexpr (PP) {
         // ---- phase-interleaved loop (cdna_hip_programming.md "The 256^2 8-phase template", T3+T4+T5) --------------------------------
         // K tiles of 32 in a 4-slot ring; a PHASE is one k sub-step of 16:   R: { ds_read the phase's fragments, issue a slice of
@@ -355,7 +403,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
         //        4j for both groups); it is restaged from phase 2j+1 on: two phases later (R(2j+1) starts after barrier 4j+1).
         // Up to 2 tiles (72-80 KB) stay in flight across 3-4 phases; vmcnt is never drained in the steady state.
         static_assert(2 * C::PER < 64, "vmcnt field");
-        const bool late = wa == 1;
+        const bool late = wave >= 4;  // waves 4-7: the second wave of every SIMD
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             if (s < ntile) issue(s);
@@ -462,10 +510,79 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             });
             slot = (slot + 1) & 3;
         };
+        if constexpr ((PP & FZ_PP_K32) != 0) {
+            // ---- K-32 phases: ONE barrier pair per K tile (half the synchronisations per MFMA).  R: the fragments of k sub-step 0 +
+            // FIRE of tile j+2 + the counted wait for tile j+1;  M: the MFMAs of sub-step 0, each A fragment register reloaded for
+            // sub-step 1 right behind its last use (LDS instructions inside the cluster: the LDS port is not the VALU port), then
+            // the MFMAs of sub-step 1.  Tile j is read in phase j (R and M); its slot is refilled from phase j+2 on (both groups have
+            // passed the barrier behind M(j) by then) with tile j+4... i.e. phase p fires tile p+2 into slot (p+2) % 4, which is
+            // waited for in phase p+1 and read in phase p+2.  Prologue (above) issued tiles 0, 1, 2: phase 0 fires nothing.
+            auto pp_phase32 = [&](int j, auto STEADY) {
+                constexpr bool steady = decltype(STEADY)::value;
+                half8_t af[TA], bf[TB], bg[TB];
+                // address VALU / scalar cursor work of this phase, at its very start
+                const fz_lds_addr base = fz_lds_addr_of(smem + slot * C::STAGE);
+                fz_lds_addr ra0 = base + 2 * oa0, rb0 = base + 2 * ob0, ra1 = base + 2 * oa1, rb1 = base + 2 * ob1;
+                FZ_PIN_V(ra0);
+                FZ_PIN_V(rb0);
+                FZ_PIN_V(ra1);
+                FZ_PIN_V(rb1);
+                const bool fires = steady || (j >= 1 && j + 2 < ntile);
+                if (fires) {
+                    prep_a();
+                    prep_b();
+                    pin_b();
+                }
+#pragma unroll
+                for (int q = 0; q < TB; ++q) bf[q] = fz_lds_ld_h8(rb0, q * 32 * BK * 2);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) af[i] = fz_lds_ld_h8(ra0, i * 32 * BK * 2);
+                if (fires) {
+                    fire_a(slot ^ 2);
+                    fire_b(slot ^ 2);
+                }
+                if (steady) {
+                    fz_wait_vm<C::PER>();
+                } else if (j + 1 < ntile) {  // tile j+1 (read in the next phase) has landed; tile j+2 stays in flight
+                    if (j + 2 < ntile) {
+                        fz_wait_vm<C::PER>();
+                    } else {
+                        fz_wait_vm0();
+                    }
+                }
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();
+                FZ_SCHED_FENCE();
+                if (!(PP & FZ_PP_NOPRIO)) fz_setprio_hi();
+#pragma unroll
+                for (int q = 0; q < TB; ++q) bg[q] = fz_lds_ld_h8(rb1, q * 32 * BK * 2);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) {
+#pragma unroll
+                    for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+                    af[i] = fz_lds_ld_h8(ra1, i * 32 * BK * 2);
+                    FZ_SCHED_FENCE();
+                }
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bg[q], acc[i][q]);
+                if (!(PP & FZ_PP_NOPRIO)) fz_setprio_lo();
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();
+                FZ_SCHED_FENCE();
+                slot = (slot + 1) & 3;
+            };
+            pp_phase32(0, std::false_type());
+            int j = 1;
+            for (; j + 2 < ntile; ++j) pp_phase32(j, std::true_type());
+            for (; j < ntile; ++j) pp_phase32(j, std::false_type());
+        } else {
         pp_tile(0, std::false_type());
         int j = 1;
         for (; j + 3 < ntile; ++j) pp_tile(j, std::true_type());
         for (; j < ntile; ++j) pp_tile(j, std::false_type());
+        }
         if (!(PP & FZ_PP_NOSTAGGER) && !late) fz_barrier_raw();  // every wave passes the same number of barriers
     } else {
 #pragma unroll
@@ -513,6 +630,11 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
     }
     }
 
+#ifdef FZ_IGEMM_TIMING
+    tacc_[7] = clock64() - tk_loop;   // the K loop as a whole (prologue fetch included)
+    tacc_[3] += 0;
+    const long long tk_setup = tk_loop - tk_entry;  // pointer set-up before the loop
+#endif
     FZ_TK_FLUSH();
 
     // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
@@ -755,6 +877,12 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             }
         }
     }
+#ifdef FZ_IGEMM_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (tid & 255) == 0) {
+        fz_igemm_timing2[tid >> 8][0] = tk_setup;
+        fz_igemm_timing2[tid >> 8][1] = clock64() - tk_entry;   // whole kernel, entry to the last store issued
+    }
+#endif
 }
 
 // split-K tail: y[b][a] = sum_s part[s][b][a] + bias[a] (+ temb) (+ res) (+ res2); one thread per 4 outputs
@@ -851,6 +979,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
     if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
+    if (PP && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
     g.tiles_a = fz_ceil_div(g.Ma, C::BA);
     const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
     const int64_t nt = (int64_t)g.tiles_a * tiles_b;
@@ -892,18 +1021,29 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 template <int MODE, bool GEGLU, bool LN = false>
 static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
     if constexpr (!LN) {  // ping-pong K loop (last digit 8): K step 32, 4-slot ring, two wave groups half a phase apart
-        if (cfg == 244218) return ig_launch<2, 4, 4, 2, 32, 4, MODE, GEGLU, false, 1>(g, batch, stream);
-        if (!GEGLU && cfg == 254218) return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1>(g, batch, stream);
-#ifdef FZ_IGEMM_TRIALS  // trial forms: tile id + 1000000 * (PP bits >> 1)
-        if (!GEGLU && MODE != 2) {
+        constexpr int P = FZ_PP_ON | FZ_PP_PREP_IN_R;  // the form that measured best (profiles/r03_igemm_ab_v3.txt)
+        if (cfg == 244218) return ig_launch<2, 4, 4, 2, 32, 4, MODE, GEGLU, false, P>(g, batch, stream);
+        if (!GEGLU) {
             switch (cfg) {
-                case 1254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 2>(g, batch, stream);
-                case 2254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 4>(g, batch, stream);
-                case 3254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 2 | 4>(g, batch, stream);
-                case 4254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 8>(g, batch, stream);
-                case 5254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 2 | 8>(g, batch, stream);
-                case 1244218: return ig_launch<2, 4, 4, 2, 32, 4, MODE, false, false, 1 | 2>(g, batch, stream);
-                case 5244218: return ig_launch<2, 4, 4, 2, 32, 4, MODE, false, false, 1 | 2 | 8>(g, batch, stream);
+                case 254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, P>(g, batch, stream);
+                default: break;
+            }
+        }
+#ifdef FZ_IGEMM_TRIALS  // trial forms: tile id + 1000000 * n
+        if (!GEGLU && MODE != 2) {
+            constexpr int P = FZ_PP_ON | FZ_PP_PREP_IN_R;
+            switch (cfg) {
+                case 254118: return ig_launch<2, 5, 4, 1, 32, 4, MODE, false, false, P>(g, batch, stream);   // one B-side tile per wave:
+                case 158118: return ig_launch<1, 5, 8, 1, 32, 4, MODE, false, false, P>(g, batch, stream);   // slower than their ring twins
+                case 1254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1>(g, batch, stream);          // prep inside the MFMA cluster
+                case 2254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 8 | 2>(g, batch, stream);  // no s_setprio
+                case 3254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 8 | 4>(g, batch, stream);  // groups not staggered
+                case 1254118: return ig_launch<2, 5, 4, 1, 32, 4, MODE, false, false, 1>(g, batch, stream);
+                case 1244218: return ig_launch<2, 4, 4, 2, 32, 4, MODE, false, false, 1>(g, batch, stream);
+                case 4254218: return ig_launch<2, 5, 4, 2, 32, 4, MODE, false, false, 1 | 16>(g, batch, stream);     // K-32 phases
+                case 4244218: return ig_launch<2, 4, 4, 2, 32, 4, MODE, false, false, 1 | 16>(g, batch, stream);
+                case 4254118: return ig_launch<2, 5, 4, 1, 32, 4, MODE, false, false, 1 | 16>(g, batch, stream);
+                case 4158118: return ig_launch<1, 5, 8, 1, 32, 4, MODE, false, false, 1 | 16>(g, batch, stream);
                 default: break;
             }
         }
@@ -989,6 +1129,19 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         ig_choose(g, batch, GEGLU, workspace ? workspace_floats : 0, &c, &sk);
         cfg = c;
         if (ksplit == 0) ksplit = sk;
+        // The two 8-wave tiles whose waves own 2 B-side MFMA tiles run the ping-pong K loop where it measured faster than the ring loop
+        // of the same tile on MI355X (profiles/r03_igemm_prod_ring_vs_pp_v3.txt, r03_igemm_ab_v*.txt): no split-K (the loop's three-tile
+        // prologue is not amortised over a short K slice: 8^2 convs lost 35 %), K >= 640 (shorter loops are epilogue / HBM-bound either
+        // way), no ragged K, not the LayerNorm-fused form.  +2 ... +7 % on the 16-frame 64^2 convs, +4 ... +16 % on the GEGLU and long-K
+        // projections.  The 320 x 128 / 160 x 256 tiles (one B-side MFMA tile per wave: five MFMAs per phase against six fragment
+        // reads) measured 3-7 % SLOWER in ping-pong form and stay on the ring loop.
+#ifdef FZ_IGEMM_TRIALS
+        if (!fz_igemm_trial_no_pp)  // scripts/igemm_timeline.hip: A/B of the library's own choice with / without the substitution
+#endif
+        if (g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr && ksplit == 1 && (int64_t)g.taps * g.Cin >= 640) {
+            if (cfg == 254222) cfg = 254218;
+            if (cfg == 244222) cfg = 244218;
+        }
     }
     if (ksplit == 0) ksplit = 1;
     if (g.ln_in != nullptr) ksplit = 1;  // the LayerNorm correction lives in the GEMM's own epilogue

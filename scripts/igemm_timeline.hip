@@ -27,8 +27,9 @@ static _Float16* dev_random(size_t n, float scale) {
 }
 
 struct Problem {
-    const char* name;
+    char name[64];
     bool conv;
+    bool geglu, temporal;
     int n, hw, cin, cout;     // conv
     int64_t rows; int k, o;   // gemm
     double flops;
@@ -36,22 +37,33 @@ struct Problem {
 };
 
 static int launch(const Problem& p, int cfg, void* ws, int64_t ws_floats) {
+    if (cfg < 0) {  // the library's own choice: -1 = ring tiles only, -2 = with the ping-pong substitution
+        fz_igemm_trial_no_pp = cfg == -1;
+        cfg = 0;
+    }
+    if (p.temporal)
+        return fz_temporal_conv3(p.x, p.w, nullptr, nullptr, nullptr, 0, p.y, p.n, p.hw, p.cin, p.cout, 8, ws, ws_floats, nullptr);
     if (p.conv)
         return fz_conv3x3(p.x, p.w, p.b, nullptr, 0, nullptr, p.y, p.n, p.hw, p.hw, p.cin, p.cout, 1, 0, p.n, ws, ws_floats, cfg, cfg ? 1 : 0, nullptr);
     FzGemmDesc d = {};
     d.rows = p.rows; d.in_features = p.k; d.out_features = p.o; d.ldx = p.k; d.ldw = p.k; d.ldy = p.o; d.batch = 1;
     d.tile_cfg = cfg; d.split_k = cfg ? 1 : 0; d.workspace_floats = ws_floats;
-    return fz_gemm(&d, p.x, p.w, p.b, nullptr, nullptr, p.y, ws, nullptr);
+    if (p.geglu) {
+        d.epilogue = FZ_GEMM_GEGLU;
+        d.ldy = p.o / 2;
+    }
+    return fz_gemm(&d, p.x, p.w, p.b, nullptr, nullptr, p.y, p.geglu ? nullptr : ws, nullptr);
 }
 
 int main(int argc, char** argv) {
     std::vector<int> cfgs;
-    for (int i = 1; i < argc; ++i) cfgs.push_back(atoi(argv[i]));
+    for (int i = 1; i < argc; ++i)
+        if (strcmp(argv[i], "prod")) cfgs.push_back(atoi(argv[i]));
     if (cfgs.empty()) cfgs = {254222, 254218, 1254218, 3254218, 5254218, 244222, 244218, 1244218};
     std::vector<Problem> probs;
     auto add_conv = [&](const char* name, int n, int hw, int cin, int cout) {
         Problem p = {};
-        p.name = name; p.conv = true; p.n = n; p.hw = hw; p.cin = cin; p.cout = cout;
+        strncpy(p.name, name, 63); p.conv = true; p.n = n; p.hw = hw; p.cin = cin; p.cout = cout;
         p.flops = 2.0 * n * hw * hw * (double)cout * cin * 9;
         p.x = dev_random((size_t)n * hw * hw * cin, 1.0f);
         p.w = dev_random((size_t)cout * 9 * cin, 0.02f);
@@ -61,7 +73,7 @@ int main(int argc, char** argv) {
     };
     auto add_gemm = [&](const char* name, int64_t rows, int k, int o) {
         Problem p = {};
-        p.name = name; p.conv = false; p.rows = rows; p.k = k; p.o = o;
+        strncpy(p.name, name, 63); p.conv = false; p.rows = rows; p.k = k; p.o = o;
         p.flops = 2.0 * rows * (double)k * o;
         p.x = dev_random((size_t)rows * k, 1.0f);
         p.w = dev_random((size_t)o * k, 0.03f);
@@ -69,12 +81,46 @@ int main(int argc, char** argv) {
         hipMalloc(&p.y, (size_t)rows * o * 2);
         probs.push_back(p);
     };
+    const bool prod = argc > 1 && !strcmp(argv[1], "prod");
+    if (prod) {  // every conv / GEMM / temporal-conv shape of the 8-frame inversion and the 16-frame edit forward (SD-1.x at 512^2)
+        cfgs = {-1, -2};
+        char nm[64];
+        for (int n : {8, 16}) {
+            const int cs[][3] = {{64, 320, 320}, {64, 640, 320}, {64, 960, 320}, {32, 320, 640}, {32, 640, 640}, {32, 960, 640}, {32, 1280, 640},
+                                 {32, 1920, 640}, {16, 640, 1280}, {16, 1280, 1280}, {16, 1920, 1280}, {16, 2560, 1280}, {8, 1280, 1280}, {8, 2560, 1280}};
+            for (auto& c : cs) {
+                snprintf(nm, 64, "conv %2df %2d^2 %4d->%4d      ", n, c[0], c[1], c[2]);
+                add_conv(nm, n, c[0], c[1], c[2]);
+            }
+            const int gs[][4] = {{4096, 320, 320, 0}, {4096, 320, 640, 0}, {4096, 320, 2560, 1}, {4096, 1280, 320, 0}, {1024, 640, 640, 0}, {1024, 640, 1280, 0},
+                                 {1024, 640, 5120, 1}, {1024, 2560, 640, 0}, {256, 1280, 1280, 0}, {256, 1280, 2560, 0}, {256, 1280, 10240, 1}, {256, 5120, 1280, 0},
+                                 {64, 1280, 1280, 0}, {64, 1280, 10240, 1}, {64, 5120, 1280, 0}};
+            for (auto& c : gs) {
+                snprintf(nm, 64, "gemm%s %6d x %4d -> %5d", c[3] ? " geglu" : "      ", n * c[0], c[1], c[2]);
+                add_gemm(nm, (int64_t)n * c[0], c[1], c[2]);
+                probs.back().geglu = c[3] != 0;
+            }
+            const int ts[][3] = {{4096, 320, 160}, {4096, 160, 320}, {1024, 640, 160}, {1024, 160, 640}, {256, 1280, 160}, {256, 160, 1280}, {64, 1280, 160}, {64, 160, 1280}};
+            for (auto& c : ts) {
+                snprintf(nm, 64, "tconv %2df %4d tok %4d->%4d  ", n, c[0], c[1], c[2]);
+                Problem p = {};
+                strncpy(p.name, nm, 63); p.temporal = true; p.n = n; p.hw = c[0]; p.cin = c[1]; p.cout = c[2];
+                p.flops = 2.0 * n * c[0] * (double)c[1] * c[2] * 3;
+                p.x = dev_random((size_t)n * c[0] * c[1], 1.0f);
+                p.w = dev_random((size_t)c[2] * 3 * c[1], 0.03f);
+                p.b = nullptr;
+                hipMalloc(&p.y, (size_t)n * c[0] * c[2] * 2);
+                probs.push_back(p);
+            }
+        }
+    } else {
     add_conv("conv 16f 64^2 320->320 ", 16, 64, 320, 320);
     add_conv("conv  8f 64^2 320->320 ", 8, 64, 320, 320);
     add_conv("conv 16f 32^2 640->640 ", 16, 32, 640, 640);
     add_gemm("gemm 65536 x 1280 -> 1280", 65536, 1280, 1280);
     add_gemm("gemm  8192 x 2560 ->  640", 8192, 2560, 640);
     add_gemm("gemm  4096 x 1280 -> 3840", 4096, 1280, 3840);
+    }
     const int64_t ws_floats = 64ll << 20;
     float* ws;
     hipMalloc(&ws, ws_floats * 4);
@@ -96,8 +142,11 @@ int main(int argc, char** argv) {
             hipDeviceSynchronize();
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
-            long long t[2][8];
+            long long t[2][8], t2[2][2];
             hipMemcpyFromSymbol(t, HIP_SYMBOL(fz_igemm_timing), sizeof(t));
+            hipMemcpyFromSymbol(t2, HIP_SYMBOL(fz_igemm_timing2), sizeof(t2));
+            printf("%s cfg %8d: wave 0 of workgroup 0: set-up %lld ticks, K loop %lld ticks, whole kernel %lld ticks; launch %.1f us\n", p.name, cfg,
+                   t2[0][0], t[0][7], t2[0][1], ms * 1e3);
             for (int w = 0; w < 2; ++w) {
                 const double n = t[w][6] > 0 ? (double)t[w][6] : 1.0;
                 double sum = 0;
@@ -109,7 +158,8 @@ int main(int argc, char** argv) {
         }
     }
 #else
-    const int ROUNDS = 15;
+    const int ROUNDS = prod ? 7 : 15;
+    std::vector<double> total_ms(cfgs.size(), 0.0);
     for (const Problem& p : probs) {
         std::vector<std::vector<float>> ms(cfgs.size());
         std::vector<bool> ok(cfgs.size());
@@ -130,10 +180,14 @@ int main(int argc, char** argv) {
         for (size_t v = 0; v < cfgs.size(); ++v) {
             if (!ok[v]) { printf(" | %8d     -      ", cfgs[v]); continue; }
             std::sort(ms[v].begin(), ms[v].end());
+            total_ms[v] += ms[v][ms[v].size() / 2];
             printf(" | %8d %5.0f/%5.0f", cfgs[v], p.flops / ms[v][ms[v].size() / 2] / 1e9, p.flops / ms[v][0] / 1e9);
         }
         printf("   (median/best TF/s)\n");
     }
+    printf("sum of the median launch times over the listed problems:");
+    for (size_t v = 0; v < cfgs.size(); ++v) printf(" | %8d %8.3f ms", cfgs[v], total_ms[v]);
+    printf("\n");
 #endif
     return 0;
 }

@@ -138,7 +138,8 @@ def test_conv3x3_small_cin_and_cout():
 @pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 3), (254222, 2), (254122, 4), (158122, 1),
                                               (254218, 1), (244218, 1), (254218, 4), (244218, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
-    KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
+    # (the ping-pong tiles ..18 have no ragged-K path: Cin a multiple of 32 there)
+    KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=96 if tile_cfg % 100 == 18 else 72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
 
 
@@ -147,11 +148,27 @@ def test_gemm_tile_shapes(tile_cfg):
     KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
 
 
-@pytest.mark.parametrize("k", [32, 40, 64, 128, 136, 160])
+@pytest.mark.parametrize("k", [32, 64, 96, 128, 160, 224, 256, 320])
 def test_gemm_pingpong_tile_counts(k):
-    # 1 .. 5 K tiles of the ping-pong loop (prologue / tail forms of its ring), ragged last tile; both tile widths
+    # 1 .. 10 K tiles of the ping-pong loop (prologue / steady-state / tail forms of its ring); both tile widths
     KC.case_gemm(DEV, rows=70, k=k, o=72, tile_cfg=254218)
     KC.case_gemm(DEV, rows=300, k=k, o=264, n_res=1, tile_cfg=244218)
+
+
+@pytest.mark.parametrize("dma", ["late", "early"])
+def test_igemm_trial_forms(dma, monkeypatch):
+    """Trial forms of the ping-pong loop (-DFZ_IGEMM_TRIALS builds only: FZ_EMU_LIB=build_tmp/libemu_trials.so from scripts/emu_variant.sh),
+    validated on the emulator under both DMA-landing models before they cost GPU time."""
+    import os
+    if not os.environ.get("FZ_EMU_LIB"):
+        pytest.skip("needs an emulator build of the trial variants (FZ_EMU_LIB)")
+    if dma == "early":
+        monkeypatch.setenv("FZ_EMU_DMA", "early")
+    for cfg in (4254218, 4244218, 4254118, 4158118, 1254218, 254118, 158118, 2254218, 3254218):
+        KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=96, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=cfg, split_k=1)
+        KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=96, cout=48, fpb=2, tile_cfg=cfg, split_k=3)
+        for k in (32, 64, 96, 128, 160, 224, 320):
+            KC.case_gemm(DEV, rows=300, k=k, o=330, n_res=1, tile_cfg=cfg)
 
 
 def test_gemm_forms():
@@ -165,7 +182,7 @@ def test_gemm_forms():
 @pytest.mark.parametrize("tile_cfg", [0, 244222, 224223, 222222, 244218])
 def test_gemm_geglu(tile_cfg):
     KC.case_gemm(DEV, rows=70, k=64, o=256, geglu=True, tile_cfg=tile_cfg)
-    KC.case_gemm(DEV, rows=33, k=40, o=128, geglu=True, bias=False, tile_cfg=tile_cfg)
+    KC.case_gemm(DEV, rows=33, k=64 if tile_cfg % 100 == 18 else 40, o=128, geglu=True, bias=False, tile_cfg=tile_cfg)
 
 
 def test_gemm_transposed_output():
@@ -204,10 +221,11 @@ def test_igemm_with_early_landing_dma(monkeypatch):
     monkeypatch.setenv("FZ_EMU_DMA", "early")
     for tile_cfg, split_k in [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 3), (212222, 1), (158122, 1), (254222, 2),
                               (254218, 1), (244218, 1), (254218, 4), (244218, 2)]:
-        KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg, split_k=split_k)
+        KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=96 if tile_cfg % 100 == 18 else 72, cout=48, with_temb=True, with_res=True, fpb=2,
+                        tile_cfg=tile_cfg, split_k=split_k)
     for tile_cfg in (0, 254222, 244222, 224223, 212222, 254218, 244218):
         KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
-    for k in (32, 40, 64, 128, 136, 160):  # 1 .. 5 K tiles of the ping-pong loop (prologue / tail forms), ragged last tile
+    for k in (32, 64, 96, 128, 160, 256):  # 1 .. 8 K tiles of the ping-pong loop (prologue / steady / tail forms)
         KC.case_gemm(DEV, rows=70, k=k, o=72, tile_cfg=254218)
     KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)
