@@ -11,7 +11,8 @@ Two ways to use N GPUs:
       (fz_groupnorm_stats / fz_groupnorm_apply);
     - sparse-causal K/V of neighbour / anchor frames -> point-to-point fetch of those frames' K and V^T from their owners
       into an extended K/V frame axis the attention kernels index directly (FzAttnSelfDesc.kv_clip_len);
-    - the k=3 temporal LoRA convolution           -> one-frame halo exchange with the neighbours (twice: x, then down(x));
+    - the k=3 temporal LoRA convolution           -> ONE two-frame halo exchange of x with the neighbours (down(x) of the halo
+      frames is recomputed locally instead of exchanged a second time);
     - temporal attention over all F frames per pixel -> all-gather of that layer's K and V.
   CFG, the DDIM update, blend masks (normalised per frame) and the latent blend are per-frame and need nothing.
 """
@@ -100,6 +101,7 @@ class FrameShard:
         self.f0, self.f1 = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.n_local = self.f1 - self.f0
         self.max_local = base + (1 if rem else 0)
+        self.stats = {"posted": 0, "overlapped": 0, "blocking": 0}
 
     # -- bookkeeping ---------------------------------------------------------------------------------------------
     def frames_of(self, rank: int) -> range:
@@ -120,11 +122,16 @@ class FrameShard:
         return x.narrow(dim, self.f0, self.n_local)
 
     # -- collectives ---------------------------------------------------------------------------------------------
-    def all_gather_frames(self, x_local: torch.Tensor) -> torch.Tensor:
-        """x_local [B, F_local, ...] -> [B, F, ...] on every rank (frames in clip order)."""
+    # Every exchange is POSTED (returns a `Pending`) and WAITED for separately: RCCL runs the transfer on its own stream, ordered
+    # behind the work already queued on the compute stream at post time, and `wait()` only makes the compute stream depend on
+    # its completion -- whatever the caller launches between post and wait overlaps with the transfer (the K / V^T fetches ride
+    # under the Q projection, attention.py).  `stats` counts, per shard object, how many waits had compute launched in between
+    # (`overlapped`) and how many came straight after the post (`blocking`): tests/test_dist_gloo.py asserts the structure.
+    def all_gather_frames_async(self, x_local: torch.Tensor, tag: str = "other") -> "Pending":
+        """x_local [B, F_local, ...] -> Pending of [B, F, ...] on every rank (frames in clip order)."""
         import torch.distributed as dist
         if self.world == 1:
-            return x_local
+            return Pending(self, [], lambda: x_local, tag=tag)
         b = x_local.shape[0]
         rest = tuple(x_local.shape[2:])
         if self.n_local == self.max_local:
@@ -133,15 +140,19 @@ class FrameShard:
             mine = x_local.new_zeros((b, self.max_local) + rest)
             mine[:, : self.n_local] = x_local
         bufs = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(bufs, mine, group=self.group)
-        return torch.cat([bufs[r][:, : len(self.frames_of(r))] for r in range(self.world)], dim=1)
+        work = dist.all_gather(bufs, mine, group=self.group, async_op=True)
+        return Pending(self, [work], lambda: torch.cat([bufs[r][:, : len(self.frames_of(r))] for r in range(self.world)], dim=1),
+                       keep=(mine,), tag=tag)
 
-    def fetch_frames(self, x_local: torch.Tensor, wanted: Callable[[int], Sequence[int]], *,
-                     zero_outside: bool = False) -> torch.Tensor:
+    def all_gather_frames(self, x_local: torch.Tensor, tag: str = "other") -> torch.Tensor:
+        return self.all_gather_frames_async(x_local, tag).wait()
+
+    def fetch_frames_async(self, x_local: torch.Tensor, wanted: Callable[[int], Sequence[int]], *,
+                           zero_outside: bool = False, tag: str = "other") -> "Pending":
         """Point-to-point gather of whole frames.  `wanted(rank)` lists the GLOBAL frame indices rank `rank` needs (the
         same pure function on every rank, so each one also knows what to send).  Indices outside [0, F) are clamped
         into the clip (sparse-causal attention, attention.py:383-386) or, with zero_outside, return zeros (the zero
-        padding of the temporal convolution).  x_local: [B, F_local, ...] -> [B, len(wanted(my rank)), ...]."""
+        padding of the temporal convolution).  x_local: [B, F_local, ...] -> Pending of [B, len(wanted(my rank)), ...]."""
         import torch.distributed as dist
 
         def resolve(g):
@@ -170,20 +181,51 @@ class FrameShard:
         for i, g in enumerate(mine):
             if g is not None and self.f0 <= g < self.f1:
                 out[:, i] = x_local[:, g - self.f0]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for slots, buf in recvs:
-            out[:, slots] = buf
-        return out
+        reqs = dist.batch_isend_irecv(ops) if ops else []
 
-    def with_halo(self, x_local: torch.Tensor, left: int, right: int, *, zero_outside: bool) -> torch.Tensor:
+        def finish():
+            for slots, buf in recvs:
+                out[:, slots] = buf
+            return out
+        return Pending(self, reqs, finish, keep=tuple(keep), tag=tag)
+
+    def fetch_frames(self, x_local: torch.Tensor, wanted: Callable[[int], Sequence[int]], *,
+                     zero_outside: bool = False, tag: str = "other") -> torch.Tensor:
+        return self.fetch_frames_async(x_local, wanted, zero_outside=zero_outside, tag=tag).wait()
+
+    def with_halo(self, x_local: torch.Tensor, left: int, right: int, *, zero_outside: bool, tag: str = "halo") -> torch.Tensor:
         """[B, F_local, ...] -> [B, left + F_local + right, ...]: the neighbours' boundary frames on both sides."""
         def wanted(r):
             fr = self.frames_of(r)
             return list(range(fr.start - left, fr.start)) + list(range(fr.stop, fr.stop + right))
-        halo = self.fetch_frames(x_local, wanted, zero_outside=zero_outside)
+        halo = self.fetch_frames(x_local, wanted, zero_outside=zero_outside, tag=tag)
         return torch.cat([halo[:, :left], x_local, halo[:, left:]], dim=1)
+
+
+class Pending:
+    """An exchange in flight: `wait()` completes it and returns the assembled tensor."""
+
+    def __init__(self, shard: FrameShard, reqs, finish, keep=(), tag="other"):
+        from . import kernels as K
+        self.shard, self.reqs, self.finish, self.keep, self.tag = shard, list(reqs), finish, keep, tag
+        self.launches_at_post = K.launch_count()
+        self.result = None
+        if self.reqs:
+            shard.stats["posted"] += 1
+
+    def wait(self) -> torch.Tensor:
+        if self.finish is not None:
+            from . import kernels as K
+            if self.reqs:
+                kind = "overlapped" if K.launch_count() > self.launches_at_post else "blocking"
+                self.shard.stats[kind] += 1
+                by = self.shard.stats.setdefault("by_tag", {}).setdefault(self.tag, {"overlapped": 0, "blocking": 0})
+                by[kind] += 1
+            for req in self.reqs:
+                req.wait()
+            self.result = self.finish()
+            self.finish, self.reqs, self.keep = None, [], ()
+        return self.result
 
 
 _active_shard: Optional[FrameShard] = None

@@ -25,7 +25,17 @@ def refresh_stream():
     _stream_cache["handle"] = C.c_void_p(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else None
 
 
+_launches = [0]
+
+
+def launch_count() -> int:
+    """Kernel launches issued through this module so far (every wrapper asks `_stream` for the launch stream exactly once per
+    launch): dist.Pending uses it to tell an exchange that had compute queued behind it from one that was waited for at once."""
+    return _launches[0]
+
+
 def _stream(t: torch.Tensor):
+    _launches[0] += 1
     if t.is_cuda:
         if _stream_cache["handle"] is None:
             refresh_stream()

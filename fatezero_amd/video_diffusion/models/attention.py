@@ -189,6 +189,20 @@ class CrossAttention(nn.Module):
             if self._qkv is None or self._qkv.device != x_norm.device:
                 self._qkv = torch.cat([self._qk_weight(x_norm.dtype, x_norm.device),
                                        self.to_v.packed(x_norm.dtype, x_norm.device)[0]], 0).contiguous()
+            shard = D.active_shard()
+            if shard is not None:
+                # frames split over ranks: every pixel attends over ALL frames of the clip.  K | V first, their all-gather POSTED,
+                # then the Q projection -- it runs while RCCL moves the other ranks' K / V (same weights, same arithmetic per
+                # output element as the fused q|k|v GEMM: the rows of the weight matrix are merely projected in two launches)
+                inner = self.inner_dim
+                kv_loc = K.gemm(x_norm, self._qkv[inner:])
+                pend = shard.all_gather_frames_async(kv_loc.reshape(batch, clip, l, 2 * inner), tag="temporal_attn")
+                q = K.gemm(x_norm, self._qkv[:inner])
+                kv = pend.wait().reshape(batch * shard.clip_len, l, 2 * inner)
+                out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
+                K.attn_temporal(q, kv[..., :inner], kv[..., inner:], out, batch=batch, clip_len=clip,
+                                kv_frames=shard.clip_len, heads=self.heads, scale=self.scale)
+                return self.to_out[0].apply(out, res=residual)
             qkv = K.gemm(x_norm, self._qkv)
         inner = self.inner_dim
         out = torch.empty(n, l, inner, dtype=x_norm.dtype, device=x_norm.device)
@@ -211,34 +225,42 @@ class CrossAttention(nn.Module):
         return super().load_state_dict(*a, **k)
 
 
-def _sharded_kv(shard, kk, vt, batch, clip, index_list):
+class _ShardedKV:
     """K / V^T of a frame-sharded clip on an extended frame axis [left halo | own frames | right halo | anchors]: the
     neighbour frames a relative index reaches and the 'first' / 'mid' / 'last' anchors are fetched from their owners
-    (attention.py:376-386 semantics: relative indices clamp to the CLIP ends, anchors are global frame numbers)."""
-    rel = [i for i in index_list if not isinstance(i, str)]
-    left, right = max([0] + [-i for i in rel]), max([0] + [i for i in rel])
-    anchors = [a for a in dict.fromkeys(K.kv_slots([i], shard.clip_len)[1][0] for i in index_list if isinstance(i, str))]
+    (attention.py:376-386 semantics: relative indices clamp to the CLIP ends, anchors are global frame numbers).
+    `post(t)` starts the fetch for one operand and returns a handle; `extend(handle)` waits and assembles -- the caller puts
+    independent work (the other projections) in between."""
 
-    def wanted(r):
-        fr = shard.frames_of(r)
-        return list(range(fr.start - left, fr.start)) + list(range(fr.stop, fr.stop + right)) + anchors
+    def __init__(self, shard, batch, clip, index_list):
+        self.shard, self.batch, self.clip = shard, batch, clip
+        rel = [i for i in index_list if not isinstance(i, str)]
+        self.left, self.right = max([0] + [-i for i in rel]), max([0] + [i for i in rel])
+        self.anchors = [a for a in dict.fromkeys(K.kv_slots([i], shard.clip_len)[1][0] for i in index_list if isinstance(i, str))]
+        kabs, kval = [], []
+        for i in index_list:
+            if isinstance(i, str):
+                kabs.append(1)
+                kval.append(self.left + clip + self.right + self.anchors.index(K.kv_slots([i], shard.clip_len)[1][0]))
+            else:
+                kabs.append(0)
+                kval.append(int(i))
+        self.ext = dict(kv_slots_override=(kabs, kval), kv_clip_len=self.left + clip + self.right + len(self.anchors),
+                        kv_frame_off=self.left)
 
-    def extend(t):  # [B*clip, ...] -> [B*(left+clip+right+len(anchors)), ...]
-        t4 = t.reshape(batch, clip, *t.shape[1:])
-        got = shard.fetch_frames(t4, wanted)
-        e = torch.cat([got[:, :left], t4, got[:, left:]], dim=1)
-        return e.reshape(batch * e.shape[1], *t.shape[1:])
+    def _wanted(self, r):
+        fr = self.shard.frames_of(r)
+        return list(range(fr.start - self.left, fr.start)) + list(range(fr.stop, fr.stop + self.right)) + self.anchors
 
-    kabs, kval = [], []
-    for i in index_list:
-        if isinstance(i, str):
-            kabs.append(1)
-            kval.append(left + clip + right + anchors.index(K.kv_slots([i], shard.clip_len)[1][0]))
-        else:
-            kabs.append(0)
-            kval.append(int(i))
-    ext = dict(kv_slots_override=(kabs, kval), kv_clip_len=left + clip + right + len(anchors), kv_frame_off=left)
-    return extend(kk), extend(vt), ext
+    def post(self, t):  # [B*clip, ...]
+        t4 = t.reshape(self.batch, self.clip, *t.shape[1:])
+        return t4, self.shard.fetch_frames_async(t4, self._wanted, tag="kv")
+
+    def extend(self, handle):  # -> [B*(left+clip+right+len(anchors)), ...]
+        t4, pend = handle
+        got = pend.wait()
+        e = torch.cat([got[:, :self.left], t4, got[:, self.left:]], dim=1)
+        return e.reshape(self.batch * e.shape[1], *t4.shape[2:])
 
 
 class SparseCausalAttention(CrossAttention):
@@ -251,17 +273,27 @@ class SparseCausalAttention(CrossAttention):
         # the projection GEMM in the log2 domain and the flash kernel gets its running max for free (csrc/attn_flash.hip)
         d_head = self.inner_dim // self.heads
         folded = d_head % 16 != 0 and d_head % 8 == 0
-        qk = K.gemm(xn, self._qk_weight(xn.dtype, xn.device, self.scale * _LOG2E if folded else 1.0))
-        q, kk = qk[..., : self.inner_dim], qk[..., self.inner_dim:]
-        # V^T straight out of the projection GEMM (operands swapped: [N, C, L], rows zero-padded to a multiple of 64 keys)
-        vt = K.gemm_vt(xn, self.to_v.packed(xn.dtype, xn.device)[0], K.pad64(lq))
-        out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
-        n_kv = max(1, len(index_list))
+        wqk = self._qk_weight(xn.dtype, xn.device, self.scale * _LOG2E if folded else 1.0)
         kw = dict(clip_len=clip, heads=self.heads, index_list=index_list, scale=self.scale, q_log2_scaled=folded)
         shard = D.active_shard()
         if shard is not None and len(index_list) > 0:
-            kk, vt, ext = _sharded_kv(shard, kk, vt, n // clip, clip, index_list)
-            kw.update(ext)
+            # frames split over ranks: K first and its neighbour / anchor fetch POSTED, then V^T and its fetch, then the Q projection
+            # -- both transfers run under it; the waits come last (the rows of the fused q|k weight are projected in two launches)
+            skv = _ShardedKV(shard, n // clip, clip, index_list)
+            kk = K.gemm(xn, wqk[self.inner_dim:])
+            hk = skv.post(kk)
+            vt = K.gemm_vt(xn, self.to_v.packed(xn.dtype, xn.device)[0], K.pad64(lq))
+            hv = skv.post(vt)
+            q = K.gemm(xn, wqk[: self.inner_dim])
+            kk, vt = skv.extend(hk), skv.extend(hv)
+            kw.update(skv.ext)
+        else:
+            qk = K.gemm(xn, wqk)
+            q, kk = qk[..., : self.inner_dim], qk[..., self.inner_dim:]
+            # V^T straight out of the projection GEMM (operands swapped: [N, C, L], rows zero-padded to a multiple of 64 keys)
+            vt = K.gemm_vt(xn, self.to_v.packed(xn.dtype, xn.device)[0], K.pad64(lq))
+        out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
+        n_kv = max(1, len(index_list))
         ctrl = self.controller
         plan = _plan_for(ctrl, False, self.place_in_unet, n, clip, self.heads, lq, n_kv * lq, xn.device)
         if plan is None:

@@ -83,12 +83,19 @@ class LoRALinearLayer(nn.Module):
             return y
         shard = D.active_shard()
         if shard is not None:
-            # the clip's frames are split over ranks: one-frame halos from the neighbours (zeros beyond the clip ends, the
-            # conv's own padding), first of x, then of down(x); the halo frames' outputs are dropped
-            x_ext = shard.with_halo(x4, 1, 1, zero_outside=True)
-            d = self._conv(x_ext, wdn)[:, 1:-1].contiguous()
-            d_ext = shard.with_halo(d, 1, 1, zero_outside=True)
-            y = self._conv(d_ext, wun)[:, 1:-1] + x4
+            # the clip's frames are split over ranks: ONE exchange -- a two-frame halo of x from both neighbours (zeros beyond the clip
+            # ends, the conv's own padding).  down() over the extended clip yields down(x) of the own frames AND of the one-frame halo
+            # the up convolution needs (recomputed from the neighbours' x instead of exchanged a second time: the same fp16 arithmetic
+            # the owner runs); halo frames that lie OUTSIDE the clip are the up convolution's zero padding, not down(zeros | x)
+            x_ext = shard.with_halo(x4, 2, 2, zero_outside=True, tag="temporal_conv")
+            d_ext = self._conv(x_ext, wdn)[:, 1:-1]
+            if shard.f0 == 0 or shard.f1 == shard.clip_len:
+                d_ext = d_ext.clone()
+                if shard.f0 == 0:
+                    d_ext[:, 0] = 0
+                if shard.f1 == shard.clip_len:
+                    d_ext[:, -1] = 0
+            y = self._conv(d_ext.contiguous(), wun)[:, 1:-1] + x4
             if temb is not None:
                 y = y + temb[:, None, None, :]
             if residual is not None:

@@ -118,7 +118,7 @@ class PseudoConv3d(nn.Module):
             shard = D.active_shard()
             y4 = y.view(x.b, x.f, oh * ow, self.out_channels)
             if shard is not None:  # frames split over ranks: one-frame halo from both neighbours, halo outputs dropped
-                y4 = temporal_conv_tokens(shard.with_halo(y4, 1, 1, zero_outside=True), wtt, rows_add=rows.contiguous())[:, 1:-1]
+                y4 = temporal_conv_tokens(shard.with_halo(y4, 1, 1, zero_outside=True, tag="temporal_conv"), wtt, rows_add=rows.contiguous())[:, 1:-1]
                 y = y4.reshape(n, oh * ow, self.out_channels)
                 if residual is not None:
                     y = y + residual
@@ -158,7 +158,7 @@ def group_norm_tokens(norm: _NormParams, x: Tokens, *, span_frames: bool, silu: 
         # and merge them in the same fixed order on every rank
         n, _, _ = x.data.shape
         part = K.groupnorm_stats(x.data, groups=norm.num_groups)
-        allp = shard.all_gather_frames(part.view(n // x.f, x.f, *part.shape[1:])).contiguous()
+        allp = shard.all_gather_frames(part.view(n // x.f, x.f, *part.shape[1:]), tag="groupnorm").contiguous()
         y = K.groupnorm_apply(x.data, g, b, allp, span=x.f, groups=norm.num_groups, eps=norm.eps, silu=silu)
         return x.like(y)
     y = K.groupnorm(x.data, g, b, span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps, silu=silu)

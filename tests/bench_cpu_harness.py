@@ -81,6 +81,7 @@ def main():
     bench.build_pipeline = _tiny_pipeline
     # 8x8 latents: the blend-word maps of spatial_blend.py:78 only line up at the 512^2 / 576^2 list layouts -> no blend words here
     bench.EDIT_KW = {k: v for k, v in bench.EDIT_KW.items() if k not in ("blend_words", "blend_self_attention", "blend_th")}
+    bench.EDIT0_KW = {k: v for k, v in bench.EDIT0_KW.items() if k not in ("blend_words", "blend_self_attention", "blend_th")}
     import torch.distributed as dist
     real_init = dist.init_process_group
     dist.init_process_group = lambda backend=None, **kw: real_init("gloo", **kw)

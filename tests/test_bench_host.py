@@ -69,9 +69,25 @@ def test_bench_main_two_ranks_clips_and_frame_shard_probe():
     assert line["config"]["parallelism"] == "dp2 over clips" and line["config"]["outputs_finite"] is True
     assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 1 / (line["ms_per_step"] / 1e3)) < 1e-6 * line["value"]  # whole-job frames/s
     assert line["steps"] == 1 and line["warmup"] == 0 and line["higher_is_better"] is True and line["cpu_baseline"] is None
+    # the config-faithful job (1 inversion + both prompts of the YAML) is measured beside the primary
+    ne2 = line["config_faithful_n_edit_2"]
+    assert ne2["n_edit"] == 2 and ne2["outputs_finite"] is True and abs(ne2["value"] - 2 * 2 / (ne2["ms_per_job"] / 1e3)) < 1e-6 * ne2["value"]
     fs = line["frame_sharded"]
     assert "error" not in fs, fs
     assert fs["scaling"] == "strong" and fs["outputs_finite"] is True and fs["value"] > 0
+
+
+def test_bench_main_two_ranks_auto_promotes_the_frame_sharded_clip():
+    """frames >= 2 x ranks: the default (`--shard auto`) reports the frame-sharded clip as `value` (strong scaling, K timed jobs) and
+    keeps the one-clip-per-rank measurement beside it; the exchange counters of the shard travel in the line."""
+    line = _run_bench_ranks(2, ["--frames", "4", "--no-kernel-breakdown", "--no-n-edit2-probe"])
+    fs = line["frame_sharded"]
+    assert "error" not in fs and fs["jobs_timed"] == 1 and fs["outputs_finite"] is True, fs
+    assert line["scaling"] == "strong" and line["config"]["parallelism"] == "2-way frame-sharded clip"
+    assert line["value"] == fs["value"] and line["ms_per_step"] == fs["ms_per_job"]
+    assert line["clips_dp"]["scaling"] == "weak" and line["clips_dp"]["parallelism"] == "dp2 over clips" and line["clips_dp"]["value"] > 0
+    ex = fs["exchanges"]
+    assert ex["overlapped_with_compute"] > 0 and ex["posted"] == ex["overlapped_with_compute"] + ex["blocking"], ex
 
 
 def test_bench_main_two_ranks_frames_mode():

@@ -147,11 +147,12 @@ def _frame_worker(rank, world, port, frames, index_list, run_model, q):
         pipe, job = _frame_job_factory(frames, index_list)
         assert D.weights_agree(pipe.unet, "cpu")
         pipe.frame_shard = shard
+        shard.stats = {"posted": 0, "overlapped": 0, "blocking": 0}  # (the primitive checks above are not part of a forward)
         res = job()
         store = pipe.store_controller
         n_maps = [t.shape[0] for t in store.attention_store_all_step[0]["down_self"]] if store.attention_store_all_step else []
         if rank == 0:
-            q.put((res.clone(), n_maps, shard.n_local))
+            q.put((res.clone(), n_maps, shard.n_local, dict(shard.stats)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -172,13 +173,33 @@ def _spawn(world, *args):
     return got
 
 
+def _check_exchange_structure(stats):
+    """What overlaps and what cannot: every sparse-causal K / V^T fetch and every temporal-attention K | V all-gather is posted
+    BEFORE the Q projection and waited for after it (never blocking); the temporal convolution costs ONE exchange (its down(x)
+    halo is recomputed, not exchanged a second time); the GroupNorm statistics gathers sit between the statistics kernel and the
+    normalisation that needs them at once (blocking by data dependence: the layer chain is sequential)."""
+    by = stats["by_tag"]
+    assert by["kv"]["blocking"] == 0 and by["kv"]["overlapped"] > 0, stats
+    assert by["temporal_attn"]["blocking"] == 0 and by["temporal_attn"]["overlapped"] > 0, stats
+    # tiny16 UNet: 16 transformer blocks (one K and one V^T fetch + one temporal-attention gather each) per forward
+    assert by["kv"]["overlapped"] == 2 * by["temporal_attn"]["overlapped"], stats
+    n_forward = by["temporal_attn"]["overlapped"] // 16
+    assert n_forward >= 4 and by["temporal_attn"]["overlapped"] == 16 * n_forward, stats
+    # one exchange per temporal LoRA convolution: 53 PseudoConv3d with a LoRA pair per forward at most (conv_in, 22 resnets x 2,
+    # 4 downsamplers, 3 upsamplers, conv_out), never two per convolution
+    assert by["temporal_conv"]["blocking"] <= 53 * n_forward, stats
+    # (+ the all-gather of the finished latents at the end of the inversion and of the edit)
+    assert 0 <= stats["blocking"] - by["temporal_conv"]["blocking"] - by["groupnorm"]["blocking"] <= 4, stats
+
+
 def test_frame_shard_exchanges_three_ranks_ragged():
     _spawn(3, 7, [-1, "first"], False)   # 3 + 2 + 2 frames: a middle rank with two neighbours, ragged all-gather
 
 
 @pytest.mark.parametrize("frames,index_list", [(4, ["mid", 1]), (5, [-1, "first"])])  # 5 frames: ragged 3 + 2 split
 def test_frame_sharded_clip_matches_single_process(frames, index_list):
-    got, n_maps, n_local = _spawn(2, frames, index_list, True)
+    got, n_maps, n_local, stats = _spawn(2, frames, index_list, True)
+    _check_exchange_structure(stats)
     _, job = _frame_job_factory(frames, index_list)
     from fatezero_amd import _native
     try:
@@ -199,7 +220,8 @@ def test_frame_sharded_clip_matches_single_process(frames, index_list):
 def test_frame_sharded_clip_four_ranks_eight_frames():
     """The teaser clip length on 4 ranks (2 frames each): interior ranks exchange halos with both neighbours, rank 0 serves the
     'first' anchor to everybody, every GroupNorm merges 4 ranks' partials."""
-    got, n_maps, n_local = _spawn(4, 8, [-1, "first"], True)
+    got, n_maps, n_local, stats = _spawn(4, 8, [-1, "first"], True)
+    _check_exchange_structure(stats)
     _, job = _frame_job_factory(8, [-1, "first"])
     from fatezero_amd import _native
     try:
