@@ -55,7 +55,7 @@ class FzGemmDesc(C.Structure):
         ("batch", C.c_int32), ("epilogue", C.c_int32),
         ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64), ("res_batch_stride", C.c_int64),
         ("transpose_out", C.c_int32), ("tile_cfg", C.c_int32), ("split_k", C.c_int32), ("reserved0", C.c_int32),
-        ("workspace_floats", C.c_int64),
+        ("workspace_floats", C.c_int64), ("w_batch_stride", C.c_int64),
     ]
 
 

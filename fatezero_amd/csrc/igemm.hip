@@ -23,6 +23,7 @@
 // igemm_reduce_kernel combines with the same tail.
 #include "fz_rt.h"
 #include <type_traits>
+#include <atomic>
 #include "../../include/fatezero_hip.h"
 
 // PP (template parameter of the kernel): 0 = ring loop; bit 0 = phase-interleaved ("ping-pong") loop, and its trial forms (only
@@ -986,12 +987,15 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     if (nt <= 0 || nt >= (1ll << 31) || batch <= 0 || batch > 65535 || g.ksplit < 1 || g.ksplit > 65535) return FZ_ERR_BAD_ARG;
     const size_t lds = (size_t)C::LDS_HALVES * sizeof(half_t);
 #ifndef FZ_EMU
-    static bool attr_set = false;  // LDS above 64 KB is an opt-in function attribute, not tuning state
-    if (!attr_set) {
+    // LDS above 64 KB is an opt-in function attribute -- PER DEVICE: a process that drives a second GPU must set it there as well
+    static std::atomic<uint64_t> attr_set_mask{0};  // bit d = set on device ordinal d (ordinals >= 64: set on every launch)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FZ_ERR_LAUNCH;
+    if (dev >= 64 || !(attr_set_mask.load(std::memory_order_relaxed) >> dev & 1)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
-        attr_set = true;
+        if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
 #endif
     dim3 grid((unsigned)nt, (unsigned)g.ksplit, (unsigned)batch), block(C::T);
@@ -1217,7 +1221,7 @@ static int gemm_impl(const FzGemmDesc* d, const FzGemmLn* ln, const void* x, con
     if (!d->transpose_out) {  // y[row][out]:  A = W (out features), B = x rows
         g.a = (const half_t*)w;
         g.lda = d->ldw;
-        g.a_bs = 0;
+        g.a_bs = d->w_batch_stride;  // 0: shared weights
         g.Ma = d->out_features;
         g.Ma_store = d->out_features;
         g.b = (const half_t*)x;

@@ -227,7 +227,7 @@ _gn_plans = {}
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span: int, groups: int, eps: float,
               silu: bool, out: Optional[torch.Tensor] = None):
     """x: [N, tokens, C] contiguous fp16; statistics shared by `span` consecutive frames."""
-    key = (x.shape, span, groups, x.device)
+    key = (x.shape, span, groups, _scratch_key(x))
     plan = _gn_plans.get(key)
     if plan is None:  # first use of this signature: validate, size the scratch
         n, tokens, c = x.shape
@@ -235,15 +235,23 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span:
         _chk16(x, gamma, beta)
         chunks = N.lib().fz_groupnorm_chunks(tokens, c)
         need = n * chunks * groups * 3 + (n // span) * groups * 2
-        buf = _gn_scratch.get(x.device)
+        skey = _scratch_key(x)
+        buf = _gn_scratch.get(skey)
         if buf is None or buf.numel() < need:
             buf = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
-            _gn_scratch[x.device] = buf
+            _gn_scratch[skey] = buf
             _gn_plans.clear()  # plans hold the scratch pointer
         plan = _gn_plans[key] = (n, tokens, c, buf.data_ptr(), buf)
     n, tokens, c, scratch, _ = plan
+    # cheap per-call checks (the plan is keyed on the shape only: a later non-contiguous / non-fp16 / misaligned tensor of the same
+    # shape must not reach the kernel)
+    if not x.is_contiguous() or x.dtype != torch.float16 or gamma.dtype != torch.float16 or beta.dtype != torch.float16 or \
+            ((x.data_ptr() | gamma.data_ptr() | beta.data_ptr()) & 15):
+        raise ValueError("fz_groupnorm: x must be contiguous fp16, gamma / beta fp16, all 16-byte aligned")
     if out is None:
         out = torch.empty_like(x)
+    elif not out.is_contiguous() or out.dtype != torch.float16 or out.shape != x.shape or (out.data_ptr() & 15):
+        raise ValueError("fz_groupnorm: out must be a contiguous fp16 tensor of x's shape")
     rc = N.lib().fz_groupnorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, span, tokens, c, groups, eps,
                               1 if silu else 0, scratch, _stream(x))
     if rc:
@@ -304,10 +312,20 @@ def pack_geglu(w: torch.Tensor, b: Optional[torch.Tensor]):
 _WS_FLOATS = 64 << 20  # 256 MB of fp32 split-K scratch per device, allocated on first need
 
 
+def _scratch_key(t_or_device):
+    """Scratch buffers (split-K slabs, GroupNorm partials) are per (device, current stream): two streams that both take a split-K
+    path must not share the fp32 slabs."""
+    dev = t_or_device.device if isinstance(t_or_device, torch.Tensor) else torch.device(t_or_device)
+    if dev.type != "cuda":
+        return (dev, 0)
+    return (dev, torch.cuda.current_stream(dev).cuda_stream)
+
+
 def _ws_ptr(device):
-    buf = _ws.get(device)
+    key = _scratch_key(device)
+    buf = _ws.get(key)
     if buf is None:
-        buf = _ws[device] = torch.empty(_WS_FLOATS, dtype=torch.float32, device=device)
+        buf = _ws[key] = torch.empty(_WS_FLOATS, dtype=torch.float32, device=device)
     return buf.data_ptr()
 
 
@@ -359,8 +377,15 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if out is None:
         out = torch.empty(out_shape, dtype=torch.float16, device=x.device)
     ptrs = x.data_ptr() | w.data_ptr() | out.data_ptr()
+    for t in (bias, res, res2):  # the plan is built once per signature: pointers and dtypes of the optional operands change per call
+        if t is not None:
+            if t.dtype != torch.float16:
+                raise ValueError("fz_gemm: bias / res / res2 must be fp16")
+            ptrs |= t.data_ptr()
     if (ptrs & 15) or x.dtype != torch.float16 or w.dtype != torch.float16:
         raise ValueError("fz_gemm operands must be fp16 and 16-byte aligned")
+    if res is not None and res2 is not None and res2.stride() != res.stride():
+        raise ValueError("fz_gemm: res2 must have the layout of res")
     if ln is None and not want_stats:
         rc = N.lib().fz_gemm(d_ref, x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                              None if res is None else res.data_ptr(), None if res2 is None else res2.data_ptr(), out.data_ptr(),
@@ -387,6 +412,33 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     elif rc:
         N.check(rc, "fz_gemm_ln")
     return (out, stats) if want_stats else out
+
+
+def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """y[b] = x[b] @ w[b]^T for every batch element in ONE launch: x [B, rows, K], w [B, O, K], y [B, rows, O]; fp16, unit
+    innermost strides, one row stride and one batch stride each (views are fine).  The two products of a single-head attention
+    block (scores = q k^T, out = P (V^T)^T): FzGemmDesc.w_batch_stride."""
+    b, rows, k = x.shape
+    o = w.shape[1]
+    assert w.shape == (b, o, k) and x.stride(2) == 1 and w.stride(2) == 1 and x.dtype == w.dtype == torch.float16
+    if out is None:
+        out = torch.empty(b, rows, o, dtype=torch.float16, device=x.device)
+    assert out.shape == (b, rows, o) and out.stride(2) == 1 and out.dtype == torch.float16
+    for t in (x, w, out):
+        if (t.data_ptr() & 15) or (t.stride(0) % 8) or (t.stride(1) % 8):
+            raise ValueError("fz_gemm (batched): 16-byte aligned operands, row / batch strides multiples of 8 halves")
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = rows, k, o
+    d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(1), out.stride(1)
+    d.batch, d.epilogue = b, N.FZ_GEMM_PLAIN
+    d.x_batch_stride, d.w_batch_stride, d.y_batch_stride = x.stride(0), w.stride(0), out.stride(0)
+    want_ws = o % 4 == 0 and 2 * b * rows * o <= _WS_FLOATS
+    d.workspace_floats = _WS_FLOATS if want_ws else 0
+    rc = N.lib().fz_gemm(C.byref(d), x.data_ptr(), w.data_ptr(), None, None, None, out.data_ptr(),
+                         _ws_ptr(x.device) if want_ws else None, _stream(x))
+    if rc:
+        N.check(rc, "fz_gemm (batched)")
+    return out
 
 
 def _gemm_plan(x, w, bias, res, res2, out, geglu, tile_cfg, split_k):
@@ -507,6 +559,8 @@ def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Opt
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):
     c = x.shape[-1]
     assert x.is_contiguous() and x.dtype == torch.float16
+    if gamma.dtype != torch.float16 or beta.dtype != torch.float16 or ((x.data_ptr() | gamma.data_ptr() | beta.data_ptr()) & 15):
+        raise ValueError("fz_layernorm: fp16, 16-byte aligned x / gamma / beta")
     if out is None:
         out = torch.empty_like(x)
     rc = N.lib().fz_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.numel() // c, c, eps, _stream(x))

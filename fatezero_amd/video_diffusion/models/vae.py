@@ -119,12 +119,16 @@ class AttentionBlock(nn.Module):
         wv, bv = self.value.packed(torch.float16, dev)
         vt = K.gemm_vt(h, wv, lp)                                     # V^T [n, c, lp] straight out of the GEMM (bias added below)
         out = torch.empty(n, l, c, dtype=torch.float16, device=dev)
-        for i in range(n):  # one frame at a time: the [l, l] score matrix of a 512^2 frame is 32 MB
-            s = K.gemm(qk[i, :, :c], qk[i, :, c:])                    # scores [l, l] = q k^T
+        # three launches for a chunk of frames (batched q k^T, row softmax, batched P V) instead of three per frame; the [l, l]
+        # score matrix of a 512^2 frame is 32 MB in fp16: chunks of at most 8 frames keep scores + probabilities under 0.6 GB
+        step = max(1, min(n, (1 << 28) // max(1, l * lp)))
+        for i0 in range(0, n, step):
+            i1 = min(n, i0 + step)
+            s = K.gemm_batched(qk[i0:i1, :, :c], qk[i0:i1, :, c:])     # scores [f, l, l] = q k^T
             if lp != l:
                 s = torch.nn.functional.pad(s, (0, lp - l), value=float("-inf"))
-            p = K.softmax_rows(s)
-            K.gemm(p, vt[i], out=out[i])                              # P V
+            p = K.softmax_rows(s.view(-1, lp)).view(i1 - i0, l, lp)
+            K.gemm_batched(p, vt[i0:i1], out=out[i0:i1])                # P V
         # softmax rows sum to one, so the value bias passes through the attention unchanged: add it here
         out = out + bv
         return x.like(self.proj_attn.apply(out, res=x.data))
@@ -322,7 +326,22 @@ class AutoencoderKL(nn.Module):
         model.load_state_dict(sd)
         return model.eval()
 
+    _ATTN_KEY_MAP = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+
     def load_state_dict(self, state_dict, strict=True):
+        # VAE folders saved by diffusers >= 0.15 name the mid-block attention to_q / to_k / to_v / to_out.0 (and older conversion
+        # scripts stored its projections as 1x1 convolutions [C, C, 1, 1]); diffusers remaps both on load, so do we
+        remapped = {}
+        for k, v in state_dict.items():
+            if ".attentions." in k:
+                for new_name, old_name in self._ATTN_KEY_MAP.items():
+                    if f".{new_name}." in k:
+                        k = k.replace(f".{new_name}.", f".{old_name}.")
+                        break
+                if k.endswith(".weight") and v.dim() == 4 and v.shape[2:] == (1, 1):
+                    v = v[:, :, 0, 0]
+            remapped[k] = v
+        state_dict = remapped
         for m in self.modules():
             if isinstance(m, (_Conv2d, _LinearParams, _NormParams)):
                 m._packed = None

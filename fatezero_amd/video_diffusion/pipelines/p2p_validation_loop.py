@@ -68,7 +68,12 @@ class P2pSampleLogger:
             samples_all.append(frames)
         for call in self._plan():
             idx, seed, kw = call["prompt_index"], call["seed"], dict(call["kwargs"])
-            generator = torch.Generator(device="cpu").manual_seed(seed)
+            # the reference seeds a generator ON the pipeline's device (p2p_validation_loop.py:108-109): noise drawn from it (strength-based
+            # img2img / use_invertion_latents False) is the device generator's stream, so per-seed results match upstream's
+            try:
+                generator = torch.Generator(device=device).manual_seed(seed)
+            except RuntimeError:  # a device without generator support (the CPU-emulation tests pass 'cpu' anyway)
+                generator = torch.Generator(device="cpu").manual_seed(seed)
             ret = pipeline(image=image, generator=generator, latents=latents, uncond_embeddings_list=uncond_embeddings_list,
                            save_path=save_dir, **kw)
             attention_output = None

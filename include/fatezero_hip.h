@@ -177,6 +177,9 @@ typedef struct FzGemmDesc {
     int32_t split_k;
     int32_t reserved0;
     int64_t workspace_floats;
+    int64_t w_batch_stride; /* elements between the w matrices of consecutive batch elements; 0: w (and bias) shared by the batch.
+                             * Per-batch w = the two batched products of a single-head attention block: scores = q k^T and P v^T^T
+                             * (diffusers AttentionBlock of the VAE mid block [3P], reached from stable_diffusion.py:297-319). */
 } FzGemmDesc;
 int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch);
 int fz_gemm(const FzGemmDesc* desc, const void* x, const void* w, const void* bias, const void* res, const void* res2,

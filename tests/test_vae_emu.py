@@ -29,6 +29,40 @@ def test_softmax_rows():
         assert float((y.float().sum(-1) - 1).abs().max()) < 5e-3
 
 
+def test_gemm_batched_per_batch_weights():
+    # y[b] = x[b] w[b]^T in one launch (FzGemmDesc.w_batch_stride): the two products of the VAE's single-head attention
+    g = torch.Generator().manual_seed(0)
+    for (b, rows, k, o) in [(3, 70, 64, 40), (2, 33, 40, 136)]:
+        x = torch.randn(b, rows, k, generator=g).half()
+        w = (torch.randn(b, o, k, generator=g) * k ** -0.5).half()
+        y = K.gemm_batched(x, w)
+        ref = torch.einsum("brk,bok->bro", x.float(), w.float())
+        assert float((y.float() - ref).abs().max()) < 4e-3 * max(1.0, float(ref.abs().max()))
+    # views with row / batch strides (the q | k halves of one projection output)
+    qk = torch.randn(2, 24, 64, generator=g).half()
+    y = K.gemm_batched(qk[:, :, :32], qk[:, :, 32:])
+    assert float((y.float() - torch.einsum("brk,bok->bro", qk[:, :, :32].float(), qk[:, :, 32:].float())).abs().max()) < 2e-2
+
+
+def test_vae_state_dict_of_newer_diffusers_loads():
+    """AutoencoderKL folders written by diffusers >= 0.15 name the mid-block attention to_q / to_k / to_v / to_out.0; older
+    conversion scripts stored those projections as 1x1 convolutions: both load (diffusers remaps them too)."""
+    vae, sd = VC.seeded_vae(VC.TINY, seed=5)
+    newer = {}
+    for k, v in sd.items():
+        for old, new in (("query", "to_q"), ("key", "to_k"), ("value", "to_v"), ("proj_attn", "to_out.0")):
+            if f".attentions.0.{old}." in k:
+                k = k.replace(f".{old}.", f".{new}.")
+                if k.endswith(".weight"):
+                    v = v[:, :, None, None]
+        newer[k] = v
+    assert any(".to_q." in k for k in newer)
+    vae2, _ = VC.seeded_vae(VC.TINY, seed=6)
+    vae2.load_state_dict(newer)
+    for (k1, v1), (k2, v2) in zip(vae.state_dict().items(), vae2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+
+
 def test_vae_encode_decode_tiny():
     r = VC.case_vae_roundtrip("cpu", VC.TINY, n=2, hw=16)
     print(r)
