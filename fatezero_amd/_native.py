@@ -83,6 +83,8 @@ _SIGS = {
     "fz_groupnorm_chunks": (C.c_int, [C.c_int, C.c_int]),
     "fz_groupnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                _P, _P]),
+    "fz_groupnorm_cat": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                   _P, _P]),
     "fz_groupnorm_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "fz_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
                                      C.c_int, C.c_int, _P, _P]),

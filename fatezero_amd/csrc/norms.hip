@@ -36,6 +36,8 @@ extern "C" int fz_groupnorm_chunks(int tokens, int channels) {
 
 struct GnArgs {
     const half_t* x;
+    const half_t* x2;  // channels [C1, C) come from a SECOND tensor [n][tokens][C - C1] (the skip connection of an up block:
+    int C1;            // GroupNorm of torch.cat([x, skip], channel) without the concatenated copy); x2 == nullptr: C1 = C
     half_t* y;
     const half_t *gamma, *beta;
     float* partial;  // [n_frames][G][chunks][3]: the partials of one (frame, group) are contiguous
@@ -64,7 +66,10 @@ FZ_KERNEL void __launch_bounds__(ROWS > 0 ? 512 : 1024) gn_stats_kernel(GnArgs a
     const int t1 = min(t0 + a.tb, a.tokens);
     const int cg = a.C / a.G;
     const float cnt = (float)((t1 - t0) * cg);
-    const half_t* base = a.x + ((int64_t)n * a.tokens) * a.C + v * 8;
+    // (a 16-byte chunk never straddles the two sources: C1 % 8 == 0)
+    const bool second = v * 8 >= a.C1;
+    const int64_t rs = second ? a.C - a.C1 : a.C1;  // row stride of this thread's source
+    const half_t* base = (second ? a.x2 + ((int64_t)n * a.tokens) * rs + (v * 8 - a.C1) : a.x + ((int64_t)n * a.tokens) * rs + v * 8);
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.0f;
@@ -74,7 +79,7 @@ FZ_KERNEL void __launch_bounds__(ROWS > 0 ? 512 : 1024) gn_stats_kernel(GnArgs a
         for (int i = 0; i < ROWS; ++i) {  // unconditional, clamped: every load is issued before the first use
             int t = t0 + r + i * a.R;
             t = t < t1 ? t : t1 - 1;
-            xr[i] = fz_ld_h8(base + (int64_t)t * a.C);
+            xr[i] = fz_ld_h8(base + (int64_t)t * rs);
         }
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
@@ -85,7 +90,7 @@ FZ_KERNEL void __launch_bounds__(ROWS > 0 ? 512 : 1024) gn_stats_kernel(GnArgs a
         }
     } else {
         for (int t = t0 + r; t < t1; t += a.R) {
-            const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+            const half8_t xv = fz_ld_h8(base + (int64_t)t * rs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += (float)xv[e];
         }
@@ -119,7 +124,7 @@ FZ_KERNEL void __launch_bounds__(ROWS > 0 ? 512 : 1024) gn_stats_kernel(GnArgs a
         }
     } else {
         for (int t = t0 + r; t < t1; t += a.R) {
-            const half8_t xv = fz_ld_h8(base + (int64_t)t * a.C);
+            const half8_t xv = fz_ld_h8(base + (int64_t)t * rs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float dlt = (float)xv[e] - mu[e];
@@ -218,11 +223,13 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
         sc[e] = rstd * (float)gv[e];
         sh[e] = (float)bv[e] - mean * sc[e];
     }
-    const half_t* xb = a.x + ((int64_t)n * a.tokens) * a.C + v * 8;
+    const bool second = v * 8 >= a.C1;
+    const int64_t rs = second ? a.C - a.C1 : a.C1;
+    const half_t* xb = (second ? a.x2 + ((int64_t)n * a.tokens) * rs + (v * 8 - a.C1) : a.x + ((int64_t)n * a.tokens) * rs + v * 8);
     half_t* yb = a.y + ((int64_t)n * a.tokens) * a.C + v * 8;
 #pragma unroll 4
     for (int t = t0 + r; t < t1; t += a.R) {
-        const half8_t xv = fz_ld_h8(xb + (int64_t)t * a.C);
+        const half8_t xv = fz_ld_h8(xb + (int64_t)t * rs);
         half8_t yv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -271,7 +278,8 @@ extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const voi
     size_t smem;
     const int rc = gn_setup(a, n_frames, span, tokens, channels, groups, threads, smem);
     if (rc != FZ_OK) return rc;
-    a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
+    a.x = (const half_t*)x; a.x2 = nullptr; a.C1 = channels;
+    a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
     a.eps = eps; a.silu = silu;
     a.partial = partial;
     a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
@@ -279,6 +287,28 @@ extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const voi
     gn_launch_stats(a, grid, block, smem, stream);
     const int nst = (n_frames / span) * groups;
     FZ_LAUNCH(gn_finalize_kernel, dim3(nst), dim3(64), 0, stream, a);
+    FZ_LAUNCH(gn_apply_kernel, grid, block, 0, stream, a);
+    return fz_last_launch_status();
+}
+
+extern "C" int fz_groupnorm_cat(const void* x1, int channels1, const void* x2, int channels2, void* y, const void* gamma,
+                                const void* beta, int n_frames, int span, int tokens, int groups, float eps, int silu, float* partial,
+                                void* stream) {
+    if (!x1 || !x2 || !y || !gamma || !beta || !partial || channels1 <= 0 || channels2 <= 0 || (channels1 % 8) || (channels2 % 8))
+        return FZ_ERR_BAD_ARG;
+    GnArgs a;
+    int threads;
+    size_t smem;
+    const int rc = gn_setup(a, n_frames, span, tokens, channels1 + channels2, groups, threads, smem);
+    if (rc != FZ_OK) return rc;
+    a.x = (const half_t*)x1; a.x2 = (const half_t*)x2; a.C1 = channels1;
+    a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
+    a.eps = eps; a.silu = silu;
+    a.partial = partial;
+    a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
+    dim3 grid(a.chunks, n_frames), block(threads);
+    gn_launch_stats(a, grid, block, smem, stream);
+    FZ_LAUNCH(gn_finalize_kernel, dim3((n_frames / span) * groups), dim3(64), 0, stream, a);
     FZ_LAUNCH(gn_apply_kernel, grid, block, 0, stream, a);
     return fz_last_launch_status();
 }
@@ -291,7 +321,8 @@ extern "C" int fz_groupnorm_stats(const void* x, int n_frames, int tokens, int c
     size_t smem;
     const int rc = gn_setup(a, n_frames, 1, tokens, channels, groups, threads, smem);
     if (rc != FZ_OK) return rc;
-    a.x = (const half_t*)x; a.y = nullptr; a.gamma = nullptr; a.beta = nullptr; a.eps = 0.0f; a.silu = 0;
+    a.x = (const half_t*)x; a.x2 = nullptr; a.C1 = channels;
+    a.y = nullptr; a.gamma = nullptr; a.beta = nullptr; a.eps = 0.0f; a.silu = 0;
     a.partial = partial; a.stats = nullptr;
     gn_launch_stats(a, dim3(a.chunks, n_frames), dim3(threads), smem, stream);
     return fz_last_launch_status();
@@ -307,7 +338,8 @@ extern "C" int fz_groupnorm_apply(const void* x, void* y, const void* gamma, con
     const int rc = gn_setup(a, n_frames, span, tokens, channels, groups, threads, smem);
     if (rc != FZ_OK) return rc;
     if (n_frames / span != stat_sets) return FZ_ERR_BAD_ARG;
-    a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
+    a.x = (const half_t*)x; a.x2 = nullptr; a.C1 = channels;
+    a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
     a.eps = eps; a.silu = silu;
     a.partial = const_cast<float*>(partial_all);
     a.stats = stats;

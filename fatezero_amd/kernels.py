@@ -259,6 +259,31 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span:
     return out
 
 
+def groupnorm_cat(x1: torch.Tensor, x2: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span: int, groups: int, eps: float,
+                  silu: bool) -> torch.Tensor:
+    """GroupNorm(+SiLU) of torch.cat([x1, x2], -1) without building the concatenation (fz_groupnorm_cat): x1 [N, tokens, C1],
+    x2 [N, tokens, C2] contiguous fp16 -> [N, tokens, C1 + C2]."""
+    n, tokens, c1 = x1.shape
+    c2 = x2.shape[2]
+    if not (x1.is_contiguous() and x2.is_contiguous() and x2.shape[:2] == x1.shape[:2] and x1.dtype == x2.dtype == torch.float16
+            and gamma.dtype == beta.dtype == torch.float16 and gamma.numel() == c1 + c2):
+        raise ValueError("fz_groupnorm_cat: two contiguous fp16 tensors [N, tokens, C1] / [N, tokens, C2], gamma / beta over C1 + C2")
+    _chk16(x1, x2, gamma, beta)
+    c = c1 + c2
+    chunks = N.lib().fz_groupnorm_chunks(tokens, c)
+    need = n * chunks * groups * 3 + (n // span) * groups * 2
+    skey = _scratch_key(x1)
+    buf = _gn_scratch.get(skey)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x1.device)
+        _gn_scratch[skey] = buf
+        _gn_plans.clear()  # plans hold the scratch pointer
+    out = torch.empty(n, tokens, c, dtype=torch.float16, device=x1.device)
+    N.check(N.lib().fz_groupnorm_cat(x1.data_ptr(), c1, x2.data_ptr(), c2, out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, span,
+                                     tokens, groups, eps, 1 if silu else 0, buf.data_ptr(), _stream(x1)), "fz_groupnorm_cat")
+    return out
+
+
 def groupnorm_stats(x: torch.Tensor, *, groups: int) -> torch.Tensor:
     """Welford partials (count, mean, M2) of this rank's frames: float [N, G, chunks, 3] (fz_groupnorm_stats)."""
     n, tokens, c = x.shape

@@ -12,7 +12,7 @@ from torch import nn
 
 from ... import dist as D
 from ... import kernels as K
-from .lora import LoRALinearLayer, _Conv1dParams, temporal_conv_tokens
+from .lora import LoRALinearLayer, _Conv1dParams, pack_temporal_weight, temporal_conv_tokens
 
 
 class Tokens:
@@ -30,12 +30,38 @@ class Tokens:
         return Tokens(data, self.b, self.f, self.h if h is None else h, self.w if w is None else w)
 
     @staticmethod
+    def cat(a, b):
+        """torch.cat([a, b], channel) as a LAZY pair (unet_3d_blocks.py:384-395: the skip connections of the up blocks): the two
+        consumers of the concatenation -- the resnet's first GroupNorm and its 1x1 shortcut convolution -- read the two tensors in
+        place (fz_groupnorm_cat; two accumulating GEMMs over the two halves of K); anything else that touches `.data` gets the
+        materialised concatenation."""
+        return CatTokens(a, b)
+
+    @staticmethod
     def from_bcfhw(x):
         b, c, f, h, w = x.shape
         return Tokens(x.permute(0, 2, 3, 4, 1).reshape(b * f, h * w, c).contiguous(), b, f, h, w)
 
     def to_bcfhw(self):
         return self.data.view(self.b, self.f, self.h, self.w, self.c).permute(0, 4, 1, 2, 3)
+
+
+class CatTokens(Tokens):
+    __slots__ = ("parts", "_cat")
+
+    def __init__(self, a: Tokens, b: Tokens):
+        self.parts, self._cat = (a.data, b.data), None
+        self.b, self.f, self.h, self.w = a.b, a.f, a.h, a.w
+
+    @property
+    def data(self):
+        if self._cat is None:
+            self._cat = torch.cat(self.parts, dim=-1)  # channel concat == last-dim concat in token-major
+        return self._cat
+
+    @property
+    def c(self):
+        return self.parts[0].shape[-1] + self.parts[1].shape[-1]
 
 
 class PseudoConv3d(nn.Module):
@@ -93,13 +119,22 @@ class PseudoConv3d(nn.Module):
         Every spatial convolution of the UNet -- all pyramid levels, conv_in, conv_out, the 1x1 shortcuts -- runs through
         the hand-written implicit-GEMM kernel (fz_conv3x3 / fz_gemm); the elementwise tail (time embedding, residual)
         rides in the epilogue of the LAST linear op of the layer (the temporal conv when it is active)."""
-        w, bias, wtt, btt = self._pack(x.data.dtype, x.data.device)
-        n, hw, c = x.data.shape
+        probe = x.parts[0] if isinstance(x, CatTokens) and x._cat is None else x.data  # (do not materialise a lazy concatenation)
+        w, bias, wtt, btt = self._pack(probe.dtype, probe.device)
+        n, hw = probe.shape[0], probe.shape[1]
         lora = self.conv_temporal if isinstance(self.conv_temporal, LoRALinearLayer) else None
         plain_t = self.conv_temporal is not None and lora is None and wtt is not None
-        temporal_active = plain_t or (lora is not None and not lora.is_noop(x.data.dtype, x.data.device))
+        temporal_active = plain_t or (lora is not None and not lora.is_noop(probe.dtype, probe.device))
         fuse_tail = not temporal_active  # the elementwise tail commutes with nothing but the last linear op
-        if self.kernel_size == 1:
+        if self.kernel_size == 1 and isinstance(x, CatTokens) and x._cat is None and residual is None and temb is None \
+                and x.parts[0].shape[-1] % 8 == 0:
+            # 1x1 convolution of a lazy channel concatenation: W = [W1 | W2] along K, y = x1 W1^T + bias, then += x2 W2^T
+            # (the second GEMM takes the first one's output as its residual)
+            c1 = x.parts[0].shape[-1]
+            y = K.gemm(x.parts[1], w[:, c1:], None, res=K.gemm(x.parts[0], w[:, :c1], bias))
+            oh, ow = x.h, x.w
+            fused = fuse_tail
+        elif self.kernel_size == 1:
             y = K.gemm(x.data, w, bias, res=residual if (fuse_tail and temb is None) else None)
             oh, ow = x.h, x.w
             fused = fuse_tail and temb is None
@@ -151,7 +186,8 @@ class _NormParams(nn.Module):
 
 
 def group_norm_tokens(norm: _NormParams, x: Tokens, *, span_frames: bool, silu: bool) -> Tokens:
-    g, b = norm.packed(x.data.device)
+    lazy = isinstance(x, CatTokens) and x._cat is None
+    g, b = norm.packed((x.parts[0] if lazy else x.data).device)
     shard = D.active_shard()
     if shard is not None and span_frames:
         # statistics span ALL frames of the clip, this rank holds x.f of them: exchange the Welford partials (a few KB)
@@ -161,8 +197,12 @@ def group_norm_tokens(norm: _NormParams, x: Tokens, *, span_frames: bool, silu: 
         allp = shard.all_gather_frames(part.view(n // x.f, x.f, *part.shape[1:]), tag="groupnorm").contiguous()
         y = K.groupnorm_apply(x.data, g, b, allp, span=x.f, groups=norm.num_groups, eps=norm.eps, silu=silu)
         return x.like(y)
+    if isinstance(x, CatTokens) and x._cat is None and x.parts[0].shape[-1] % 8 == 0 and x.parts[1].shape[-1] % 8 == 0:
+        y = K.groupnorm_cat(x.parts[0], x.parts[1], g, b, span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps,
+                            silu=silu)
+        return Tokens(y, x.b, x.f, x.h, x.w)
     y = K.groupnorm(x.data, g, b, span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps, silu=silu)
-    return x.like(y)
+    return Tokens(y, x.b, x.f, x.h, x.w)
 
 
 def upsample_nearest2x(x: Tokens) -> Tokens:

@@ -89,7 +89,7 @@ class UNetMidBlockPseudo3DCrossAttn(nn.Module):
 
 
 def _cat_skip(x: Tokens, skip: Tokens) -> Tokens:
-    return x.like(torch.cat([x.data, skip.data], dim=-1))  # channel concat == last-dim concat in token-major
+    return Tokens.cat(x, skip)  # lazy: the resnet reads the two halves in place (resnet.py: CatTokens)
 
 
 class CrossAttnUpBlockPseudo3D(nn.Module):

@@ -135,6 +135,13 @@ int fz_groupnorm_chunks(int tokens, int channels);
 int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
                  int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream);
 
+/* The same on torch.cat([x1, x2], channel) WITHOUT the concatenated copy: the skip connections of the up blocks
+ * (unet_3d_blocks.py:384-395 `hidden_states = torch.cat([hidden_states, res_hidden_states], dim=1)` feeding
+ * ResnetBlockPseudo3D.norm1, resnet.py:338).  x1: [n][tokens][channels1], x2: [n][tokens][channels2], y: [n][tokens][channels1 +
+ * channels2] = the normalised concatenation; gamma / beta over channels1 + channels2; channels1, channels2 % 8 == 0. */
+int fz_groupnorm_cat(const void* x1, int channels1, const void* x2, int channels2, void* y, const void* gamma, const void* beta,
+                     int n_frames, int span, int tokens, int groups, float eps, int silu, float* partial, void* stream);
+
 /* The two halves of fz_groupnorm for statistics that span frames living on several GPUs:
  *   fz_groupnorm_stats  writes this rank's Welford partials  partial[n_frames][G][chunks][3] = (count, mean, M2);
  *   (the caller all-gathers them over the ranks and orders them [stat_sets][frames_per_set][G][chunks][3])

@@ -403,6 +403,27 @@ def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_t
     return {"max_err": err}
 
 
+def case_groupnorm_cat(device, *, n, span, tokens, c1, c2, groups, silu=True, seed=0):
+    """fz_groupnorm_cat == fz_groupnorm on the materialised torch.cat([x1, x2], channel): same kernels, same arithmetic -> bit-equal;
+    and against torch's GroupNorm on the 5-D view (resnet.py:338 after unet_3d_blocks.py:384-395)."""
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(n, tokens, c1, generator=g).half().to(device)
+    x2 = (torch.randn(n, tokens, c2, generator=g) * 2 + 0.5).half().to(device)
+    gm = (1 + 0.2 * torch.randn(c1 + c2, generator=g)).half().to(device)
+    bt = (0.2 * torch.randn(c1 + c2, generator=g)).half().to(device)
+    y = K.groupnorm_cat(x1, x2, gm, bt, span=span, groups=groups, eps=1e-5, silu=silu)
+    xc = torch.cat([x1, x2], -1).contiguous()
+    assert torch.equal(y, K.groupnorm(xc, gm, bt, span=span, groups=groups, eps=1e-5, silu=silu))
+    xr = xc.float().cpu().reshape(n // span, span * tokens, c1 + c2).permute(0, 2, 1)
+    ref = F.group_norm(xr, groups, gm.float().cpu(), bt.float().cpu(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(n, tokens, c1 + c2)
+    err = float((y.float().cpu() - ref).abs().max())
+    assert err < 2e-2, err
+    return {"max_err": err}
+
+
 def case_temporal_conv3(device, *, batch, clip, tokens, cin, cout, with_res, seed=0, with_rows=False):
     """k=3 convolution over the frame axis (lora.py:31-54, resnet.py:42-55); with_rows: one row of cout values per batch element
     added to every output (the time embedding / the Conv1d bias riding in fz_temporal_conv3's `temb`)."""

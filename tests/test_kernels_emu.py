@@ -155,6 +155,12 @@ def test_gemm_pingpong_tile_counts(k):
     KC.case_gemm(DEV, rows=300, k=k, o=264, n_res=1, tile_cfg=244218)
 
 
+def test_groupnorm_of_a_lazy_concatenation():
+    KC.case_groupnorm_cat(DEV, n=4, span=2, tokens=50, c1=64, c2=32, groups=8)
+    KC.case_groupnorm_cat(DEV, n=2, span=2, tokens=33, c1=320, c2=640, groups=32)   # groups straddle the seam (30 channels each)
+    KC.case_groupnorm_cat(DEV, n=2, span=1, tokens=20, c1=24, c2=40, groups=8, silu=False)
+
+
 @pytest.mark.parametrize("dma", ["late", "early"])
 def test_igemm_trial_forms(dma, monkeypatch):
     """Trial forms of the ping-pong loop (-DFZ_IGEMM_TRIALS builds only: FZ_EMU_LIB=build_tmp/libemu_trials.so from scripts/emu_variant.sh),

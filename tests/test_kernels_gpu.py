@@ -112,6 +112,13 @@ def test_groupnorm(span, c, groups, tokens):
     KC.case_groupnorm(DEV, n=span, span=span, tokens=tokens, c=c, groups=groups, silu=False, eps=1e-6)
 
 
+@pytest.mark.parametrize("n,span,tokens,c1,c2", [(16, 8, 4096, 320, 320), (8, 8, 4096, 320, 640), (16, 8, 1024, 640, 1280),
+                                                 (8, 8, 256, 1280, 1280), (16, 8, 64, 1280, 1280), (2, 1, 100, 24, 40)])
+def test_groupnorm_of_a_lazy_concatenation(n, span, tokens, c1, c2):
+    # the up blocks' torch.cat([x, skip]) -> GroupNorm without the concatenated copy; real SD-1.x up-path shapes
+    print(KC.case_groupnorm_cat(DEV, n=n, span=span, tokens=tokens, c1=c1, c2=c2, groups=32 if c1 >= 320 else 8))
+
+
 def test_layernorm_geglu_transpose_latent():
     KC.case_layernorm(DEV, rows=4099, c=320)
     KC.case_layernorm(DEV, rows=513, c=1280)

@@ -23,6 +23,14 @@ def test_pipeline_small(name):
     PC.check(res)
 
 
+def test_unet_tiny16_conv1d_reference_golden_emu():
+    # configs WITHOUT a `lora` key: the plain nn.Conv1d temporal convolution (resnet.py:42-55) with non-identity recorded weights,
+    # on fz_temporal_conv3 (MFMA form for the wide layers, the direct kernel for conv_out's 4 channels)
+    r = PC.run_unet_golden("unet_tiny16_conv1d", "cpu")
+    print(r)
+    assert r["err"] <= 1.5e-2 * r["scale"], r
+
+
 def test_unet_tiny40_reference_golden_emu():
     # head dims 40 / 80 / 160 (the log2-folded flash path) on a vector recorded from the unmodified reference UNet
     r = PC.run_unet_golden("unet_tiny40_default", "cpu")
