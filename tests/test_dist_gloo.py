@@ -196,6 +196,11 @@ def test_frame_shard_exchanges_three_ranks_ragged():
     _spawn(3, 7, [-1, "first"], False)   # 3 + 2 + 2 frames: a middle rank with two neighbours, ragged all-gather
 
 
+def test_frame_shard_exchanges_one_frame_per_rank():
+    # 8 GPUs x 8 frames in bench.py's probe: a two-frame halo then comes from TWO ranks on each side
+    _spawn(4, 4, [-1, "first"], False)
+
+
 @pytest.mark.parametrize("frames,index_list", [(4, ["mid", 1]), (5, [-1, "first"])])  # 5 frames: ragged 3 + 2 split
 def test_frame_sharded_clip_matches_single_process(frames, index_list):
     got, n_maps, n_local, stats = _spawn(2, frames, index_list, True)
