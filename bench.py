@@ -329,6 +329,10 @@ def main():
     ap.add_argument("--cpu-k", type=int, default=1, help="DDIM steps of each kind in the CPU-oracle sample (after one warm-up step)")
     ap.add_argument("--cpu-cfg1", action="store_true",
                     help="also run BASELINE cfg1 (8 f x 256^2 x 10 steps) IN FULL on the CPU oracle (minutes of host time) -> cpu_baseline.cfg1_full")
+    ap.add_argument("--cfg1", action="store_true",
+                    help="BASELINE configs[0] instead of the judged cfg2: config/low_resource_teaser (8 f x 256^2, 10 DDIM steps, model config "
+                         "{lora 160, SparseCausalAttention_index ['mid'], least_sc_channel 640}, Refine + Reweight x10, no blend) -- the case "
+                         "--cpu-cfg1 measures in full on the CPU")
     ap.add_argument("--n-edit", type=int, default=1, choices=[1, 2],
                     help="edits per inversion in the timed jobs: 1 = the primary metric (SURVEY 8d); 2 = both prompts of the config")
     ap.add_argument("--no-n-edit2-probe", action="store_true",
@@ -367,7 +371,17 @@ def main():
     timer.extra = False
     install_timers(K, timer)
 
-    pipe = build_pipeline(device, seed=0)
+    model_config = None
+    if args.cfg1:
+        global SRC_PROMPT, TGT_PROMPT, EDIT_KW
+        args.latent_size, args.ddim_steps, args.no_n_edit2_probe = 32, 10, True
+        model_config = {"lora": 160, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 640}
+        SRC_PROMPT = "a silver jeep driving down a curvy road in the countryside"
+        TGT_PROMPT = "watercolor painting of a silver jeep driving down a curvy road in the countryside"
+        EDIT_KW = dict(cross_replace_steps={"default_": 0.8}, self_replace_steps=0.8, use_inversion_attention=True,
+                       is_replace_controller=False, eq_params={"words": ["watercolor"], "values": [10]}, save_self_attention=False,
+                       guidance_scale=7.5)
+    pipe = build_pipeline(device, seed=0, model_config=model_config)
     by_frames = args.shard == "frames" and world > 1
     auto_frames = args.shard == "auto" and world > 1 and args.frames >= 2 * world  # the judged single clip: frames are the natural axis
     g = torch.Generator().manual_seed(1234 + (0 if by_frames else rank))  # frame-sharded: every rank holds the same clip
@@ -441,16 +455,18 @@ def main():
         value = (1 if by_frames else world) * args.frames * args.n_edit * args.steps / dt
         roof, others = rooflines(timer.summary())
         px = 8 * L
-        judged = args.frames == 8 and L == 64 and args.ddim_steps == 50
+        judged = args.frames == 8 and L == 64 and args.ddim_steps == 50 and not args.cfg1
         line = {"metric": "edited frames/sec (8f x 512^2 x 50 DDIM steps: capture inversion + 1 CFG edit, latents in/out)" if judged else
                           f"edited frames/sec ({args.frames}f x {px}^2 x {args.ddim_steps} DDIM steps: capture inversion + 1 CFG edit, latents in/out)",
                 "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if by_frames else "weak",
                 "vs_baseline": None,
                 "dtype": "fp16", "data": "synthetic",
-                "config": {"workload": f"config/teaser/jeep_posche.yaml shape: {args.frames} x {px}x{px} (latents {args.frames}x{L}x{L}x4), "
+                "config": {"workload": ("config/low_resource_teaser (BASELINE configs[0]) shape: " if args.cfg1 else "config/teaser/jeep_posche.yaml shape: ") +
+                                       f"{args.frames} x {px}x{px} (latents {args.frames}x{L}x{L}x4), "
                                        f"{args.ddim_steps}-step DDIM inversion with HBM map capture + {args.ddim_steps}-step "
-                                       "CFG edit (Replace, blend-masked self-attention), SD-1.x pseudo-3D UNet lora=160, "
+                                       + ("CFG edit (Refine + Reweight x10, index ['mid'], least_sc_channel 640), " if args.cfg1 else
+                                          "CFG edit (Replace, blend-masked self-attention), ") + "SD-1.x pseudo-3D UNet lora=160, "
                                        "random-init weights",
                            "frames": args.frames, "ddim_steps": args.ddim_steps, "n_edit": args.n_edit,
                            "parallelism": ("single GPU" if world == 1 else

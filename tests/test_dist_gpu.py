@@ -1,0 +1,103 @@
+"""Frame-sharded pipeline on the REAL kernels: two ranks that share the one MI355X of the test box (gloo carries the exchanges
+through host memory -- RCCL refuses two ranks on one device, and gloo moves host tensors only, so the test routes the two exchange
+primitives through `.cpu()` copies; everything else is the product path), each holding half of the clip's frames; the assembled result
+must match the single-process run on the same GPU.  What this adds to tests/test_dist_gloo.py (CPU emulation) and
+test_frame_shard_kernel_forms (single kernels): the sharded forms of the HIP kernels -- extended K/V frame axis, GroupNorm from
+gathered partials, temporal attention against gathered K|V, the recomputed temporal-conv halo -- inside an assembled UNet over an
+inversion + edit, with the posted / waited exchange handles on device tensors."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _job(frames, index_list, device):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pipeline_cases as PC
+    from fatezero_amd.synthetic import WordTokenizer
+    from fatezero_amd.video_diffusion.pipelines.p2p_ddim_spatial_temporal import P2pDDIMSpatioTemporalPipeline
+    from fatezero_amd.video_diffusion.schedulers import DDIMScheduler
+    unet = PC.build_unet("tiny16", {"lora": 16, "SparseCausalAttention_index": index_list}, device)
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=WordTokenizer(), unet=unet, scheduler=DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(7)
+    emb = torch.randn(2, 77, 64, generator=g).to(device)
+    pipe._encode_prompt = lambda *a, **k: emb
+    z0 = torch.randn(1, 4, frames, 16, 16, generator=g).to(device)
+
+    def job():
+        pipe.scheduler.set_timesteps(2)
+        pipe.store_controller = type(pipe.store_controller)()
+        lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1, text_embeddings=emb,
+                                                 store_attention=True, LOW_RESOURCE=True, latents=z0)
+        out = pipe(prompt="a red car", source_prompt="a blue car", edit_type="swap", num_inference_steps=2,
+                   latents=lat[-1], output_type="latent", cross_replace_steps={"default_": 0.5}, self_replace_steps=0.5,
+                   use_inversion_attention=True, is_replace_controller=True, save_self_attention=False, guidance_scale=3.0)
+        return torch.stack([lat[-1].float().cpu(), out["sdimage_output"].images.float().cpu()])
+    return pipe, job
+
+
+class _ViaHost:
+    """A dist.Pending whose payload travelled as a host tensor (gloo) and comes back on the device."""
+
+    def __init__(self, pend, device):
+        self.pend, self.device = pend, device
+
+    def wait(self):
+        return self.pend.wait().to(self.device)
+
+
+def _route_exchanges_through_host(D):
+    ag, ff = D.FrameShard.all_gather_frames_async, D.FrameShard.fetch_frames_async
+    D.FrameShard.all_gather_frames_async = lambda self, x, tag="other": _ViaHost(ag(self, x.cpu(), tag), x.device)
+    D.FrameShard.fetch_frames_async = lambda self, x, wanted, zero_outside=False, tag="other": _ViaHost(
+        ff(self, x.cpu(), wanted, zero_outside=zero_outside, tag=tag), x.device)
+
+
+def _worker(rank, world, port, frames, index_list, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fatezero_amd import _native, dist as D
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _route_exchanges_through_host(D)
+    pipe, job = _job(frames, index_list, "cuda")
+    assert D.weights_agree(pipe.unet, "cpu")
+    pipe.frame_shard = D.FrameShard(frames)
+    res = job()
+    assert _native.loaded_path().endswith("libfatezero_hip.so")
+    if rank == 0:
+        q.put((res, dict(pipe.frame_shard.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("frames,index_list", [(4, [-1, "first"]), (5, ["mid", 1])])  # 5 frames: ragged 3 + 2 split
+def test_frame_sharded_clip_on_the_hip_kernels_matches_single_process(frames, index_list):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, frames, index_list, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, stats = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    _, job = _job(frames, index_list, "cuda")
+    ref = job()
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max())
+    print("frame-sharded on HIP kernels", frames, index_list, {"err": err, "scale": scale, "exchanges": stats})
+    assert torch.isfinite(got).all() and err <= 1.5e-2 * scale, (err, scale)
+    by = stats["by_tag"]
+    assert by["kv"]["blocking"] == 0 and by["temporal_attn"]["blocking"] == 0 and by["kv"]["overlapped"] > 0, stats
