@@ -199,11 +199,13 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
             boff[i] = (uint32_t)(((br - b0) * g.ldb + bsc[i] * 8) * 2);
             bn[i] = boy[i] = box[i] = 0;
         } else {
-            const int hw = g.Ho * g.Wo;
-            bn[i] = (int)(br / hw);
-            const int rem = (int)(br - (int64_t)bn[i] * hw);
-            boy[i] = rem / g.Wo;
-            box[i] = rem - boy[i] * g.Wo;
+            // (pixel rows of a convolution launch fit 31 bits -- checked by conv_common --: unsigned 32-bit divisions, a third of the
+            // instructions of the 64-bit one, in the set-up every lane of every conv / temporal-conv launch runs)
+            const uint32_t hw = (uint32_t)(g.Ho * g.Wo), br32 = (uint32_t)br;
+            bn[i] = (int)(br32 / hw);
+            const uint32_t rem = br32 - (uint32_t)bn[i] * hw;
+            boy[i] = (int)(rem / (uint32_t)g.Wo);
+            box[i] = (int)(rem - (uint32_t)boy[i] * (uint32_t)g.Wo);
             bptr[i] = zero;
             if (KORD) {
                 const int cy = boy[i] * g.stride, cx = box[i] * g.stride;  // centre tap (always inside the image)
@@ -1287,7 +1289,7 @@ static int conv_common(IgArgs& g, const void* x, const void* wt, const void* bia
     g.y = (half_t*)y;
     g.ldy = g.ldres = cout;
     g.Nb = (int64_t)g.N * g.Ho * g.Wo;
-    return FZ_OK;
+    return g.Nb < (1ll << 31) ? FZ_OK : FZ_ERR_UNSUPPORTED;
 }
 
 // Temporal k=3 convolution with fewer than 8 channels on a side: conv_out's rank-2 LoRA pair (4 -> 2 -> 4, lora.py:26-28 caps the
@@ -1335,7 +1337,7 @@ extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res,
     IgArgs g = {};
     g.taps = 3;
     g.N = n; g.Hi = 1; g.Wi = tokens; g.Ho = 1; g.Wo = tokens; g.stride = 1; g.upsample = 0; g.fpb = clip_len;
-    conv_common(g, x, wt, nullptr, temb, temb_stride, res, res2, y, cin, cout);
+    if (conv_common(g, x, wt, nullptr, temb, temb_stride, res, res2, y, cin, cout) != FZ_OK) return FZ_ERR_UNSUPPORTED;
     if (cin % 8 || cout < 8) {  // conv_out's 4 / 2-channel temporal convolutions: direct VALU kernel
         if (cin > 8 || cout > 8 || cin <= 0 || cout <= 0) return FZ_ERR_UNSUPPORTED;
         const int64_t total = (int64_t)n * tokens;
@@ -1358,7 +1360,7 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
     const int hu = upsample ? 2 * hi : hi, wu = upsample ? 2 * wi : wi;
     g.Ho = (hu + 2 - 3) / stride + 1;
     g.Wo = (wu + 2 - 3) / stride + 1;
-    conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout);
+    if (conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout) != FZ_OK) return FZ_ERR_UNSUPPORTED;
     if (cin % 8) {  // conv_in (4 input channels): direct VALU convolution
         if (cout % 8 || upsample || cin != 4 || (int64_t)9 * cin * cout * 2 > 64 * 1024 || (temb && g.temb_stride % 8))
             return FZ_ERR_UNSUPPORTED;
