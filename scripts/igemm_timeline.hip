@@ -58,7 +58,7 @@ static int launch(const Problem& p, int cfg, void* ws, int64_t ws_floats) {
 int main(int argc, char** argv) {
     std::vector<int> cfgs;
     for (int i = 1; i < argc; ++i)
-        if (strcmp(argv[i], "prod")) cfgs.push_back(atoi(argv[i]));
+        if (strcmp(argv[i], "prod") && strcmp(argv[i], "gemmsweep")) cfgs.push_back(atoi(argv[i]));
     if (cfgs.empty()) cfgs = {254222, 254218, 1254218, 3254218, 5254218, 244222, 244218, 1244218};
     std::vector<Problem> probs;
     auto add_conv = [&](const char* name, int n, int hw, int cin, int cout) {
@@ -112,6 +112,16 @@ int main(int argc, char** argv) {
                 hipMalloc(&p.y, (size_t)n * c[0] * c[2] * 2);
                 probs.push_back(p);
             }
+        }
+    } else if (argc > 1 && !strcmp(argv[1], "gemmsweep")) {  // the long-K / GEGLU shapes on which hipBLASLt is ahead (profiles/r03_kbench_gemm.json)
+        char nm[64];
+        const int gs[][4] = {{8192, 2560, 640, 0}, {16384, 2560, 640, 0}, {2048, 1280, 2560, 0}, {2048, 1280, 3840, 0}, {4096, 1280, 2560, 0},
+                             {4096, 1280, 3840, 0}, {2048, 5120, 1280, 0}, {4096, 5120, 1280, 0}, {1024, 5120, 1280, 0}, {8192, 640, 5120, 1},
+                             {16384, 640, 5120, 1}, {2048, 1280, 10240, 1}, {4096, 1280, 10240, 1}, {512, 1280, 10240, 1}};
+        for (auto& c : gs) {
+            snprintf(nm, 64, "gemm%s %6d x %4d -> %5d", c[3] ? " geglu" : "      ", c[0], c[1], c[2]);
+            add_gemm(nm, c[0], c[1], c[2]);
+            probs.back().geglu = c[3] != 0;
         }
     } else {
     add_conv("conv 16f 64^2 320->320 ", 16, 64, 320, 320);
