@@ -32,6 +32,7 @@
 // v1 form) instead of inside the MFMA cluster before it
 #ifdef FZ_IGEMM_TRIALS
 __attribute__((weak)) int fz_igemm_trial_no_pp = 0;
+__attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute under split-K as well when a K slice has at least this many K-64 steps
 #endif
 #define FZ_PP_ON 1
 #define FZ_PP_NOPRIO 2
@@ -1141,10 +1142,18 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         // way), no ragged K, not the LayerNorm-fused form.  +2 ... +7 % on the 16-frame 64^2 convs, +4 ... +16 % on the GEGLU and long-K
         // projections.  The 320 x 128 / 160 x 256 tiles (one B-side MFMA tile per wave: five MFMAs per phase against six fragment
         // reads) measured 3-7 % SLOWER in ping-pong form and stay on the ring loop.
-#ifdef FZ_IGEMM_TRIALS
-        if (!fz_igemm_trial_no_pp)  // scripts/igemm_timeline.hip: A/B of the library's own choice with / without the substitution
+        // (under split-K only when a K slice keeps >= 16 K-64 steps: +1.5 ... +5 % on the 1920 / 2560-wide 16^2 and 32^2 convs,
+        //  profiles/r03_igemm_prod_pp_under_splitk.txt; the 8^2 convs with their 5-11-step slices lost 35 %)
+        const int64_t k64_per_slice = (int64_t)g.taps * g.Cin / 64 / ksplit;
+        bool pp_ok = g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr && (int64_t)g.taps * g.Cin >= 640 &&
+                     (ksplit == 1 || k64_per_slice >= 16);
+#ifdef FZ_IGEMM_TRIALS  // scripts/igemm_timeline.hip: A/B of the library's own choice with / without the substitution, and under split-K
+        if (fz_igemm_trial_pp_splitk_min > 0 && ksplit > 1 && g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr &&
+            (int64_t)g.taps * g.Cin / 64 / ksplit >= fz_igemm_trial_pp_splitk_min)
+            pp_ok = true;
+        if (fz_igemm_trial_no_pp) pp_ok = false;
 #endif
-        if (g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr && ksplit == 1 && (int64_t)g.taps * g.Cin >= 640) {
+        if (pp_ok) {
             if (cfg == 254222) cfg = 254218;
             if (cfg == 244222) cfg = 244218;
         }

@@ -37,8 +37,9 @@ struct Problem {
 };
 
 static int launch(const Problem& p, int cfg, void* ws, int64_t ws_floats) {
-    if (cfg < 0) {  // the library's own choice: -1 = ring tiles only, -2 = with the ping-pong substitution
-        fz_igemm_trial_no_pp = cfg == -1;
+    if (cfg < 0) {  // the library's own choice: -1 = ring tiles only, -2 = with the ping-pong substitution, -N (N >= 4) = also under
+        fz_igemm_trial_no_pp = cfg == -1;                      // split-K when a K slice has at least N K-64 steps
+        fz_igemm_trial_pp_splitk_min = cfg <= -4 ? -cfg : 0;
         cfg = 0;
     }
     if (p.temporal)
@@ -59,7 +60,8 @@ int main(int argc, char** argv) {
     std::vector<int> cfgs;
     for (int i = 1; i < argc; ++i)
         if (strcmp(argv[i], "prod") && strcmp(argv[i], "gemmsweep")) cfgs.push_back(atoi(argv[i]));
-    if (cfgs.empty()) cfgs = {254222, 254218, 1254218, 3254218, 5254218, 244222, 244218, 1244218};
+    const bool named = argc > 1 && (!strcmp(argv[1], "prod") || !strcmp(argv[1], "gemmsweep"));
+    if (cfgs.empty() && !named) cfgs = {254222, 254218, 1254218, 3254218, 5254218, 244222, 244218, 1244218};
     std::vector<Problem> probs;
     auto add_conv = [&](const char* name, int n, int hw, int cin, int cout) {
         Problem p = {};
@@ -83,7 +85,7 @@ int main(int argc, char** argv) {
     };
     const bool prod = argc > 1 && !strcmp(argv[1], "prod");
     if (prod) {  // every conv / GEMM / temporal-conv shape of the 8-frame inversion and the 16-frame edit forward (SD-1.x at 512^2)
-        cfgs = {-1, -2};
+        if (cfgs.empty()) cfgs = {-1, -2};
         char nm[64];
         for (int n : {8, 16}) {
             const int cs[][3] = {{64, 320, 320}, {64, 640, 320}, {64, 960, 320}, {32, 320, 640}, {32, 640, 640}, {32, 960, 640}, {32, 1280, 640},
