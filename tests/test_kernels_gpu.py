@@ -103,6 +103,14 @@ def test_temporal():
     KC.case_attn_temporal(DEV, batch=1, clip=16, heads=8, d=80, tokens=1024)
     KC.case_attn_temporal(DEV, batch=2, clip=8, heads=8, d=160, tokens=256)
     KC.case_attn_temporal(DEV, batch=1, clip=8, heads=8, d=40, tokens=4096)
+    # BASELINE cfg4 / cfg5 clip lengths: register-resident forms for 24 and 32 frames (one token of a 32-frame clip per workgroup at
+    # 320 channels = 40 KB of K | V; at 1280 channels 160 KB: the whole LDS) and a clip length without one (generic paths)
+    KC.case_attn_temporal(DEV, batch=2, clip=32, heads=8, d=40, tokens=5184)
+    KC.case_attn_temporal(DEV, batch=1, clip=24, heads=8, d=40, tokens=4096)
+    KC.case_attn_temporal(DEV, batch=1, clip=32, heads=8, d=80, tokens=1296)
+    KC.case_attn_temporal(DEV, batch=1, clip=32, heads=8, d=160, tokens=324)
+    KC.case_attn_temporal(DEV, batch=1, clip=24, heads=8, d=160, tokens=81)
+    KC.case_attn_temporal(DEV, batch=1, clip=20, heads=8, d=40, tokens=300)
 
 
 @pytest.mark.parametrize("span,c,groups,tokens", [(8, 320, 32, 4096), (1, 640, 32, 1024), (4, 2560, 32, 64),
