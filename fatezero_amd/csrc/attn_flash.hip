@@ -63,10 +63,28 @@ FZ_DEVICE int fl_pi(int i) {
     return ((a & 2) << 3) + 8 * hp + 4 * (a & 1) + t;
 }
 
+// Source frame of kv slot j for clip frame f of batch element b (attention.py:383-386: relative slots clamp into the clip).
+FZ_HOST_DEVICE inline int fl_kv_source(const FzAttnSelfDesc& d, int b, int f, int j) {
+    const int kvl = d.kv_clip_len ? d.kv_clip_len : d.clip_len;  // frames per batch element of k / vt
+    int s = d.kv_abs[j] ? d.kv_val[j] : f + (d.kv_clip_len ? d.kv_frame_off : 0) + d.kv_val[j];
+    s = s < 0 ? 0 : (s > kvl - 1 ? kvl - 1 : s);
+    return b * kvl + s;
+}
+
+// Dispatch order of the frames of a launch.  A frame whose kv slots ALL resolve to one source frame after clamping (frames 0 and 1
+// of a clip with [-1, 'first']: both slots are frame 0) reads that source once -- the softmax over a key set listed n times, against
+// values listed n times, is the softmax over the set listed once (not so when only SOME slots coincide: [0, 1, 1] weighs frame 1
+// twice) -- so its workgroups run 1/n as long; the launcher lists the full-length frames first so that the short ones fill the
+// last round instead of opening a new one.
+struct FlashOrder {
+    int heads_per_xcd;  // > 0: every XCD owns whole heads and walks the frames in `fl` order; 0: plain group order
+    unsigned char fl[64];
+};
+
 template <int D, int W, int QB, bool USE_BIAS, int NSTG>
 FZ_KERNEL void __launch_bounds__(256, W)
 attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* __restrict__ k,
-                  const half_t* __restrict__ vt, half_t* __restrict__ o) {
+                  const half_t* __restrict__ vt, half_t* __restrict__ o, FlashOrder ord) {
     typedef FlashCfg<D, QB, NSTG> C;
     static_assert(NSTG == 2 || NSTG == 4, "K/V ring of 2 stages (barrier per tile) or 4 (barrier per pair of tiles)");
     static_assert(C::LDS_HALVES * 2 <= 160 * 1024 / W, "LDS per workgroup at W workgroups per CU");
@@ -75,19 +93,27 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq_ = lane & 31, hi = lane >> 5;
     const int nq = (d.lq + C::QROWS - 1) / C::QROWS;
     const int groups = d.heads * d.n_frames;
-    int group, qt;
+    int h, fl, qt;
     {
         const int bid = blockIdx.x;
         if ((groups & 7) == 0) {
-            const int xcd = bid & 7, idx = bid >> 3;
-            group = xcd * (groups >> 3) + idx / nq;
+            const int xcd = bid & 7, idx = bid >> 3, lg = idx / nq;  // lg: this XCD's lg-th (head, frame) group
             qt = idx % nq;
+            if (ord.heads_per_xcd > 0) {
+                h = xcd * ord.heads_per_xcd + lg % ord.heads_per_xcd;
+                fl = ord.fl[lg / ord.heads_per_xcd];
+            } else {
+                const int group = xcd * (groups >> 3) + lg;
+                h = group / d.n_frames;
+                fl = group % d.n_frames;
+            }
         } else {
-            group = bid / nq;
+            const int group = bid / nq;
             qt = bid % nq;
+            h = group / d.n_frames;
+            fl = group % d.n_frames;
         }
     }
-    const int h = group / d.n_frames, fl = group % d.n_frames;
     const int n = d.frame0 + fl, b = n / d.clip_len, f = n % d.clip_len;
     constexpr bool BIAS = C::BIAS_SLOT && USE_BIAS;
     // Padded keys (last tile of a kv slot whose length is not a multiple of 64).  With the bias slot AND the ones row the
@@ -111,17 +137,18 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
                            : fz_zero_h8();
         }
     }
+    // source frames of the kv slots (wave-uniform scalars); when ALL slots resolve to one frame the keys are read once
     int src[FZ_MAX_KV_SLOTS];
+    bool one_source = true;
 #pragma unroll
     for (int j = 0; j < FZ_MAX_KV_SLOTS; ++j) {
-        const int kvl = d.kv_clip_len ? d.kv_clip_len : d.clip_len;  // frames per batch element of k / vt
-        int s = d.kv_abs[j] ? d.kv_val[j] : f + (d.kv_clip_len ? d.kv_frame_off : 0) + d.kv_val[j];
-        s = s < 0 ? 0 : (s > kvl - 1 ? kvl - 1 : s);
-        src[j] = b * kvl + s;
+        src[j] = fl_kv_source(d, b, f, j);
+        one_source = one_source && (j >= d.n_kv || src[j] == src[0]);
     }
+    const int nkv = one_source ? 1 : d.n_kv;
     const int lkfp = (d.lkf + FKVBLK - 1) / FKVBLK * FKVBLK;
     const int tps = lkfp / FKVBLK;
-    const int ntiles = d.n_kv * tps;
+    const int ntiles = nkv * tps;
     const int64_t khs = d.k_head_stride ? d.k_head_stride : (int64_t)D;
 
     // ---- constant parts of the K / V^T stages, written once: the padding chunks of every K row (zeros; slot D = 1.0 when
@@ -440,9 +467,22 @@ static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, c
     // 32-bit per-lane byte offsets inside one (frame, head) K / V^T panel
     if (d.k_row_stride >= (1 << 22) || (int64_t)D * d.vt_chan_stride >= (1ll << 30)) return FZ_ERR_UNSUPPORTED;
     const int nq = (d.lq + 128 * QB - 1) / (128 * QB);
+    FlashOrder ord = {};
+    const int groups = d.heads * d.n_frames;
+    if ((groups & 7) == 0 && (groups >> 3) % d.n_frames == 0 && d.n_frames <= 64) {
+        ord.heads_per_xcd = (groups >> 3) / d.n_frames;
+        int pos = 0;
+        for (int pass = 0; pass < 2; ++pass)  // full-length frames first, the single-source ones after them
+            for (int fl = 0; fl < d.n_frames; ++fl) {
+                const int n = d.frame0 + fl, b = n / d.clip_len, f = n % d.clip_len;
+                bool one_source = d.n_kv > 1;
+                for (int j = 1; j < d.n_kv; ++j) one_source = one_source && fl_kv_source(d, b, f, j) == fl_kv_source(d, b, f, 0);
+                if (one_source == (pass == 1)) ord.fl[pos++] = (unsigned char)fl;
+            }
+    }
     dim3 grid(nq * d.heads * d.n_frames), block(256);
     FZ_LAUNCH((attn_flash_kernel<D, W, QB, USE_BIAS, NSTG>), grid, block, 0, stream, d, (const half_t*)q, (const half_t*)k,
-              (const half_t*)vt, (half_t*)o);
+              (const half_t*)vt, (half_t*)o, ord);
     return fz_last_launch_status();
 }
 

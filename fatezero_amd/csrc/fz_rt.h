@@ -32,6 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FZ_KERNEL __global__
 #define FZ_DEVICE __device__ __forceinline__
+#define FZ_HOST_DEVICE __host__ __device__
 #define FZ_SHARED __shared__
 #define FZ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 
@@ -159,6 +160,7 @@ f32x16 mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c);        // one wave-wid
 
 #define FZ_KERNEL
 #define FZ_DEVICE static inline
+#define FZ_HOST_DEVICE static
 #define FZ_SHARED static thread_local
 #define FZ_DYN_SMEM(name) unsigned char* name = fz_emu::t_dyn_smem
 #define __launch_bounds__(...)

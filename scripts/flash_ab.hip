@@ -1,5 +1,5 @@
 // flash_ab.hip -- within-process A/B of attn_flash_kernel variants on the 64x64 SD level (d = 40, Lq 4096, Lk 8192,
-// 8 and 16 frames x 8 heads), interleaved rounds, uniform random [-1.5, 1.5) operands, outputs cross-checked.
+// 8 and 16 frames x 8 heads), interleaved rounds, TF/s priced at the full 4 Lq (2 Lkf) C per frame whatever the kernel skips, uniform random [-1.5, 1.5) operands, outputs cross-checked.
 // Tuning tool, never part of the library (the product's variant choice lives in fz_attn_flash_dispatch).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffast-math -fno-finite-math-only -w -o build_tmp/flash_ab scripts/flash_ab.hip
 #define FZ_FLASH_NO_DISPATCH 1
@@ -19,18 +19,23 @@ typedef int (*LaunchFn)(const FzAttnSelfDesc&, const void*, const void*, const v
 struct Variant {
     const char* name;
     LaunchFn fn;
+    bool distinct;  // kv slots [-1, 'last'] instead of [-1, 'first']: no frame has coinciding slots (every frame reads 2 x Lkf keys)
 };
 
 int main(int argc, char** argv) {
     const int only = argc > 1 ? atoi(argv[1]) : -1;  // PMC runs: one variant, 8 frames, a few launches
     const Variant vars[] = {
 #ifdef FLASH_AB_OLD
-        {"r02 v1 kernel (commit 13e2b00) <40,W2,QB2,bias>     ", launch_flash_old<40, 2, 2>},
+        {"r02 v1 kernel (commit 13e2b00) <40,W2,QB2,bias>     ", launch_flash_old<40, 2, 2>, false},
 #endif
-        {"ring2 (barrier per tile)      <40,W2,QB2,bias,2>", launch_flash<40, 2, 2, true, 2>},
-        {"ring4 (barrier per two tiles) <40,W2,QB2,bias,4>", launch_flash<40, 2, 2, true, 4>},
-        {"ring2 QB1 W4                  <40,W4,QB1,bias,2>", launch_flash<40, 4, 1, true, 2>},
-        {"no bias slot ring2            <40,W2,QB2,fma ,2>", launch_flash<40, 2, 2, false, 2>},
+        {"ring2 [-1,first]: frames 0,1 single-source <40,W2,QB2>", launch_flash<40, 2, 2, true, 2>, false},
+        {"ring2 [-1,last ]: all frames two sources   <40,W2,QB2>", launch_flash<40, 2, 2, true, 2>, true},
+        {"QB1 W4 [-1,first]                          <40,W4,QB1>", launch_flash<40, 4, 1, true, 2>, false},
+        {"QB1 W4 [-1,last ]                          <40,W4,QB1>", launch_flash<40, 4, 1, true, 2>, true},
+#ifdef FLASH_AB_ALL
+        {"ring4 (barrier per two tiles) <40,W2,QB2,bias,4>", launch_flash<40, 2, 2, true, 4>, false},
+        {"no bias slot ring2            <40,W2,QB2,fma ,2>", launch_flash<40, 2, 2, false, 2>, false},
+#endif
     };
     const int NV = sizeof(vars) / sizeof(vars[0]);
     const int H = 8, L = 4096, D = 40, C = H * D;
@@ -66,7 +71,9 @@ int main(int argc, char** argv) {
             for (int v = 0; v < NV; ++v) {
                 if (only >= 0 && (v != only || r > 1)) { ms[v].push_back(1.0f); continue; }
                 hipEventRecord(e0);
-                for (int i = 0; i < REP; ++i) vars[v].fn(d, qk, qk + C, vt, o[v], nullptr);
+                FzAttnSelfDesc dv = d;
+                if (vars[v].distinct) dv.kv_val[1] = d.clip_len - 1;
+                for (int i = 0; i < REP; ++i) vars[v].fn(dv, qk, qk + C, vt, o[v], nullptr);
                 hipEventRecord(e1);
                 hipDeviceSynchronize();
                 float t; hipEventElapsedTime(&t, e0, e1);
@@ -84,7 +91,7 @@ int main(int argc, char** argv) {
                 maxa = std::max(maxa, (double)fabsf((float)ref[i]));
             }
             const double med = ms[v][ms[v].size() / 2], mn = ms[v][0];
-            printf("F=%2d %-52s median %.4f ms %7.1f TF/s | min %.4f ms %7.1f TF/s | max|o - o[0]| %.2e (max|o| %.3f)\n", F,
+            printf("F=%2d %-56s median %.4f ms %7.1f TF/s | min %.4f ms %7.1f TF/s | max|o - o[0]| %.2e (max|o| %.3f)\n", F,
                    vars[v].name, med, flops / med / 1e9, mn, flops / mn / 1e9, maxd, maxa);
         }
         hipFree(qk); hipFree(vt);

@@ -40,7 +40,15 @@ def test_self_flash_log2_folded_q(lq, qk_scale, shape):
     print("flash folded", lq, qk_scale, shape, r)
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("batch,clip,heads,lq,index_list", [(2, 3, 8, 64, [-1, "first"]), (1, 3, 16, 100, [-1, "first"]),
+                                                             (2, 4, 8, 64, [-1, "first", "first"]), (1, 8, 8, 64, [-1, "first"])])
+def test_self_flash_coinciding_kv_slots(batch, clip, heads, lq, index_list):
+    # frames 0 and 1 of a clip see frame 0 in both slots: the kernel reads each distinct source once (same softmax), and -- when every
+    # XCD owns whole heads (8 | heads) -- the launcher dispatches the full-length frames first; the oracle lists the keys twice
+    KC.case_attn_self(DEV, batch=batch, clip=clip, heads=heads, d=40, lq=lq, index_list=index_list, mode=K.FZ_ATTN_FLASH, fold=True)
+    KC.case_attn_self(DEV, batch=batch, clip=clip, heads=heads, d=80, lq=lq, index_list=index_list, mode=K.FZ_ATTN_FLASH)
+
+
 @pytest.mark.parametrize("lq,index_list,shape", [(576, ["mid"], "ramp"), (600, ["mid"], None), (640, [-1, "mid", 1], "ramp")])
 def test_self_flash_pair_ring_odd_tiles(lq, index_list, shape):
     # the d=40 log2-domain variant meets at a barrier every SECOND 64-key tile (4-stage K/V ring): odd tile counts (9, 10
