@@ -250,7 +250,17 @@ def install_timers(K, timer):
         nf = kw.get("n_frames") or q.shape[0]
         if mode == K.FZ_ATTN_FLASH:
             if q.shape[1] == 4096 and q.shape[2] == 320:
-                return ("flash", nf, max(1, len(kw["index_list"])))
+                # kv slots the kernel actually contracts: a frame whose slots all resolve to ONE source frame reads it once
+                # (csrc/attn_flash.hip); the algorithmic figure prices every slot, as the reference computes it
+                n_kv, clip, f0 = max(1, len(kw["index_list"])), kw["clip_len"], kw.get("frame0", 0)
+                read = nf * n_kv
+                if kw.get("kv_slots_override") is None and not kw.get("kv_clip_len") and len(kw["index_list"]) > 1:
+                    kabs, kval = K.kv_slots(kw["index_list"], clip)
+                    read = 0
+                    for n in range(f0, f0 + nf):
+                        src = {v if a else min(max(n % clip + v, 0), clip - 1) for a, v in zip(kabs, kval)}
+                        read += 1 if len(src) == 1 else n_kv
+                return ("flash", nf, n_kv, read)
             return None
         if not timer.extra:
             return None
@@ -285,10 +295,11 @@ def rooflines(summ):
     roof, others = None, []
     fl = {k: v for k, v in summ.items() if k[0] == "flash"}
     if fl:
-        flops_total, ms_total, launches, frames_total = 0.0, 0.0, 0, 0
-        for (tag, nf, n_kv), v in fl.items():
+        flops_total, flops_read, ms_total, launches, frames_total = 0.0, 0.0, 0.0, 0, 0
+        for (tag, nf, n_kv, read), v in fl.items():
             frames_total += nf * v["launches"]
             flops_total += 4.0 * 4096 * (n_kv * 4096) * 320 * nf * v["launches"]  # 4*Lq*Lk*C per frame
+            flops_read += 4.0 * 4096 * 4096 * 320 * read * v["launches"]
             ms_total += v["total_ms"]
             launches += v["launches"]
         achieved = flops_total / (ms_total * 1e-3) / 1e12
@@ -296,7 +307,11 @@ def rooflines(summ):
         roof = {"kernel": "attn_flash_kernel<40> (64x64 level, Lq 4096, Lk 8192, d 40)", "bound": "mfma",
                 "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "launches": launches,
-                "avg_launch_ms": ms_total / launches, "algorithmic_flops_per_launch": flops_total / launches}
+                "avg_launch_ms": ms_total / launches, "algorithmic_flops_per_launch": flops_total / launches,
+                # frames 0 and 1 of a clip see frame 0 in both [-1, 'first'] slots and read it once (the same softmax): the rate over
+                # the key tiles the kernel really contracts, beside the algorithmic one SURVEY section 8(d) defines
+                "contracted_fraction": flops_read / flops_total,
+                "achieved_over_contracted_tiles": achieved * flops_read / flops_total}
     for name, kernel, bound, peak, unit, scale in (
             ("conv3x3", "igemm_kernel<.., MODE 1> (all 3x3 convolutions, 2*9*Cin*Cout FLOP per output pixel)", "mfma", 2500.0, "TFLOP/s", 1e12),
             ("gemm", "igemm_kernel<.., MODE 0> (projection GEMMs with >= 1024 rows, 2*K*N FLOP per row)", "mfma", 2500.0, "TFLOP/s", 1e12),

@@ -106,6 +106,12 @@ struct IgCfg {
     static constexpr int STAGE = A_HALVES + B_HALVES;
     static constexpr int LDS_HALVES = NS * STAGE;
     static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS ring exceeds 160 KB");
+    // (trial builds only) waves per SIMD the register allocation must leave room for: one workgroup per CU (the launch bound's own
+    // implication) unless the tile is an 8-wave one whose ring fits the LDS twice and whose accumulators fit a 128-register wave -- then
+    // TWO workgroups share a CU, and one's epilogue (VALU, stores) runs under the other's K loop.  Measured on the epilogue-dominated
+    // short-K projections (profiles/r03_igemm_shortk_two_wg_per_cu.txt): 128 x 256 gains 5-10 % on the K = 320 / 640 GEGLU at 8-16
+    // frames and loses 10-40 % on every plain projection; 256 x 128, 128 x 128 and 320 x 128 lose everywhere.  Not shipped.
+    static constexpr int WAVES_PER_SIMD = (NW == 8 && LDS_HALVES * 2 * 2 <= 160 * 1024 && TA * TB * 16 <= 80) ? 4 : NW / 4;
     static_assert((NS - 2) * PER < 64 && NS >= 2, "ring depth");
     static constexpr int CW = GEGLU ? BA / 2 : BA;  // output columns of the tile
     static constexpr int CSTR = CW + 8;
@@ -126,7 +132,11 @@ struct IgCfg {
 // LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
 // instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
 template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0>
+#ifdef FZ_IGEMM_TRIALS
+FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::WAVES_PER_SIMD)) igemm_kernel(IgArgs g) {
+#else
 FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
+#endif
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
@@ -1037,6 +1047,15 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
             }
         }
 #ifdef FZ_IGEMM_TRIALS  // trial forms: tile id + 1000000 * n
+        if constexpr (MODE == 0) {  // two workgroups per CU (K step 32, 2-deep ring, <= 80 accumulator registers)
+            switch (cfg) {
+                case 244112: return ig_launch<2, 4, 4, 1, 32, 2, MODE, GEGLU, false>(g, batch, stream);  // 256 x 128
+                case 224212: return ig_launch<2, 2, 4, 2, 32, 2, MODE, GEGLU, false>(g, batch, stream);  // 128 x 256
+                case 224112: return ig_launch<2, 2, 4, 1, 32, 2, MODE, GEGLU, false>(g, batch, stream);  // 128 x 128
+                default: break;
+            }
+            if (!GEGLU && cfg == 254112) return ig_launch<2, 5, 4, 1, 32, 2, MODE, false, false>(g, batch, stream);  // 320 x 128
+        }
         if (!GEGLU && MODE != 2) {
             constexpr int P = FZ_PP_ON | FZ_PP_PREP_IN_R;
             switch (cfg) {

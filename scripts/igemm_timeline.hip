@@ -59,8 +59,8 @@ static int launch(const Problem& p, int cfg, void* ws, int64_t ws_floats) {
 int main(int argc, char** argv) {
     std::vector<int> cfgs;
     for (int i = 1; i < argc; ++i)
-        if (strcmp(argv[i], "prod") && strcmp(argv[i], "gemmsweep")) cfgs.push_back(atoi(argv[i]));
-    const bool named = argc > 1 && (!strcmp(argv[1], "prod") || !strcmp(argv[1], "gemmsweep"));
+        if (strcmp(argv[i], "prod") && strcmp(argv[i], "gemmsweep") && strcmp(argv[i], "shortk")) cfgs.push_back(atoi(argv[i]));
+    const bool named = argc > 1 && (!strcmp(argv[1], "prod") || !strcmp(argv[1], "gemmsweep") || !strcmp(argv[1], "shortk"));
     if (cfgs.empty() && !named) cfgs = {254222, 254218, 1254218, 3254218, 5254218, 244222, 244218, 1244218};
     std::vector<Problem> probs;
     auto add_conv = [&](const char* name, int n, int hw, int cin, int cout) {
@@ -113,6 +113,18 @@ int main(int argc, char** argv) {
                 p.b = nullptr;
                 hipMalloc(&p.y, (size_t)n * c[0] * c[2] * 2);
                 probs.push_back(p);
+            }
+        }
+    } else if (argc > 1 && !strcmp(argv[1], "shortk")) {  // the epilogue-dominated projections: GEGLU and the K = 320 / 640 GEMMs of the 64^2 / 32^2 levels
+        char nm[64];
+        for (int n : {8, 16}) {
+            const int gs[][4] = {{4096, 320, 2560, 1}, {1024, 640, 5120, 1}, {256, 1280, 10240, 1}, {64, 1280, 10240, 1},
+                                 {4096, 320, 320, 0}, {4096, 320, 640, 0}, {4096, 320, 960, 0}, {4096, 1280, 320, 0},
+                                 {1024, 640, 640, 0}, {1024, 640, 1280, 0}, {1024, 640, 1920, 0}, {1024, 2560, 640, 0}};
+            for (auto& c : gs) {
+                snprintf(nm, 64, "gemm%s %6d x %4d -> %5d", c[3] ? " geglu" : "      ", n * c[0], c[1], c[2]);
+                add_gemm(nm, (int64_t)n * c[0], c[1], c[2]);
+                probs.back().geglu = c[3] != 0;
             }
         }
     } else if (argc > 1 && !strcmp(argv[1], "gemmsweep")) {  // the long-K / GEGLU shapes on which hipBLASLt is ahead (profiles/r03_kbench_gemm.json)

@@ -35,18 +35,47 @@ def test_spawned_ranks_see_world_size(tmp_path):
 
 
 def test_rooflines_bookkeeping():
-    summ = {("flash", 8, 2): {"launches": 10, "avg_ms": 0.5, "total_ms": 5.0},
-            ("flash", 16, 2): {"launches": 10, "avg_ms": 1.0, "total_ms": 10.0},
+    # 4th field: kv slots really contracted -- frames 0, 1 of every 8-frame clip read their single source frame once (14 of 16 slots)
+    summ = {("flash", 8, 2, 14): {"launches": 10, "avg_ms": 0.5, "total_ms": 5.0},
+            ("flash", 16, 2, 28): {"launches": 10, "avg_ms": 1.0, "total_ms": 10.0},
             ("conv3x3", 1e12, 0): {"launches": 4, "avg_ms": 1.0, "total_ms": 4.0},
             ("capture", 268435456, 0): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2}}
     roof, others = bench.rooflines(summ)
     flops = 4.0 * 4096 * 8192 * 320 * (8 + 16) * 10
     assert abs(roof["achieved"] - flops / 15e-3 / 1e12) < 1e-6 and roof["peak"] == 2500.0 and roof["bound"] == "mfma"
     assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-12 and roof["launches"] == 20
+    assert abs(roof["contracted_fraction"] - 0.875) < 1e-12
+    assert abs(roof["achieved_over_contracted_tiles"] - 0.875 * roof["achieved"]) < 1e-9
     byname = {o["kernel"].split(" ")[0]: o for o in others}
     assert abs(byname["igemm_kernel<..,"]["achieved"] - 1000.0) < 1e-6
     cap = [o for o in others if o["bound"] == "hbm"][0]
     assert abs(cap["achieved"] - 2 * 268435456 / 0.2e-3 / 1e9) < 1e-6 and cap["peak"] == 8000.0
+
+
+def test_flash_timer_counts_the_kv_slots_really_contracted(monkeypatch):
+    """The roofline's `contracted_fraction`: under [-1, 'first'] frames 0 and 1 of every clip resolve both slots to frame 0 and are
+    read once by the kernel (csrc/attn_flash.hip); ['mid'] and three-slot lists with a distinct member are read in full."""
+    import types
+    import torch
+    from fatezero_amd import kernels as K
+    tags = []
+
+    class T(bench.KernelTimer):
+        def wrap(self, module, fn_name, select):
+            if fn_name == "attn_self":
+                self.select = select
+    fake = types.SimpleNamespace(FZ_ATTN_FLASH=K.FZ_ATTN_FLASH, FZ_ATTN_CAPTURE=K.FZ_ATTN_CAPTURE, kv_slots=K.kv_slots,
+                                 attn_self=None, conv3x3=None, gemm=None)
+    t = T()
+    t.extra = False
+    bench.install_timers(fake, t)
+    q = torch.empty(16, 4096, 320, device="meta")
+    assert t.select(q, None, None, None, clip_len=8, heads=8, index_list=[-1, "first"], n_frames=16) == ("flash", 16, 2, 28)
+    assert t.select(q, None, None, None, clip_len=8, heads=8, index_list=[-1, "first"], frame0=8, n_frames=8) == ("flash", 8, 2, 14)
+    assert t.select(q, None, None, None, clip_len=8, heads=8, index_list=[-1, "first"], frame0=2, n_frames=6) == ("flash", 6, 2, 12)
+    assert t.select(q, None, None, None, clip_len=16, heads=8, index_list=["mid"], n_frames=16) == ("flash", 16, 1, 16)
+    assert t.select(q, None, None, None, clip_len=4, heads=8, index_list=[-1, "first", 1], n_frames=4) == ("flash", 4, 3, 12)
+    assert t.select(q, None, None, None, clip_len=4, heads=8, index_list=[-1, "first", "first"], n_frames=4) == ("flash", 4, 3, 8)
 
 
 def _run_bench_ranks(world, extra, timeout=600):
