@@ -149,6 +149,8 @@ def cpu_baseline(pipe, ddim_steps, frames, sample_frames=3, k=1):
     work as k = 2 at 2 frames -- `--cpu-k 2` runs the longer sample.  The reference's own modules cannot be timed here: neither
     /root/reference nor diffusers exists on the GPU box, hence kind = "port".)"""
     import platform
+    from oracle.host_cpu import cpu_budget, size_torch_pool
+    size_torch_pool()  # the box's cgroup CPU quota, not the 256 logical CPUs torch sees (oracle/host_cpu.py)
     from oracle import fatezero_oracle as O
     sd = {kk: v.float().cpu() for kk, v in pipe.unet.state_dict().items()}
     cfg = O.UNetConfig(block_out_channels=SD15["block_out_channels"], attention_head_dim=8, cross_attention_dim=768,
@@ -197,7 +199,7 @@ def cpu_baseline(pipe, ddim_steps, frames, sample_frames=3, k=1):
     except (OSError, StopIteration):
         pass
     return {"value": frames / job_s, "unit": "edited frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": cpu,
+            "cpu_model": cpu, "logical_cpus_visible": os.cpu_count(), "cpu_budget": cpu_budget(),
             "sample": f"after 1 warm-up step ({t_warm:.1f} s): {k} capture-inversion steps ({t_inv:.1f} s) + {k} CFG edit steps "
                       f"({t_edit:.1f} s) of a {sample_frames}-frame 512x512 clip, full-size SD-1.x pseudo-3D UNet fp32 "
                       f"(oracle/fatezero_oracle.py), same weights / controller; extrapolated x{ddim_steps}/{k} steps and "
@@ -208,6 +210,8 @@ def cpu_cfg1_full(pipe, frames=8, latent=32, steps=10):
     """cfg1 (config/low_resource_teaser, 8 frames x 256^2, 10 DDIM steps) measured IN FULL on the host cores
     -- no extrapolation: 10 capture-inversion steps + 10 CFG edit steps of the CPU oracle at full SD-1.x width, cfg1's model config
     ({lora 160, SparseCausalAttention_index ['mid'], least_sc_channel 640}) and controller (Refine + Reweight x10, no blend)."""
+    from oracle.host_cpu import size_torch_pool
+    size_torch_pool()
     from oracle import fatezero_oracle as O
     mc = {"lora": 160, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 640}
     sd = {kk: v.float().cpu() for kk, v in pipe.unet.state_dict().items()}

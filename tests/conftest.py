@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the CPU oracle must not run 128 threads against a 16-core cgroup quota (oracle/host_cpu.py)
+    from oracle.host_cpu import size_torch_pool
+    size_torch_pool()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
 
