@@ -4,7 +4,8 @@
 // ResnetBlockPseudo3D (resnet.py:338-339, :369, :384) and conv_norm_out (unet_3d_condition.py:439-440) the
 // statistics of one (batch, group) span ALL frames ("span" = F); inside SpatioTemporalTransformerModel
 // (attention.py:110) the input is 4-D [(b f),c,h,w] so they are per frame (span = 1).
-// Layout is x[n][token][C] fp16.  Three small HBM-bound kernels:
+// Layout is x[n][token][C] fp16.  Where a (stat set, group) fits the registers of one workgroup: ONE launch (gn_fused_kernel below).
+// Otherwise three small HBM-bound kernels:
 //   gn_stats    : per (frame, token chunk) Welford partials (n, mean, M2) for each group      (reads x once)
 //   gn_finalize : deterministic Chan merge of the partials of a span -> (mean, rstd) per (span, group)
 //   gn_apply    : y = silu?((x - mean) * rstd * gamma + beta)                          (reads x once, writes y)
@@ -241,6 +242,141 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// One-launch form for the small pyramid levels.  One workgroup per (stat set, group): the group's span x tokens x C/G
+// elements (<= GN_FUSED_MAX_PAIRS channel pairs: all of the 8^2 and 16^2 levels of an 8-frame clip, the 640-wide norms of the 32^2
+// level, every per-frame norm) are loaded ONCE into registers -- NE channel pairs per thread, every load in flight before the first
+// use --, then exact mean, exact sum of squared deviations, scale / shift per channel through LDS, normalise (+SiLU), store.
+// Below ~1 MB per tensor the three-kernel form is three launch latencies (stats 5-9 us + finalize 4.7 us + apply 5-10 us); this is one.
+// Reductions are in a fixed order (thread-serial, xor butterfly, wave results summed in wave order): bitwise reproducible.
+// ----------------------------------------------------------------------------------------------------------
+#define GN_FUSED_THREADS 1024
+#define GN_FUSED_MAX_NE 80
+#define GN_FUSED_MAX_PAIRS (GN_FUSED_THREADS * GN_FUSED_MAX_NE)
+
+FZ_DEVICE float gn_block_sum(float v, float* red, int tid) {  // red: GN_FUSED_THREADS / 64 floats of LDS
+#pragma unroll
+    for (int msk = 1; msk < 64; msk <<= 1) v += fz_shfl_xor(v, msk);
+    __syncthreads();  // the previous user of `red` is done
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < GN_FUSED_THREADS / 64; ++w) s += red[w];
+    return s;
+}
+
+template <int NE>
+FZ_KERNEL void __launch_bounds__(GN_FUSED_THREADS) gn_fused_kernel(GnArgs a) {
+    FZ_SHARED float red[GN_FUSED_THREADS / 64];
+    FZ_SHARED float gsc[128], gsh[128];  // per channel of the group: rstd * gamma, beta - mean * rstd * gamma  (C/G <= 128)
+    const int tid = threadIdx.x;
+    const int sp = (int)blockIdx.x / a.G, g = (int)blockIdx.x % a.G;
+    const int cg = a.C / a.G, P = cg >> 1;       // channel pairs per row of the group
+    const int total = a.span * a.tokens * P;     // channel pairs of the (set, group)
+    const int c0 = g * cg;
+    const int64_t row0 = (int64_t)sp * a.span * a.tokens;  // the set's frames are consecutive: its rows too
+    // two wave-uniform bases (x | the skip tensor of a lazy concatenation) + 32-bit element offsets; a group may straddle the seam
+    const uint32_t rs1 = (uint32_t)a.C1, rs2 = (uint32_t)(a.C - a.C1);
+    const half_t* const src1 = a.x + row0 * a.C1;
+    const half_t* const src2 = a.x2 != nullptr ? a.x2 + row0 * (a.C - a.C1) : src1;
+    half_t* const dst = a.y + row0 * a.C + c0;
+    // thread t owns pairs e = t + 1024 i: (row, pair) advance incrementally
+    const int drow = GN_FUSED_THREADS / P, dpr = GN_FUSED_THREADS - drow * P;
+    const int row = tid / P, pr = tid - row * P;
+    const int last_row = a.span * a.tokens - 1;
+    half2_t v[NE];
+    {
+        int r = row, q = pr;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {  // unconditional, clamped: all NE loads are in flight before the first use; issued in order, so
+            const int rr = r < last_row ? r : last_row;  // that one address register serves them all (hoisted, the 2 x NE address
+            const uint32_t ch = (uint32_t)(c0 + 2 * q);                                          // registers spilled)
+            const half_t* p = ch >= rs1 ? src2 + ((uint32_t)rr * rs2 + (ch - rs1)) : src1 + ((uint32_t)rr * rs1 + ch);
+            v[i] = *reinterpret_cast<const half2_t*>(p);
+            FZ_SCHED_FENCE();
+            r += drow;
+            q += dpr;
+            if (q >= P) { q -= P; ++r; }
+        }
+    }
+    const float cnt = (float)total * 2.0f;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (tid + GN_FUSED_THREADS * i < total) s += (float)v[i][0] + (float)v[i][1];
+    const float mean = gn_block_sum(s, red, tid) / cnt;
+    // (the packed halves stay THE copy of the data: without the pins the fp32 conversions of the first sweep are kept alive for the
+    // other two -- 2 x NE more registers, spilled)
+#pragma unroll
+    for (int i = 0; i < NE; ++i) FZ_PIN_V(v[i]);
+    s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (tid + GN_FUSED_THREADS * i < total) {
+            const float d0 = (float)v[i][0] - mean, d1 = (float)v[i][1] - mean;
+            s += d0 * d0 + d1 * d1;
+        }
+    const float var = gn_block_sum(s, red, tid) / cnt;  // biased, as torch.nn.GroupNorm
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) FZ_PIN_V(v[i]);
+    if (tid < cg) {
+        const float sc = rstd * (float)a.gamma[c0 + tid];
+        gsc[tid] = sc;
+        gsh[tid] = (float)a.beta[c0 + tid] - mean * sc;
+    }
+    __syncthreads();
+    {
+        int r = row, q = pr;
+        FZ_PIN_V(r);  // a fresh chain: otherwise the (row, pair) of every element is kept from the load loop -- 2 x NE registers
+        FZ_PIN_V(q);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (tid + GN_FUSED_THREADS * i < total) {
+                float f0 = (float)v[i][0] * gsc[2 * q] + gsh[2 * q];
+                float f1 = (float)v[i][1] * gsc[2 * q + 1] + gsh[2 * q + 1];
+                if (a.silu) {
+                    f0 = f0 / (1.0f + __builtin_expf(-f0));
+                    f1 = f1 / (1.0f + __builtin_expf(-f1));
+                }
+                half2_t o;
+                o[0] = (half_t)f0;
+                o[1] = (half_t)f1;
+                *reinterpret_cast<half2_t*>(dst + ((uint32_t)r * (uint32_t)a.C + 2u * (uint32_t)q)) = o;
+            }
+            FZ_SCHED_FENCE();
+            r += drow;
+            q += dpr;
+            if (q >= P) { q -= P; ++r; }
+        }
+    }
+}
+
+// the one-launch form when a (stat set, group) fits the registers of one workgroup; false: the caller runs the three-kernel form
+static bool gn_try_fused(const GnArgs& a, void* stream) {
+    const int cg = a.C / a.G;
+    if ((cg & 1) || cg > 128 || (a.C1 & 1)) return false;
+    const int64_t pairs = (int64_t)a.span * a.tokens * (cg / 2);
+    if (pairs > GN_FUSED_MAX_PAIRS || (int64_t)a.span * a.tokens * a.C >= (1ll << 31)) return false;  // 32-bit element offsets
+    const int ne = (int)((pairs + GN_FUSED_THREADS - 1) / GN_FUSED_THREADS);
+    const dim3 grid((a.n_frames / a.span) * a.G), block(GN_FUSED_THREADS);
+    if (ne <= 8) {
+        FZ_LAUNCH(gn_fused_kernel<8>, grid, block, 0, stream, a);
+    } else if (ne <= 16) {
+        FZ_LAUNCH(gn_fused_kernel<16>, grid, block, 0, stream, a);
+    } else if (ne <= 32) {
+        FZ_LAUNCH(gn_fused_kernel<32>, grid, block, 0, stream, a);
+    } else if (ne <= 48) {
+        FZ_LAUNCH(gn_fused_kernel<48>, grid, block, 0, stream, a);
+    } else if (ne <= 64) {
+        FZ_LAUNCH(gn_fused_kernel<64>, grid, block, 0, stream, a);
+    } else {
+        FZ_LAUNCH(gn_fused_kernel<GN_FUSED_MAX_NE>, grid, block, 0, stream, a);
+    }
+    return true;
+}
+
 static void gn_launch_stats(const GnArgs& a, dim3 grid, dim3 block, size_t smem, void* stream) {
     const int rows = (a.tb + a.R - 1) / a.R;  // rows of a chunk per thread
     if (rows > 32 || block.x > 512) {
@@ -283,6 +419,7 @@ extern "C" int fz_groupnorm(const void* x, void* y, const void* gamma, const voi
     a.eps = eps; a.silu = silu;
     a.partial = partial;
     a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
+    if (gn_try_fused(a, stream)) return fz_last_launch_status();
     dim3 grid(a.chunks, n_frames), block(threads);
     gn_launch_stats(a, grid, block, smem, stream);
     const int nst = (n_frames / span) * groups;
@@ -306,6 +443,7 @@ extern "C" int fz_groupnorm_cat(const void* x1, int channels1, const void* x2, i
     a.eps = eps; a.silu = silu;
     a.partial = partial;
     a.stats = partial + (int64_t)n_frames * a.chunks * groups * 3;
+    if (gn_try_fused(a, stream)) return fz_last_launch_status();
     dim3 grid(a.chunks, n_frames), block(threads);
     gn_launch_stats(a, grid, block, smem, stream);
     FZ_LAUNCH(gn_finalize_kernel, dim3((n_frames / span) * groups), dim3(64), 0, stream, a);

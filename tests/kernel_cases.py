@@ -234,7 +234,10 @@ def case_sharded_pieces(device, *, batch, clip, lo, hi, heads, d, tokens, groups
     part = K.groupnorm_stats(x, groups=groups)
     y_own = K.groupnorm_apply(own(x), gamma, beta, part.view(batch, clip, *part.shape[1:]).contiguous(), span=fl,
                               groups=groups, eps=1e-5, silu=True)
-    assert torch.equal(y_own, own(y_full)), "split GroupNorm must reproduce fz_groupnorm bit for bit"
+    # (fz_groupnorm runs its one-launch form where a group fits one workgroup -- exact two-sweep statistics instead of merged chunk
+    # partials: the same numbers to a rounding of the fp32 statistics, i.e. at most an fp16 ulp of the output here and there)
+    gn_err = float((y_own.float() - own(y_full).float()).abs().max())
+    assert gn_err <= 2e-3 * max(1.0, float(y_full.float().abs().max())), gn_err
     # -- sparse-causal attention, index [-1, 'first', +1]: halos of one frame on both sides + anchor frame 0 -----
     qk = _mk((batch * clip, tokens, 2 * c), g, device, 1.5)
     q, k = qk[..., :c], qk[..., c:]
