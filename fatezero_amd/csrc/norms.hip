@@ -243,15 +243,14 @@ FZ_KERNEL void gn_apply_kernel(GnArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// One-launch form for the small pyramid levels.  One workgroup per (stat set, group): the group's span x tokens x C/G
-// elements (<= GN_FUSED_MAX_PAIRS channel pairs: all of the 8^2 and 16^2 levels of an 8-frame clip, the 640-wide norms of the 32^2
-// level, every per-frame norm) are loaded ONCE into registers -- NE channel pairs per thread, every load in flight before the first
-// use --, then exact mean, exact sum of squared deviations, scale / shift per channel through LDS, normalise (+SiLU), store.
+// One-launch form for the small launches.  One workgroup per (stat set, group): the group's span x tokens x C/G elements
+// (<= GN_FUSED_MAX_PAIRS channel pairs) are loaded ONCE into registers -- NE channel pairs per thread, every load in flight before the
+// first use --, then exact mean, exact sum of squared deviations, scale / shift per channel through LDS, normalise (+SiLU), store.
 // Below ~1 MB per tensor the three-kernel form is three launch latencies (stats 5-9 us + finalize 4.7 us + apply 5-10 us); this is one.
 // Reductions are in a fixed order (thread-serial, xor butterfly, wave results summed in wave order): bitwise reproducible.
 // ----------------------------------------------------------------------------------------------------------
 #define GN_FUSED_THREADS 1024
-#define GN_FUSED_MAX_NE 80
+#define GN_FUSED_MAX_NE 20
 #define GN_FUSED_MAX_PAIRS (GN_FUSED_THREADS * GN_FUSED_MAX_NE)
 
 FZ_DEVICE float gn_block_sum(float v, float* red, int tid) {  // red: GN_FUSED_THREADS / 64 floats of LDS
@@ -353,24 +352,33 @@ FZ_KERNEL void __launch_bounds__(GN_FUSED_THREADS) gn_fused_kernel(GnArgs a) {
     }
 }
 
-// the one-launch form when a (stat set, group) fits the registers of one workgroup; false: the caller runs the three-kernel form
+// The one-launch form where it measured faster than the three kernels on MI355X (profiles/r03_gn_one_launch_vs_three.txt, GPU time from
+// the kernel trace): a workgroup's serial time grows with the pairs per thread (~0.55 us each: 2 + 5.5 us at 10, 25 us at 40, where the
+// three-kernel form takes 17-28 us whatever the shape), and many workgroups of it are VALU-bound where the three kernels are
+// bandwidth-bound.  Wins 1.3-2.7x: <= 20 pairs per thread and <= 2560 pairs-per-thread x workgroups -- the 8^2 level (both widths),
+// the per-frame transformer norms of the 16^2 level and of the 32^2 level at 8 frames.  false: the caller runs the three-kernel form.
 static bool gn_try_fused(const GnArgs& a, void* stream) {
     const int cg = a.C / a.G;
     if ((cg & 1) || cg > 128 || (a.C1 & 1)) return false;
     const int64_t pairs = (int64_t)a.span * a.tokens * (cg / 2);
     if (pairs > GN_FUSED_MAX_PAIRS || (int64_t)a.span * a.tokens * a.C >= (1ll << 31)) return false;  // 32-bit element offsets
     const int ne = (int)((pairs + GN_FUSED_THREADS - 1) / GN_FUSED_THREADS);
-    const dim3 grid((a.n_frames / a.span) * a.G), block(GN_FUSED_THREADS);
-    if (ne <= 8) {
+    const int wgs = (a.n_frames / a.span) * a.G;
+    if ((int64_t)ne * wgs > 2560) return false;
+    const dim3 grid(wgs), block(GN_FUSED_THREADS);
+    // (a masked iteration costs what a live one does: tight buckets)
+    if (ne <= 2) {
+        FZ_LAUNCH(gn_fused_kernel<2>, grid, block, 0, stream, a);
+    } else if (ne <= 4) {
+        FZ_LAUNCH(gn_fused_kernel<4>, grid, block, 0, stream, a);
+    } else if (ne <= 5) {
+        FZ_LAUNCH(gn_fused_kernel<5>, grid, block, 0, stream, a);
+    } else if (ne <= 8) {
         FZ_LAUNCH(gn_fused_kernel<8>, grid, block, 0, stream, a);
+    } else if (ne <= 10) {
+        FZ_LAUNCH(gn_fused_kernel<10>, grid, block, 0, stream, a);
     } else if (ne <= 16) {
         FZ_LAUNCH(gn_fused_kernel<16>, grid, block, 0, stream, a);
-    } else if (ne <= 32) {
-        FZ_LAUNCH(gn_fused_kernel<32>, grid, block, 0, stream, a);
-    } else if (ne <= 48) {
-        FZ_LAUNCH(gn_fused_kernel<48>, grid, block, 0, stream, a);
-    } else if (ne <= 64) {
-        FZ_LAUNCH(gn_fused_kernel<64>, grid, block, 0, stream, a);
     } else {
         FZ_LAUNCH(gn_fused_kernel<GN_FUSED_MAX_NE>, grid, block, 0, stream, a);
     }

@@ -127,23 +127,24 @@ def test_groupnorm(span, c, groups, tokens):
     KC.case_groupnorm(DEV, n=span * 2, span=span, tokens=tokens, c=c, groups=groups, silu=True)
     KC.case_groupnorm(DEV, n=span, span=span, tokens=tokens, c=c, groups=groups, silu=False, eps=1e-6)
 
-@pytest.mark.parametrize("span,tokens,c,sets", [(8, 64, 1280, 2), (8, 256, 640, 1), (8, 256, 1280, 1), (8, 256, 1920, 1), (8, 256, 2560, 2),
-                                                (8, 1024, 640, 1), (8, 1024, 320, 2), (1, 1024, 640, 3), (3, 37, 960, 1)])
+@pytest.mark.parametrize("span,tokens,c,sets", [(1, 64, 1280, 8), (1, 300, 640, 4), (1, 256, 1280, 16), (2, 256, 960, 2), (8, 64, 1280, 2),
+                                                (8, 100, 1280, 1), (8, 64, 2560, 2), (3, 37, 960, 1), (1, 1024, 640, 8)])
 def test_groupnorm_one_launch_form(span, tokens, c, sets):
-    # the levels whose (stat set, group) fits one workgroup (csrc/norms.hip gn_fused_kernel): every register bucket (8 ... 80 channel
-    # pairs per thread), the exact upper bound (8 x 256 x 2560 and 8 x 1024 x 640: 81 920 pairs), per-frame statistics, a ragged tail
+    # launches that take the one-launch form (csrc/norms.hip gn_fused_kernel: <= 20 channel pairs per thread, <= 2560 pairs-per-thread x
+    # workgroups): every register bucket (2, 4, 5, 8, 10, 16, 20), the rule's boundary (512 workgroups x 5; 256 x 10), a ragged tail
     KC.case_groupnorm(DEV, n=span * sets, span=span, tokens=tokens, c=c, groups=32, silu=True)
 
 
-def test_groupnorm_three_kernel_form_beyond_the_register_bound():
-    KC.case_groupnorm(DEV, n=8, span=8, tokens=1024, c=960, groups=32, silu=True)   # 122 880 pairs per group
-    KC.case_groupnorm_cat(DEV, n=4, span=4, tokens=1500, c1=320, c2=640, groups=32)  # 90 000 pairs, groups straddle the seam
+def test_groupnorm_three_kernel_form_beyond_the_rule():
+    KC.case_groupnorm(DEV, n=8, span=8, tokens=256, c=1280, groups=32, silu=True)    # 40 pairs per thread
+    KC.case_groupnorm(DEV, n=16, span=1, tokens=1024, c=640, groups=32, silu=True)   # 10 pairs per thread x 512 workgroups
+    KC.case_groupnorm_cat(DEV, n=4, span=4, tokens=1500, c1=320, c2=640, groups=32)  # 90 000 pairs per group, groups straddle the seam
 
 
 def test_groupnorm_one_launch_form_of_a_lazy_concatenation():
     KC.case_groupnorm_cat(DEV, n=8, span=8, tokens=64, c1=1280, c2=1280, groups=32)   # seam on a group boundary
     KC.case_groupnorm_cat(DEV, n=16, span=8, tokens=64, c1=1280, c2=640, groups=32)   # 60-channel groups: group 21 straddles the seam
-    KC.case_groupnorm_cat(DEV, n=8, span=8, tokens=256, c1=640, c2=320, groups=32)
+    KC.case_groupnorm_cat(DEV, n=4, span=1, tokens=256, c1=640, c2=320, groups=32)
 
 
 @pytest.mark.parametrize("n,span,tokens,c1,c2", [(16, 8, 4096, 320, 320), (8, 8, 4096, 320, 640), (16, 8, 1024, 640, 1280),
