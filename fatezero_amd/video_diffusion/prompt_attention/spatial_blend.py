@@ -151,6 +151,7 @@ class SpatialBlender:
         self.counter = 0
         self.th = th
         self.mask_list = []
+        self.applied_mask_list = []  # (extension) what blends the EDITED latents each step: mask[1:], the source mask OR-ed with the target one
         self._alpha_dev = {}
         self._cache = {}
         self._staged = {}
@@ -220,6 +221,7 @@ class SpatialBlender:
         if x_t is not None:
             m = mask[:, None, ...] if x_t.dim() == 5 else mask
             if (self.counter > self.start_blend) and (self.counter < self.end_blend):
+                self.applied_mask_list.append(mask[1:])
                 x_t = x_t[:1] + m * (x_t - x_t[:1])
             return x_t
         return mask

@@ -549,6 +549,7 @@ class Blender:
         self.prompt_choose = prompt_choose
         self.counter = 0
         self.mask_list: List[torch.Tensor] = []
+        self.applied_mask_list: List[torch.Tensor] = []  # test aid: the rows that blend the EDITED latents (mask[1:]) when they do
 
     def __call__(self, attention_store, target_h=None, target_w=None, x_t=None):
         if target_h is None and x_t is not None:
@@ -572,6 +573,7 @@ class Blender:
             if x_t.dim() == 5:
                 mask = mask[:, None]
             if self.start_blend < self.counter < self.end_blend:
+                self.applied_mask_list.append(mask[1:, 0] if mask.dim() == 5 else mask[1:])
                 x_t = x_t[:1] + mask * (x_t - x_t[:1])
             return x_t
         return mask
