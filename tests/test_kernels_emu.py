@@ -62,6 +62,11 @@ def test_self_flash_coinciding_kv_slots(batch, clip, heads, lq, index_list):
     KC.case_attn_self(DEV, batch=batch, clip=clip, heads=heads, d=80, lq=lq, index_list=index_list, mode=K.FZ_ATTN_FLASH)
 
 
+def test_self_flash_more_frames_than_the_dispatch_order_lists():
+    # 72 frames in one launch (9 clips of 8): beyond the 64 entries of the launcher's frame order -> plain group order, same results
+    KC.case_attn_self(DEV, batch=9, clip=8, heads=8, d=40, lq=32, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH, fold=True)
+
+
 def test_self_capture_and_inject_log2_folded_q():
     KC.case_attn_self(DEV, batch=1, clip=2, heads=2, d=40, lq=64, index_list=[-1, "first"], mode=K.FZ_ATTN_CAPTURE,
                       fold=True)
@@ -173,6 +178,13 @@ def test_groupnorm_one_launch_form(span, tokens, c, sets):
     # launches that take the one-launch form (csrc/norms.hip gn_fused_kernel: <= 20 channel pairs per thread, <= 2560 pairs-per-thread x
     # workgroups): every register bucket (2, 4, 5, 8, 10, 16, 20), the rule's boundary (512 workgroups x 5; 256 x 10), a ragged tail
     KC.case_groupnorm(DEV, n=span * sets, span=span, tokens=tokens, c=c, groups=32, silu=True)
+
+
+def test_groupnorm_one_launch_form_edges():
+    KC.case_groupnorm(DEV, n=2, span=2, tokens=50, c=16, groups=8, silu=True)       # 2 channels per group: one pair per row
+    KC.case_groupnorm(DEV, n=2, span=1, tokens=33, c=24, groups=8, silu=False)     # 3 channels per group (odd): three-kernel form
+    KC.case_groupnorm(DEV, n=4, span=2, tokens=7, c=2048, groups=16, silu=True)    # 128 channels per group: the LDS scale / shift bound
+    KC.case_groupnorm_cat(DEV, n=2, span=2, tokens=20, c1=24, c2=40, groups=8)     # 8-channel groups, seam on a group boundary
 
 
 def test_groupnorm_three_kernel_form_beyond_the_rule():
