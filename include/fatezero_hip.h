@@ -130,7 +130,11 @@ int fz_blend_mask(const void* const* maps, int n_maps, int n_prompts, int64_t pr
 /* GroupNorm (+SiLU) on token-major activations x[n][tokens][C] (resnet.py:338-339,369,384; attention.py:110;
  * unet_3d_condition.py:439-440).  span = number of consecutive frames sharing statistics: F for the 5-D
  * ResNet norms (stats over C/G x F x H x W), 1 for the per-frame transformer norm.
- * partial: float scratch, >= n_frames * fz_groupnorm_chunks(tokens, C) * G * 3. */
+ * partial: float scratch, >= n_frames * fz_groupnorm_chunks(tokens, C) * G * 3 + (n_frames / span) * G * 2.
+ * Small launches (a (stat set, group) of <= 20 channel pairs per thread of one 1024-thread workgroup, few workgroups) run as ONE kernel with
+ * exact two-sweep statistics; the others as statistics partials + merge + normalise.  The two forms agree to the rounding of the fp32
+ * statistics (an fp16 ulp of y here and there): fz_groupnorm_stats + fz_groupnorm_apply reproduce the three-kernel form bit for bit,
+ * fz_groupnorm as a whole to that rounding. */
 int fz_groupnorm_chunks(int tokens, int channels);
 int fz_groupnorm(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span,
                  int tokens, int channels, int groups, float eps, int silu, float* partial, void* stream);
