@@ -242,6 +242,20 @@ class _SB(SpatialBlender):
     def __init__(self, *a, **k):
         k["save_path"] = None
         super().__init__(*a, **k)
+        self._last_full_mask = None
+        self.applied_mask_list = []  # what the reference never keeps: the rows that blend the EDITED latents (mask[1:]) when they do
+
+    def get_mask(self, *a, **k):
+        m = super().get_mask(*a, **k)
+        self._last_full_mask = m.float().cpu().detach().clone()
+        return m
+
+    def __call__(self, *a, **k):
+        out = super().__call__(*a, **k)
+        x_t = k.get("x_t")
+        if x_t is not None and self.start_blend < self.counter < self.end_blend and self.substruct_layers is None:  # spatial_blend.py:117-120
+            self.applied_mask_list.append(self._last_full_mask[1:])
+        return out
 
 
 def synthetic_layer_calls(F_, heads, n_kv, g, batch, peaky=4.0):
@@ -436,6 +450,11 @@ def gen_pipeline(tok, only=None):
             ml = torch.stack(out["mask_list"]).bool()
             arrays["latent_mask_bits"] = np.packbits(ml.numpy(), axis=None)
             arrays["latent_mask_shape"] = np.array(ml.shape)
+        lb = getattr(stash["ctrl"], "latent_blend", None)
+        if lb is not None and getattr(lb, "applied_mask_list", None):
+            am = torch.stack(lb.applied_mask_list).bool()  # [blending steps, P - 1, F, h, w]
+            arrays["latent_applied_mask_bits"] = np.packbits(am.numpy(), axis=None)
+            arrays["latent_applied_mask_shape"] = np.array(am.shape)
         ab = stash["ctrl"].attention_blend
         ab_frac = None
         if ab is not None:  # attention-blend masks, in call order, grouped by resolution

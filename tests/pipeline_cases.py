@@ -174,6 +174,17 @@ def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_
         emap = (edited - ref).abs().amax(dim=(0, 1))                                       # [F, h, w]
         res["edit_positions_beyond_band"] = int((emap > EDIT_TOL_VS_REFERENCE * res["edit_scale"]).sum())
         res["edit_positions"] = emap.numel()
+        if "latent_applied_mask_bits" in gz:
+            # the reference's APPLIED masks, recorded by a subclass hook in oracle/gen_golden.py (the reference run itself is
+            # unchanged: every other array of the recording came out bit-identical): flips against them, and the max error away
+            # from the flipped pixels and their 3x3 neighbourhood (the next UNet step's convolutions spread a jump)
+            want_a = unpack_bits(gz["latent_applied_mask_bits"], gz["latent_applied_mask_shape"])
+            got_a = torch.stack([m.bool().cpu() for m in ctrl.latent_blend.applied_mask_list]).numpy()
+            assert got_a.shape == want_a.shape, (got_a.shape, want_a.shape)
+            res["applied_mask_flips"], res["applied_mask_flips_total"] = int((got_a != want_a).sum()), got_a.size
+            fl = torch.from_numpy(got_a != want_a).reshape(-1, *emap.shape).any(0)
+            near = torch.nn.functional.max_pool2d(fl[None].float(), 3, 1, 1)[0].bool()
+            res["edit_err_off_applied_flips"] = float(emap[~near].max())
     if mixed_oracle:
         o_edit, o_ctrl = oracle_edit_on_native_maps(meta, consts, gz, store, ReplayTokenizer())
         res["edit_err_vs_oracle_on_native_maps"] = float((edited - o_edit).abs().max())
@@ -222,6 +233,9 @@ def check(res):
     # the max: without masks every value is bounded; with masks single flipped pixels (counted and bounded below) may move
     if latent_blend:
         assert res["edit_positions_beyond_band"] <= MASK_FLIP_TOL * res["edit_positions"], res
+        if "applied_mask_flips" in res:
+            assert res["applied_mask_flips"] <= MASK_FLIP_TOL * res["applied_mask_flips_total"], res
+            assert res["edit_err_off_applied_flips"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
         assert res["edit_err"] <= 1.0 * res["edit_scale"], res  # a flipped pixel jumps by |x - inverted|: never more than the scale
     else:
         assert res["edit_err"] <= (EDIT_TOL_VS_REFERENCE if has_mask else EDIT_MAX_TOL) * res["edit_scale"], res
