@@ -186,3 +186,7 @@ def test_pipeline_matches_reference(tok, name):
         got = torch.stack(ctrl.latent_blend.mask_list).bool().numpy()
         want = unpack_bits(gz["latent_mask_bits"], gz["latent_mask_shape"])
         assert got.shape == want.shape and (got != want).sum() == 0
+        if "latent_applied_mask_bits" in gz:  # the rows that blend the edited latents (source mask OR live target mask), step by step
+            got_a = torch.stack(ctrl.latent_blend.applied_mask_list).bool().numpy()
+            want_a = unpack_bits(gz["latent_applied_mask_bits"], gz["latent_applied_mask_shape"])
+            assert got_a.shape == want_a.shape and (got_a != want_a).sum() == 0
