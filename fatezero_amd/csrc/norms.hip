@@ -352,6 +352,92 @@ FZ_KERNEL void __launch_bounds__(GN_FUSED_THREADS) gn_fused_kernel(GnArgs a) {
     }
 }
 
+#ifdef FZ_GN_TRIALS  // build_tmp variant (scripts/build_variant.sh ... -DFZ_GN_TRIALS): a second thread layout of the one-launch form
+// MEASURED (profiles/r03_gn_one_launch_layout2_trial.txt): 10-20 % faster than the shipped layout on the same shapes (7.6 vs 8.3 us, 11.3 vs
+// 13.2 us), same crossover against the three kernels (19 vs 16 us at 40 rows per thread): the one-launch form is bound by what ONE
+// workgroup can stream with 4-byte strided accesses (~10 GB/s), not by its instruction count.  Kept as a trial, not shipped.
+// Thread t owns ONE channel pair (q = t % P) of rows r0 + i R (r0 = t / P, R = 1024 / P rows per sweep): no per-element index
+// arithmetic (one 32-bit add per load / store), the pair's source tensor, scale and shift live in registers.
+template <int NE>
+FZ_KERNEL void __launch_bounds__(GN_FUSED_THREADS) gn_fused2_kernel(GnArgs a) {
+    FZ_SHARED float red[GN_FUSED_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int sp = (int)blockIdx.x / a.G, g = (int)blockIdx.x % a.G;
+    const int cg = a.C / a.G, P = cg >> 1;
+    const int R = GN_FUSED_THREADS / P;          // rows per sweep
+    const int rows = a.span * a.tokens;
+    const int r0 = tid / P, q = tid - r0 * P;
+    const bool active = r0 < R;                  // threads beyond R * P idle (they still meet the barriers)
+    const int ch = g * cg + 2 * q;               // this thread's channel pair, for all its rows
+    const int64_t row0 = (int64_t)sp * rows;
+    const bool second = ch >= a.C1;
+    const uint32_t rs = (uint32_t)(second ? a.C - a.C1 : a.C1);
+    const half_t* const src = second ? a.x2 + row0 * (a.C - a.C1) + (ch - a.C1) : a.x + row0 * a.C1 + ch;
+    half_t* const dst = a.y + row0 * a.C + ch;
+    const uint32_t step_in = (uint32_t)R * rs, step_out = (uint32_t)R * (uint32_t)a.C;
+    const int r_first = active ? r0 : 0;
+    half2_t v[NE];
+    {
+        uint32_t off = (uint32_t)r_first * rs;
+        const uint32_t off_max = (uint32_t)(rows - 1) * rs;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {  // all loads in flight before the first use, issued in order (one address register)
+            v[i] = *reinterpret_cast<const half2_t*>(src + (off < off_max ? off : off_max));
+            FZ_SCHED_FENCE();
+            off += step_in;
+        }
+    }
+    const int r_lim = active ? rows - r0 : 0;  // row i of this thread is inside the set iff i * R < r_lim
+    const float cnt = (float)rows * (float)cg;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (i * R < r_lim) s += (float)v[i][0] + (float)v[i][1];
+    const float mean = gn_block_sum(s, red, tid) / cnt;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) FZ_PIN_V(v[i]);
+    s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (i * R < r_lim) {
+            const float d0 = (float)v[i][0] - mean, d1 = (float)v[i][1] - mean;
+            s += d0 * d0 + d1 * d1;
+        }
+    const float var = gn_block_sum(s, red, tid) / cnt;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) FZ_PIN_V(v[i]);
+    const half2_t gm = *reinterpret_cast<const half2_t*>(a.gamma + ch), bt = *reinterpret_cast<const half2_t*>(a.beta + ch);
+    const float sc0 = rstd * (float)gm[0], sc1 = rstd * (float)gm[1];
+    const float sh0 = (float)bt[0] - mean * sc0, sh1 = (float)bt[1] - mean * sc1;
+    uint32_t off = (uint32_t)r_first * (uint32_t)a.C;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if (i * R < r_lim) {
+            float f0 = (float)v[i][0] * sc0 + sh0, f1 = (float)v[i][1] * sc1 + sh1;
+            if (a.silu) {
+                f0 = f0 / (1.0f + __builtin_expf(-f0));
+                f1 = f1 / (1.0f + __builtin_expf(-f1));
+            }
+            half2_t o;
+            o[0] = (half_t)f0;
+            o[1] = (half_t)f1;
+            *reinterpret_cast<half2_t*>(dst + off) = o;
+        }
+        FZ_SCHED_FENCE();
+        off += step_out;
+    }
+}
+
+template <int NE>
+static void gn_launch_fused2(const GnArgs& a, int ne, dim3 grid, void* stream) {
+    if constexpr (NE > 4) {
+        if (ne < NE) return gn_launch_fused2<NE - 4>(a, ne, grid, stream);
+    }
+    FZ_LAUNCH(gn_fused2_kernel<NE>, grid, dim3(GN_FUSED_THREADS), 0, stream, a);
+}
+#endif
+
 // The one-launch form where it measured faster than the three kernels on MI355X (profiles/r03_gn_one_launch_vs_three.txt, GPU time from
 // the kernel trace): a workgroup's serial time grows with the pairs per thread (~0.55 us each: 2 + 5.5 us at 10, 25 us at 40, where the
 // three-kernel form takes 17-28 us whatever the shape), and many workgroups of it are VALU-bound where the three kernels are
@@ -361,9 +447,21 @@ static bool gn_try_fused(const GnArgs& a, void* stream) {
     const int cg = a.C / a.G;
     if ((cg & 1) || cg > 128 || (a.C1 & 1)) return false;
     const int64_t pairs = (int64_t)a.span * a.tokens * (cg / 2);
-    if (pairs > GN_FUSED_MAX_PAIRS || (int64_t)a.span * a.tokens * a.C >= (1ll << 31)) return false;  // 32-bit element offsets
+#ifndef FZ_GN_TRIALS
+    if (pairs > GN_FUSED_MAX_PAIRS) return false;
+#endif
+    if ((int64_t)a.span * a.tokens * a.C >= (1ll << 31)) return false;  // 32-bit element offsets
     const int ne = (int)((pairs + GN_FUSED_THREADS - 1) / GN_FUSED_THREADS);
     const int wgs = (a.n_frames / a.span) * a.G;
+#ifdef FZ_GN_TRIALS  // the second layout on EVERY group that fits (no rule): scripts/gn_ab.py against the three-kernel form
+    {
+        const int P = cg / 2, R = GN_FUSED_THREADS / P, rows = a.span * a.tokens;
+        const int ne2 = (rows + R - 1) / R;  // rows per thread
+        if (ne2 > 84) return false;
+        gn_launch_fused2<84>(a, ne2 < 4 ? 4 : (ne2 + 3) / 4 * 4, dim3(wgs), stream);
+        return true;
+    }
+#endif
     if ((int64_t)ne * wgs > 2560) return false;
     const dim3 grid(wgs), block(GN_FUSED_THREADS);
     // (a masked iteration costs what a live one does: tight buckets)

@@ -16,6 +16,9 @@ REP = 10
 
 def run():
     import torch
+    from fatezero_amd import _native
+    if os.environ.get("FZ_VARIANT_LIB"):  # a trial build of the kernels (scripts/build_variant.sh), never the product's library
+        _native.HIP_LIB = os.environ["FZ_VARIANT_LIB"]
     from fatezero_amd import kernels as K
     dev = "cuda"
     marker = torch.empty(64, device=dev, dtype=torch.float64)  # its fill kernel (FillFunctor<double>) is the segment separator
