@@ -333,6 +333,25 @@ def rooflines(summ):
     return roof, others
 
 
+def promote_frame_sharded(line, fs, world):
+    """`--shard auto`, frames >= 2 x GPUs: the frame-sharded clip becomes the primary number (one clip, strong scaling) and the
+    one-clip-per-GPU measurement taken first stays in the line as `clips_dp` -- provided the sharded job completed, is finite, and the
+    N GPUs working on ONE clip are not slower than ONE GPU working on it (clips value / N): an exchange path that bad is reported
+    (`frame_sharded`, `frame_sharded_not_promoted`), not made the headline."""
+    if "error" in fs or not fs.get("outputs_finite"):
+        line["frame_sharded_not_promoted"] = "did not complete"
+        return False
+    if fs["value"] < line["value"] / world:
+        line["frame_sharded_not_promoted"] = (f"{world} GPUs on one clip ({fs['value']:.3f} frames/s) slower than one GPU on it "
+                                              f"({line['value'] / world:.3f} frames/s)")
+        return False
+    line["clips_dp"] = {k: line[k] for k in ("value", "ms_per_step", "scaling")}
+    line["clips_dp"]["parallelism"] = line["config"]["parallelism"]
+    line.update(value=fs["value"], ms_per_step=fs["ms_per_job"], scaling="strong")
+    line["config"]["parallelism"] = f"{world}-way frame-sharded clip"
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -543,13 +562,8 @@ def main():
             dog.cancel()
             if rank == 0:
                 line["frame_sharded"] = fs
-                if auto_frames and "error" not in fs and fs["outputs_finite"]:
-                    # frames >= 2 x GPUs: the frame-sharded clip is the primary number (one clip, strong scaling); the one-clip-per-GPU
-                    # measurement taken first stays in the line as `clips_dp`
-                    line["clips_dp"] = {k: line[k] for k in ("value", "ms_per_step", "scaling")}
-                    line["clips_dp"]["parallelism"] = line["config"]["parallelism"]
-                    line.update(value=fs["value"], ms_per_step=fs["ms_per_job"], scaling="strong")
-                    line["config"]["parallelism"] = f"{world}-way frame-sharded clip"
+                if auto_frames:
+                    promote_frame_sharded(line, fs, world)
         else:
             return
     if rank == 0:

@@ -113,10 +113,27 @@ def test_bench_main_two_ranks_auto_promotes_the_frame_sharded_clip():
     fs = line["frame_sharded"]
     assert "error" not in fs and fs["jobs_timed"] == 1 and fs["outputs_finite"] is True, fs
     assert line["scaling"] == "strong" and line["config"]["parallelism"] == "2-way frame-sharded clip"
-    assert line["value"] == fs["value"] and line["ms_per_step"] == fs["ms_per_job"]
+    assert line["value"] == fs["value"] and line["ms_per_step"] == fs["ms_per_job"] and "frame_sharded_not_promoted" not in line
     assert line["clips_dp"]["scaling"] == "weak" and line["clips_dp"]["parallelism"] == "dp2 over clips" and line["clips_dp"]["value"] > 0
     ex = fs["exchanges"]
     assert ex["overlapped_with_compute"] > 0 and ex["posted"] == ex["overlapped_with_compute"] + ex["blocking"], ex
+
+
+def test_frame_sharded_promotion_rule():
+    def mk():
+        return {"value": 6.8, "ms_per_step": 2350.0, "scaling": "weak", "config": {"parallelism": "dp2 over clips"}}
+    good = {"value": 4.7, "ms_per_job": 1700.0, "outputs_finite": True}
+    line = mk()
+    assert bench.promote_frame_sharded(line, good, 2) is True
+    assert line["value"] == 4.7 and line["ms_per_step"] == 1700.0 and line["scaling"] == "strong"
+    assert line["clips_dp"] == {"value": 6.8, "ms_per_step": 2350.0, "scaling": "weak", "parallelism": "dp2 over clips"}
+    assert line["config"]["parallelism"] == "2-way frame-sharded clip"
+    line = mk()  # two GPUs on one clip slower than one GPU on it: reported, not promoted
+    assert bench.promote_frame_sharded(line, {"value": 3.0, "ms_per_job": 2666.0, "outputs_finite": True}, 2) is False
+    assert line["value"] == 6.8 and line["scaling"] == "weak" and "slower than one GPU" in line["frame_sharded_not_promoted"]
+    for bad in ({"error": "x"}, {"value": 9.0, "ms_per_job": 1.0, "outputs_finite": False}):
+        line = mk()
+        assert bench.promote_frame_sharded(line, bad, 2) is False and line["value"] == 6.8 and "clips_dp" not in line
 
 
 def test_bench_main_two_ranks_frames_mode():
