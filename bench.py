@@ -379,7 +379,8 @@ def main():
                     help="N > 1: 'clips' = one clip per GPU (weak scaling, latents only on the wire); 'frames' = ONE clip's frames split "
                          "over the GPUs (strong scaling; GroupNorm / K-V / temporal exchanges over RCCL: SURVEY 8e's natural axis); 'auto' "
                          "(default) measures clips first, then the frame-sharded clip (K timed jobs under a watchdog), and reports the "
-                         "frame-sharded number as `value` when frames >= 2 x GPUs and it completed -- the other one rides beside it")
+                         "frame-sharded number as `value` when frames >= 2 x GPUs, it completed and was not slower than ONE GPU on the clip -- the "
+                         "other one rides beside it")
     ap.add_argument("--no-frame-shard-probe", action="store_true",
                     help="N > 1, --shard clips: skip the extra frame-sharded job reported under `frame_sharded` (it runs AFTER the clips "
                          "measurement is complete, under a 120 s watchdog that prints the clips line and exits if the exchange path stalls)")
