@@ -106,11 +106,12 @@ struct IgCfg {
     static constexpr int STAGE = A_HALVES + B_HALVES;
     static constexpr int LDS_HALVES = NS * STAGE;
     static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS ring exceeds 160 KB");
-    // (trial builds only) waves per SIMD the register allocation must leave room for: one workgroup per CU (the launch bound's own
-    // implication) unless the tile is an 8-wave one whose ring fits the LDS twice and whose accumulators fit a 128-register wave -- then
-    // TWO workgroups share a CU, and one's epilogue (VALU, stores) runs under the other's K loop.  Measured on the epilogue-dominated
-    // short-K projections (profiles/r03_igemm_shortk_two_wg_per_cu.txt): 128 x 256 gains 5-10 % on the K = 320 / 640 GEGLU at 8-16
-    // frames and loses 10-40 % on every plain projection; 256 x 128, 128 x 128 and 320 x 128 lose everywhere.  Not shipped.
+    // Waves per SIMD the register allocation must leave room for: what the launch bound implies by itself (one workgroup per CU; the
+    // explicit value leaves the code of those tiles bit for bit as it was) unless the tile is an 8-wave one whose ring fits the LDS twice
+    // and whose accumulators fit a 128-register wave -- then TWO workgroups share a CU, and one's epilogue (VALU, stores) runs under the
+    // other's K loop.  Measured on the epilogue-dominated short-K projections (profiles/r03_igemm_shortk_two_wg_per_cu.txt): 128 x 256
+    // gains 5-10 % on the K = 320 / 640 GEGLU launches (64 gelu per lane in the epilogue) and loses 10-40 % on every plain projection;
+    // 256 x 128, 128 x 128 and 320 x 128 lose everywhere.  Shipped for those GEGLU launches only (ig_run), the rest are trial ids.
     static constexpr int WAVES_PER_SIMD = (NW == 8 && LDS_HALVES * 2 * 2 <= 160 * 1024 && TA * TB * 16 <= 80) ? 4 : NW / 4;
     static_assert((NS - 2) * PER < 64 && NS >= 2, "ring depth");
     static constexpr int CW = GEGLU ? BA / 2 : BA;  // output columns of the tile
@@ -132,11 +133,7 @@ struct IgCfg {
 // LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
 // instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
 template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0>
-#ifdef FZ_IGEMM_TRIALS
 FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::WAVES_PER_SIMD)) igemm_kernel(IgArgs g) {
-#else
-FZ_KERNEL void __launch_bounds__(64 * WA * WB) igemm_kernel(IgArgs g) {
-#endif
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
@@ -1046,6 +1043,9 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
                 default: break;
             }
         }
+        if constexpr (MODE == 0 && GEGLU) {  // 128 x 256, K step 32, 2-deep ring: two workgroups per CU (the short-K GEGLU launches)
+            if (cfg == 224212) return ig_launch<2, 2, 4, 2, 32, 2, MODE, true, false>(g, batch, stream);
+        }
 #ifdef FZ_IGEMM_TRIALS  // trial forms: tile id + 1000000 * n
         if constexpr (MODE == 0) {  // two workgroups per CU (K step 32, 2-deep ring, <= 80 accumulator registers)
             switch (cfg) {
@@ -1176,6 +1176,12 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
             if (cfg == 254222) cfg = 254218;
             if (cfg == 244222) cfg = 244218;
         }
+        // GEGLU with a short K: the epilogue (64 gelu per lane) is longer than the K loop, and with one 8-wave workgroup per CU nothing
+        // runs under it.  The 128 x 256 tile fits a CU twice; same-process A/B on MI355X (profiles/r03_igemm_shortk_two_wg_per_cu.txt):
+        // 32768 / 65536 x 320 -> 2560: +6 / +10 %, 8192 x 640 -> 5120: +5 % (16384 rows: -2 %, K = 1280: -3 ... -20 %) -- exactly those.
+        if (GEGLU && MODE == 0 && g.ln_in == nullptr && g.st_out == nullptr && ksplit == 1 && cfg != 0 &&
+            ((g.Cin == 320 && g.Nb >= 32768) || (g.Cin == 640 && g.Nb >= 4096 && g.Nb <= 8192)))
+            cfg = 224212;
     }
     if (ksplit == 0) ksplit = 1;
     if (g.ln_in != nullptr) ksplit = 1;  // the LayerNorm correction lives in the GEMM's own epilogue

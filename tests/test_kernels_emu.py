@@ -229,10 +229,13 @@ def test_gemm_forms():
     KC.case_gemm(DEV, rows=2, k=1280, o=96)                                                 # time-embedding shaped
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 244222, 224223, 222222, 244218])
+@pytest.mark.parametrize("tile_cfg", [0, 244222, 224223, 222222, 244218, 224212])
 def test_gemm_geglu(tile_cfg):
+    # (224212: the 128 x 256 tile with K step 32 and a 2-deep ring -- two workgroups per CU -- that carries the short-K GEGLU launches)
     KC.case_gemm(DEV, rows=70, k=64, o=256, geglu=True, tile_cfg=tile_cfg)
     KC.case_gemm(DEV, rows=33, k=64 if tile_cfg % 100 == 18 else 40, o=128, geglu=True, bias=False, tile_cfg=tile_cfg)
+    if tile_cfg == 224212:
+        KC.case_gemm(DEV, rows=300, k=320, o=512, geglu=True, tile_cfg=tile_cfg)  # 10 K steps, ragged row tile, two column tiles
 
 
 def test_gemm_transposed_output():

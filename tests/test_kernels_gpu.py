@@ -212,10 +212,17 @@ def test_gemm_sd_shapes(rows, k, o, kw):
     print(rows, k, o, kw, r)
 
 
-@pytest.mark.parametrize("rows,k,o", [(32768, 320, 2560), (8192, 640, 5120), (2048, 1280, 10240), (300, 64, 256)])
+@pytest.mark.parametrize("rows,k,o", [(32768, 320, 2560), (65536, 320, 2560), (8192, 640, 5120), (4100, 640, 5120), (16384, 640, 5120),
+                                      (2048, 1280, 10240), (300, 64, 256)])
 def test_gemm_geglu(rows, k, o):
+    # (the first four take the 128 x 256 two-workgroups-per-CU tile by the library's rule, csrc/igemm.hip ig_run)
     r = KC.case_gemm(DEV, rows=rows, k=k, o=o, geglu=True)
     print(rows, k, o, r)
+
+
+def test_gemm_geglu_two_workgroups_per_cu_tile_forced():
+    KC.case_gemm(DEV, rows=3000, k=640, o=1024, geglu=True, tile_cfg=224212)
+    KC.case_gemm(DEV, rows=333, k=320, o=2560, geglu=True, bias=False, tile_cfg=224212)
 
 
 @pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218])
