@@ -1031,6 +1031,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
 //   158122: 160 x 256, 8 waves -- the rank-160 down projection of the temporal LoRA convolution (lora.py:31-37)
 //   244222: 256 x 256, 8 waves -- the GEGLU projection (8C = multiples of 256) and generic large shapes
 //   224223: 128 x 256, 8 waves, 3-deep;  222222: 128 x 128, 4 waves, two workgroups per CU
+//   224212: 128 x 256, 8 waves, K step 32, 2-deep: TWO workgroups per CU -- the short-K GEGLU launches (rule in ig_run)
 //   212222:  64 x 128, 4 waves, three workgroups per CU -- small launches and ragged widths
 template <int MODE, bool GEGLU, bool LN = false>
 static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
