@@ -101,11 +101,32 @@ def build_pipeline(device, seed=0, model_config=None):
     return pipe
 
 
+PMC_JOB_FILES = ("r04_pmc_job.json",)  # newest in-situ pass first
+
+
+def pmc_job_traffic():
+    """HBM traffic per kernel class from the IN-SITU counter passes over one bench job (scripts/pmc_job.sh: rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE in two separate runs of this very script, every dispatch of the job attributed to a class by kernel name --
+    and, for the projection GEMMs, by the launch log this script writes with FZ_BENCH_LAUNCHLOG set).  Counters cannot be read from
+    inside this process, so the committed summary under profiles/ is what the line quotes: bytes per launch, FETCH_SIZE doubled
+    (gfx950 tallies a 128-byte request as 64, MI355X_MICROARCH.md, HBM section), both counters in KiB."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in PMC_JOB_FILES:
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                return json.load(f), f"profiles/{name}"
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_traffic_per_launch(frames_per_launch):
-    """HBM bytes of the judged kernel per launch.  PMC counters cannot be read from inside this process; they come
-    from the separate rocprofv3 --pmc passes of scripts/pmc_flash.sh (same kernel, 8 frames per launch), whose
-    summary is committed under profiles/.  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request,
-    MI355X_MICROARCH.md, HBM section); both counters are KiB.  Scaled linearly to this run's frames per launch."""
+    """HBM bytes of the judged kernel per launch: the in-situ job pass when it exists (pmc_job_traffic), else the A/B-harness pass of
+    scripts/pmc_flash.sh (same kernel, 8 frames per launch, scaled linearly to this run's frames per launch)."""
+    job, src = pmc_job_traffic()
+    if job is not None and "flash" in job.get("classes", {}):
+        c = job["classes"]["flash"]
+        return c["traffic_bytes_per_launch"], f"{src} (in situ: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one bench job, {c['launches']} launches)"
     here = os.path.dirname(os.path.abspath(__file__))
     for name in ("r03_pmc_flash_d40_final2.json", "r03_pmc_flash_d40_final.json", "r02_pmc_flash_d40_final.json", "r01_pmc_flash_d40_final.json"):  # newest measurement of the shipped kernel first
         try:
@@ -270,7 +291,8 @@ def install_timers(K, timer):
             return None
         p = kw["p"]
         per_frame = p.shape[1] * p.shape[2] * p.shape[3] * 2  # bytes of the fp16 map of one frame
-        return ("capture" if mode == K.FZ_ATTN_CAPTURE else "inject", nf * per_frame, 0)
+        # algorithmic bytes of the launch = the map itself -- q / k / V^T / o are < 2 % of it
+        return ("capture" if mode == K.FZ_ATTN_CAPTURE else "inject", nf * per_frame, nf * per_frame)
     timer.wrap(K, "attn_self", sel_attn)
 
     def sel_conv(x, wt, bias, **kw):
@@ -279,19 +301,58 @@ def install_timers(K, timer):
         h, w = kw["hw"]
         st = kw.get("stride", 1)
         ho, wo = ((2 * h if kw.get("upsample") else h) - 1) // st + 1, ((2 * w if kw.get("upsample") else w) - 1) // st + 1
-        return ("conv3x3", 2.0 * 9 * x.shape[2] * wt.shape[0] * x.shape[0] * ho * wo, 0)
+        n, cin, cout = x.shape[0], x.shape[2], wt.shape[0]
+        alg = 2.0 * (x.numel() + n * ho * wo * cout * (2 if kw.get("res") is not None else 1) + 9 * cin * cout)
+        return ("conv3x3", 2.0 * 9 * cin * cout * n * ho * wo, alg)
     timer.wrap(K, "conv3x3", sel_conv)
 
     def sel_gemm(x, w, bias=None, **kw):
         if not timer.extra:
             return None
-        rows = x.numel() // x.shape[-1]
-        if rows < 1024:
-            return None
-        if w is None:  # LayerNorm folded into the projection (fz_gemm_ln): the weights travel in `ln`
-            w = kw["ln"].w
-        return ("gemm", 2.0 * rows * x.shape[-1] * w.shape[0], 0)
+        tag = gemm_class(x, w, kw)
+        return None if tag is None else tag
     timer.wrap(K, "gemm", sel_gemm)
+
+
+def gemm_class(x, w, kw):
+    """Roofline class of one projection GEMM (>= 1024 rows).  The launches fall into two regimes: plain projections with
+    K <= 640 move 2 (rows K + rows N + K N) bytes (+ one more rows x N per residual) for 2 rows K N FLOP -- <= 213 FLOP per byte at
+    K = N = 640, below the chip's ridge of 2500 T / 8 T = 312: their roof is HBM; the GEGLU projections (N = 8 C, gate in the epilogue)
+    and the long-K ones (K >= 1280) sit above it: MFMA.  Returns (class, work in the class's unit, algorithmic bytes)."""
+    rows = x.numel() // x.shape[-1]
+    if rows < 1024:
+        return None
+    if w is None:  # LayerNorm folded into the projection (fz_gemm_ln): the weights travel in `ln`
+        w = kw["ln"].w
+    k, o = x.shape[-1], w.shape[0]
+    geglu = bool(kw.get("geglu"))
+    n_out = o // 2 if geglu else o
+    n_res = (kw.get("res") is not None) + (kw.get("res2") is not None)
+    alg = 2.0 * (rows * k + rows * n_out * (1 + n_res) + k * o)
+    flops = 2.0 * rows * k * o
+    if geglu or k > 640:
+        return ("gemm_mfma", flops, alg)
+    return ("gemm_hbm", alg, alg)
+
+
+def install_launch_log(K, path):
+    """FZ_BENCH_LAUNCHLOG=<path> (scripts/pmc_job.sh): one entry per MODE-0 igemm dispatch of this process, in launch order -- the
+    roofline class of the GEMM (gemm_class; 'gemm_small' below 1024 rows, 'gemm_vt' for the transposed V projection) -- so that the
+    counter rows rocprofv3 writes per dispatch can be attributed to the classes the line reports.  Written at exit."""
+    import atexit
+    log = []
+    for fn_name in ("gemm", "gemm_vt", "gemm_batched"):
+        orig = getattr(K, fn_name)
+
+        def wrapped(x, w, *a, _orig=orig, _name=fn_name, **k):
+            if _name == "gemm":
+                tag = gemm_class(x, w, k)
+                log.append("gemm_small" if tag is None else tag[0])
+            else:
+                log.append(_name)
+            return _orig(x, w, *a, **k)
+        setattr(K, fn_name, wrapped)
+    atexit.register(lambda: json.dump(log, open(path, "w")))
 
 
 def rooflines(summ):
@@ -316,20 +377,38 @@ def rooflines(summ):
                 # the key tiles the kernel really contracts, beside the algorithmic one SURVEY section 8(d) defines
                 "contracted_fraction": flops_read / flops_total,
                 "achieved_over_contracted_tiles": achieved * flops_read / flops_total}
+    if roof is not None:  # q, k (two source frames' worth is re-read from L2, not algorithmic), V^T in, o out: 4 x Lq x C halves per frame
+        roof["algorithmic_bytes_per_launch"] = 2.0 * 4 * 4096 * 320 * frames_total / launches
+        if roof["traffic"]:
+            roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+    job_pmc, job_src = pmc_job_traffic()
     for name, kernel, bound, peak, unit, scale in (
-            ("conv3x3", "igemm_kernel<.., MODE 1> (all 3x3 convolutions, 2*9*Cin*Cout FLOP per output pixel)", "mfma", 2500.0, "TFLOP/s", 1e12),
-            ("gemm", "igemm_kernel<.., MODE 0> (projection GEMMs with >= 1024 rows, 2*K*N FLOP per row)", "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("conv3x3", "igemm_kernel<.., MODE 1 / 3> (all 3x3 convolutions, 2*9*Cin*Cout FLOP per output pixel)", "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("gemm_mfma", "igemm_kernel<.., MODE 0> MFMA class: GEGLU projections and K >= 1280 projections with >= 1024 rows (2*K*N FLOP per row)",
+             "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("gemm_hbm", "igemm_kernel<.., MODE 0> HBM class: plain projections with K <= 640 and >= 1024 rows (algorithmic bytes "
+                         "2 (rows K + rows N (1 + residuals) + K N))", "hbm", 8000.0, "GB/s", 1e9),
             ("capture", "attn_self_kernel<CAPTURE> (bytes of the fp16 probability maps written to the HBM arena)", "hbm", 8000.0, "GB/s", 1e9),
             ("inject", "attn_self_kernel<INJECT> (bytes of the stored maps read back)", "hbm", 8000.0, "GB/s", 1e9)):
         sel = {k: v for k, v in summ.items() if k[0] == name}
         if not sel:
             continue
         work = sum(k[1] * v["launches"] for k, v in sel.items())
+        alg = sum(k[2] * v["launches"] for k, v in sel.items())
         ms = sum(v["total_ms"] for v in sel.values())
         n = sum(v["launches"] for v in sel.values())
         ach = work / (ms * 1e-3) / scale
-        others.append({"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                       "traffic": None, "launches": n, "total_ms": ms, "sampled": "one extra job after the timed region, HIP events per launch"})
+        ent = {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+               "traffic": None, "launches": n, "total_ms": ms, "algorithmic_bytes_per_launch": alg / n,
+               "sampled": "one extra job after the timed region, HIP events per launch"}
+        if bound == "mfma":  # the same launches against the OTHER roof, so that the class can be read off the line
+            ent["algorithmic_GBps"] = alg / (ms * 1e-3) / 1e9
+        c = (job_pmc or {}).get("classes", {}).get(name)
+        if c is not None:
+            ent.update(traffic=c["traffic_bytes_per_launch"], traffic_unit="bytes/launch", traffic_launches=c["launches"],
+                       traffic_source=f"{job_src} (in situ, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                       traffic_over_algorithmic=c["traffic_bytes_per_launch"] / (alg / n))
+        others.append(ent)
     return roof, others
 
 
@@ -349,6 +428,9 @@ def promote_frame_sharded(line, fs, world):
     line["clips_dp"]["parallelism"] = line["config"]["parallelism"]
     line.update(value=fs["value"], ms_per_step=fs["ms_per_job"], scaling="strong")
     line["config"]["parallelism"] = f"{world}-way frame-sharded clip"
+    # the definition of `value` changed with the promotion: say so in the metric itself, and keep BOTH numbers as top-level fields
+    # under fixed names (value_clips_dp / value_frame_sharded, set by the caller) so that lines stay comparable across rounds
+    line["metric"] += f" [value = ONE clip, frames sharded over {world} GPUs (strong scaling); one clip per GPU: value_clips_dp]"
     return True
 
 
@@ -406,6 +488,8 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from fatezero_amd import kernels as K
+    if os.environ.get("FZ_BENCH_LAUNCHLOG"):
+        install_launch_log(K, os.environ["FZ_BENCH_LAUNCHLOG"])
     timer = KernelTimer()
     timer.extra = False
     install_timers(K, timer)
@@ -563,6 +647,8 @@ def main():
             dog.cancel()
             if rank == 0:
                 line["frame_sharded"] = fs
+                line["value_clips_dp"] = line["value"]  # fixed definitions, whatever `value` ends up meaning (see `metric`)
+                line["value_frame_sharded"] = fs.get("value")
                 if auto_frames:
                     promote_frame_sharded(line, fs, world)
         else:

@@ -71,6 +71,7 @@ _P = C.c_void_p
 _SIGS = {
     "fz_gemm": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_gemm_ln": (C.c_int, [C.POINTER(FzGemmDesc), C.POINTER(FzGemmLn), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fz_gemm_qkvt": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
     "fz_gemm_workspace_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "fz_attn_self": (C.c_int, [C.POINTER(FzAttnSelfDesc), _P, _P, _P, _P, _P, _P, _P]),
     "fz_attn_cross": (C.c_int, [C.POINTER(FzAttnCrossDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -24,6 +24,7 @@
 #include "fz_rt.h"
 #include <type_traits>
 #include <atomic>
+#include <stdlib.h>
 #include "../../include/fatezero_hip.h"
 
 // PP (template parameter of the kernel): 0 = ring loop; bit 0 = phase-interleaved ("ping-pong") loop, and its trial forms (only
@@ -78,6 +79,7 @@ struct IgArgs {
     int Cin, taps, kchunks;
     int N, Hi, Wi, Ho, Wo, stride, upsample, fpb;
     int ksplit, tiles_a;
+    int nt_flat;          // > 0: split-K launch with a FLAT grid of nt_flat * ksplit workgroups, K slices mapped onto XCDs (ig_launch)
     // LayerNorm fused around the GEMM (fz_gemm_ln): the B rows are the RAW LayerNorm input, A holds gamma * W
     const float* ln_in;   // per B row: ln_blocks x (sum, sum of squares) of its 64-channel blocks, or null
     const float* ln_c1;   // [Ma]: sum_k (gamma W)[a][k]
@@ -85,6 +87,11 @@ struct IgArgs {
     float ln_eps;
     int ln_blocks;
     float* st_out;        // per output row: (Ma / 64) x (sum, sum of squares) of the STORED values, or null
+    // fz_gemm_qkvt (the q | k | V^T projection of a self-attention in ONE launch): A rows [vt_split, Ma) are the V projection; the
+    // tiles that hold them store TRANSPOSED, yt[row / vt_rows][a - vt_split][row % vt_rows] -- the attention kernels' V^T operand
+    half_t* yt;           // [frames][Ma - vt_split][ldyt] or null
+    int64_t yt_bs, ldyt;
+    int vt_split, vt_rows;
 };
 
 template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, int PP = 0>
@@ -132,7 +139,8 @@ struct IgCfg {
 
 // LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
 // instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0>
+// VT: the fz_gemm_qkvt form (column tiles at or beyond g.vt_split store transposed).  Its own instantiation for the same reason.
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::WAVES_PER_SIMD)) igemm_kernel(IgArgs g) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
@@ -144,13 +152,27 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
 #endif
     // ---- tile of this workgroup: XCD-aware (blocks b, b+8, b+16.. share an XCD and get consecutive tiles, which share
     //      their B rows: the activation panel is fetched once per XCD L2), a-tile fastest
-    const int nt = gridDim.x, bid = blockIdx.x;
-    const int q8 = nt >> 3, r8 = nt & 7, xcd = bid & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    // Split-K: every XCD has its own L2, and with the K slices spread over all XCDs each of the eight L2s streams the WHOLE weight
+    // matrix (16^2 conv 1280 -> 1280: 29.5 MB x 8 against 5 MB of input; in situ the 3x3 convolutions fetch 4.2x their algorithmic
+    // bytes, profiles/r04_pmc_job.json).  The flat grid hands XCD x the work items [x, x + 1) * total / 8 of the K-slice-major order:
+    // whole K slices when ksplit is a multiple of 8, a run of one slice's tiles otherwise -- an XCD then reads only ITS slices of the
+    // weights and of the input channels.
+    int lid, ks;
+    if (g.nt_flat > 0) {
+        const int per = (int)gridDim.x >> 3;
+        const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        ks = item / g.nt_flat;
+        lid = item - ks * g.nt_flat;
+    } else {
+        const int nt = gridDim.x, bid = blockIdx.x;
+        const int q8 = nt >> 3, r8 = nt & 7, xcd = bid & 7;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        ks = blockIdx.y;
+    }
     const int ta = lid % g.tiles_a, tb = lid / g.tiles_a;
     const int a0 = ta * C::BA;
     const int64_t b0 = (int64_t)tb * C::BB;
-    const int ks = blockIdx.y, z = blockIdx.z;
+    const int z = blockIdx.z;
     const half_t* A = g.a + (int64_t)z * g.a_bs;
     const half_t* B = g.b + (int64_t)z * g.b_bs;
     const char* zero = reinterpret_cast<const char*>(fz_zero_page);
@@ -740,6 +762,65 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * gq + e] += (float)bv[e];
             }
     }
+    if constexpr (VT) {
+        // The accumulators are rounded to fp16 HERE, before the two store forms part ways: element pairs (4 gq, 4 gq + 1) of every
+        // register group then carry the four halves of the group as raw bits and the other two die -- 80 live registers per wave of
+        // the 5 x 2 tile instead of 160 where the two epilogue paths meet (with fp32 accumulators live on both sides of the branch
+        // that tile spilled 91 VGPRs).
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    half4_t v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (half_t)acc[i][j][4 * gq + e];
+                    const f32x2 pk = __builtin_bit_cast(f32x2, v);
+                    acc[i][j][4 * gq] = pk[0];
+                    acc[i][j][4 * gq + 1] = pk[1];
+                }
+        // ---- transposed tile (fz_gemm_qkvt): the V columns of the fused q | k | v projection leave as V^T[frame][channel][token].
+        // The accumulator layout already has the token (B row) on the lane: lanes 0..31 of a register hold 32 CONSECUTIVE tokens of
+        // one channel, so the tile is staged channel-major -- Cs[channel][token], 2-byte LDS writes, 64 contiguous bytes per half
+        // wave -- and leaves in 16-byte pieces of 8 tokens.  A piece never straddles a frame (vt_rows % 8 == 0, checked by the host).
+        if (a0 >= g.vt_split) {  // workgroup-uniform
+            constexpr int RSTR = C::RP + 8;
+            static_assert(C::CW * RSTR <= C::LDS_HALVES, "transposed epilogue staging does not fit");
+            half_t* Ct = smem;
+            for (int ps = 0; ps < WB / C::WBP; ++ps) {
+                __syncthreads();
+                if (wb / C::WBP == ps) {
+                    const int rl = (wb % C::WBP) * TB * 32 + l31;
+#pragma unroll
+                    for (int j = 0; j < TB; ++j)
+#pragma unroll
+                        for (int i = 0; i < TA; ++i)
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                f32x2 pk;
+                                pk[0] = acc[i][j][4 * gq];
+                                pk[1] = acc[i][j][4 * gq + 1];
+                                const half4_t v = __builtin_bit_cast(half4_t, pk);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) Ct[((wa * TA + i) * 32 + 8 * gq + 4 * hi + e) * RSTR + rl + j * 32] = v[e];
+                            }
+                }
+                __syncthreads();
+                constexpr int RCH = C::RP / 8;
+                for (int id = tid; id < C::CW * RCH; id += C::T) {
+                    const int col = id / RCH, rc = id - col * RCH;
+                    const int64_t px = b0 + ps * C::RP + rc * 8;
+                    const int a = a0 + col;
+                    if (px >= g.Nb || a >= g.Ma) continue;
+                    const int64_t fr = px / g.vt_rows;
+                    const int64_t tok = px - fr * g.vt_rows;
+                    fz_st_h8(g.yt + fr * g.yt_bs + (int64_t)(a - g.vt_split) * g.ldyt + tok, fz_ld_h8(Ct + col * RSTR + rc * 8));
+                }
+            }
+            return;
+        }
+    }
     const int Mo = GEGLU ? g.Ma / 2 : g.Ma;          // output columns in total
     const int o0 = GEGLU ? a0 / 2 : a0;              // first output column of this tile
     const int Mo_store = GEGLU ? Mo : g.Ma_store;
@@ -773,8 +854,15 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
                             half4_t v;
+                            if constexpr (VT) {  // already rounded: the group's four halves as raw bits in its first two registers
+                                f32x2 pk;
+                                pk[0] = acc[i][j][4 * gq];
+                                pk[1] = acc[i][j][4 * gq + 1];
+                                v = __builtin_bit_cast(half4_t, pk);
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (half_t)acc[i][j][4 * gq + e];
+                                for (int e = 0; e < 4; ++e) v[e] = (half_t)acc[i][j][4 * gq + e];
+                            }
                             *reinterpret_cast<half4_t*>(crow + (wa * TA + i) * 32 + 8 * gq + 4 * hi) = v;
                         }
                 }
@@ -985,7 +1073,7 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false>
 static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
@@ -1002,14 +1090,17 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FZ_ERR_LAUNCH;
     if (dev >= 64 || !(attr_set_mask.load(std::memory_order_relaxed) >> dev & 1)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
         if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
 #endif
-    dim3 grid((unsigned)nt, (unsigned)g.ksplit, (unsigned)batch), block(C::T);
-    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP>), grid, block, lds, stream, g);
+    static const bool xcd_ks_off = getenv("FZ_IGEMM_NO_XCD_KS") != nullptr;  // A/B switch of the K-slice -> XCD mapping (tuning only)
+    const bool flat = g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
+    g.nt_flat = flat ? (int)nt : 0;
+    dim3 grid(flat ? (unsigned)(nt * g.ksplit) : (unsigned)nt, flat ? 1u : (unsigned)g.ksplit, (unsigned)batch), block(C::T);
+    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT>), grid, block, lds, stream, g);
     return fz_last_launch_status();
 }
 
@@ -1094,6 +1185,19 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
     return FZ_ERR_BAD_ARG;
 }
 
+// The fz_gemm_qkvt instantiations (MODE 0, plain epilogue, ring loop): the tiles whose width divides every 2 C of the UNet (320 | 640,
+// 1280, 2560; 128 and 64 likewise), so that no column tile straddles the k | v boundary.
+static int ig_dispatch_vt(int cfg, const IgArgs& g, int batch, void* stream) {
+    switch (cfg) {
+        case 254222: return ig_launch<2, 5, 4, 2, 64, 2, 0, false, false, 0, true>(g, batch, stream);
+        case 254122: return ig_launch<2, 5, 4, 1, 64, 2, 0, false, false, 0, true>(g, batch, stream);
+        case 224223: return ig_launch<2, 2, 4, 2, 64, 3, 0, false, false, 0, true>(g, batch, stream);
+        case 222222: return ig_launch<2, 2, 2, 2, 64, 2, 0, false, false, 0, true>(g, batch, stream);
+        case 212222: return ig_launch<2, 1, 2, 2, 64, 2, 0, false, false, 0, true>(g, batch, stream);
+        default: return FZ_ERR_BAD_ARG;
+    }
+}
+
 struct IgTile {
     int cfg, ba, bb, bk, wg_per_cu;
     double rate_pf;   // PFLOP/s the whole chip sustains in the K loop of this tile with every CU busy (long-K convolutions)
@@ -1127,11 +1231,12 @@ static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats,
     for (const IgTile& t : kTiles) {
         if (geglu && !t.geglu_ok) continue;
         if (g.st_out != nullptr && (t.ba % 64)) continue;  // row statistics are per 64-column block
+        if (g.yt != nullptr && (g.vt_split % t.ba || t.cfg == 244222 || t.cfg == 158122)) continue;  // no tile across the k | v boundary
         const int nkt = g.taps * fz_ceil_div(g.Cin, t.bk);
         const int64_t tiles = (int64_t)fz_ceil_div(g.Ma, t.ba) * ((g.Nb + t.bb - 1) / t.bb) * batch;
         const double t_step = 2.0 * t.ba * t.bb * t.bk * t.wg_per_cu / (t.rate_pf * 1e15 / 256.0) * 1e6;  // microseconds
         for (int sk = 1; sk <= 32; sk *= 2) {
-            if (sk > 1 && (geglu || g.ln_in != nullptr || g.Ma % 4 || g.Ma_store != g.Ma || nkt / sk < 4 || out_elems * sk > (double)ws_floats)) break;
+            if (sk > 1 && (geglu || g.ln_in != nullptr || g.yt != nullptr || g.Ma % 4 || g.Ma_store != g.Ma || nkt / sk < 4 || out_elems * sk > (double)ws_floats)) break;
             const int64_t wgs = tiles * sk;
             const int64_t slots = 256 * t.wg_per_cu;
             const int64_t rounds = (wgs + slots - 1) / slots;
@@ -1165,7 +1270,7 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         // (under split-K only when a K slice keeps >= 16 K-64 steps: +1.5 ... +5 % on the 1920 / 2560-wide 16^2 and 32^2 convs,
         //  profiles/r03_igemm_prod_pp_under_splitk.txt; the 8^2 convs with their 5-11-step slices lost 35 %)
         const int64_t k64_per_slice = (int64_t)g.taps * g.Cin / 64 / ksplit;
-        bool pp_ok = g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr && (int64_t)g.taps * g.Cin >= 640 &&
+        bool pp_ok = g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr && g.yt == nullptr && (int64_t)g.taps * g.Cin >= 640 &&
                      (ksplit == 1 || k64_per_slice >= 16);
 #ifdef FZ_IGEMM_TRIALS  // scripts/igemm_timeline.hip: A/B of the library's own choice with / without the substitution, and under split-K
         if (fz_igemm_trial_pp_splitk_min > 0 && ksplit > 1 && g.Cin % 32 == 0 && g.ln_in == nullptr && g.st_out == nullptr &&
@@ -1186,6 +1291,12 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
     }
     if (ksplit == 0) ksplit = 1;
     if (g.ln_in != nullptr) ksplit = 1;  // the LayerNorm correction lives in the GEMM's own epilogue
+    if (g.yt != nullptr) {               // fz_gemm_qkvt: transposed tiles leave from the GEMM's own epilogue as well
+        if (GEGLU || MODE != 0 || ksplit != 1 || g.ln_in != nullptr || g.st_out != nullptr) return FZ_ERR_UNSUPPORTED;
+        g.ksplit = 1;
+        g.part = nullptr;
+        return ig_dispatch_vt(cfg, g, batch, stream);
+    }
     bool stats_dropped = false;
     if (g.st_out != nullptr && ksplit > 1) {  // the split-K tail does not compute row statistics: tell the caller
         g.st_out = nullptr;
@@ -1305,6 +1416,35 @@ static int gemm_impl(const FzGemmDesc* d, const FzGemmLn* ln, const void* x, con
     g.bias = nullptr;
     if (d->ldy < g.Ma_store) return FZ_ERR_BAD_ARG;
     return ig_run<0, false>(g, batch, d->tile_cfg, 1, nullptr, 0, stream);
+}
+
+extern "C" int fz_gemm_qkvt(const FzGemmDesc* d, const void* x, const void* w, void* y, void* yt, int split_col, int64_t rows_per_frame,
+                            int64_t yt_frame_stride, int64_t ldyt, void* stream) {
+    if (!d || !x || !w || !y || !yt || d->rows <= 0 || d->in_features <= 0 || d->out_features <= 0) return FZ_ERR_BAD_ARG;
+    if (d->epilogue != FZ_GEMM_PLAIN || d->transpose_out || (d->batch > 1) || d->w_batch_stride) return FZ_ERR_UNSUPPORTED;
+    if (split_col <= 0 || split_col >= d->out_features || split_col % 64 || rows_per_frame <= 0 || rows_per_frame % 8 ||
+        d->rows % rows_per_frame || ldyt < rows_per_frame || (ldyt % 8) || (yt_frame_stride % 8) || d->ldy < split_col || (d->ldy % 8))
+        return FZ_ERR_BAD_ARG;
+    if (d->ldx < d->in_features || d->ldw < d->in_features || (d->ldx % 8) || (d->ldw % 8) || d->rows >= (1ll << 31)) return FZ_ERR_BAD_ARG;
+    IgArgs g = {};
+    g.taps = 1;
+    g.fpb = 1;
+    g.Cin = d->in_features;
+    g.temb_group = 1;
+    g.a = (const half_t*)w;
+    g.lda = d->ldw;
+    g.Ma = g.Ma_store = d->out_features;
+    g.b = (const half_t*)x;
+    g.ldb = d->ldx;
+    g.Nb = d->rows;
+    g.y = (half_t*)y;
+    g.ldy = g.ldres = d->ldy;
+    g.yt = (half_t*)yt;
+    g.yt_bs = yt_frame_stride;
+    g.ldyt = ldyt;
+    g.vt_split = split_col;
+    g.vt_rows = (int)rows_per_frame;
+    return ig_run<0, false>(g, 1, d->tile_cfg, 1, nullptr, 0, stream);
 }
 
 static int conv_common(IgArgs& g, const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride,

@@ -17,12 +17,14 @@ CROSS_KEYS = N.FZ_CROSS_MAX_KEYS
 SUPPORTED_HEAD_DIMS = (16, 32, 40, 64, 80, 128, 160)
 
 
-_stream_cache = {"handle": None}
+def _raw_stream(dev_index: int) -> int:
+    """PyTorch's CURRENT HIP stream on that device as a raw hipStream_t (no Stream object is built: ~0.2 us per call)."""
+    return torch._C._cuda_getCurrentRawStream(dev_index)
 
 
 def refresh_stream():
-    """Re-read PyTorch's current HIP stream (call when the caller switches streams; the pipelines do it per forward)."""
-    _stream_cache["handle"] = C.c_void_p(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else None
+    """Kept for callers of earlier revisions: the launch stream is read from PyTorch at EVERY launch now (per device), so there is
+    nothing to refresh."""
 
 
 _launches = [0]
@@ -35,11 +37,12 @@ def launch_count() -> int:
 
 
 def _stream(t: torch.Tensor):
+    """The stream a launch on `t` goes to: PyTorch's current stream OF t's DEVICE, read per launch -- a call under
+    `torch.cuda.stream(s)` launches on s, a tensor on cuda:1 launches on cuda:1's stream whatever ran before.  The split-K /
+    GroupNorm scratch is keyed on this same handle (_scratch_key)."""
     _launches[0] += 1
     if t.is_cuda:
-        if _stream_cache["handle"] is None:
-            refresh_stream()
-        return _stream_cache["handle"]
+        return C.c_void_p(_raw_stream(t.device.index))
     if not N.is_test_backend():
         raise RuntimeError("fatezero_amd kernels run on the GPU only (CPU tensors are accepted only by the "
                            "emulation backend used in tests)")
@@ -337,13 +340,29 @@ def pack_geglu(w: torch.Tensor, b: Optional[torch.Tensor]):
 _WS_FLOATS = 64 << 20  # 256 MB of fp32 split-K scratch per device, allocated on first need
 
 
+_SCRATCH_STREAMS_MAX = 4  # per-stream scratch sets kept alive (least recently used beyond that are released)
+_scratch_lru = []
+
+
 def _scratch_key(t_or_device):
-    """Scratch buffers (split-K slabs, GroupNorm partials) are per (device, current stream): two streams that both take a split-K
-    path must not share the fp32 slabs."""
+    """Scratch buffers (split-K slabs, GroupNorm partials) are per (device, launch stream) -- the SAME raw handle `_stream` hands to
+    the launch: two streams that both take a split-K path must not share the fp32 slabs.  At most _SCRATCH_STREAMS_MAX stream sets
+    stay allocated; an evicted set goes back to PyTorch's caching allocator, which hands a block to another stream only after the
+    work queued on the stream that allocated it -- the stream the scratch was used on -- has run."""
     dev = t_or_device.device if isinstance(t_or_device, torch.Tensor) else torch.device(t_or_device)
     if dev.type != "cuda":
         return (dev, 0)
-    return (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev, _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device()))
+    if not _scratch_lru or _scratch_lru[-1] != key:
+        if key in _scratch_lru:
+            _scratch_lru.remove(key)
+        _scratch_lru.append(key)
+        while len(_scratch_lru) > _SCRATCH_STREAMS_MAX:
+            old = _scratch_lru.pop(0)
+            _ws.pop(old, None)
+            if _gn_scratch.pop(old, None) is not None:
+                _gn_plans.clear()  # plans hold the scratch pointer
+    return key
 
 
 def _ws_ptr(device):
@@ -524,6 +543,41 @@ def gemm_vt(x: torch.Tensor, w: torch.Tensor, lp: int, out: Optional[torch.Tenso
     if rc:
         N.check(rc, "fz_gemm(vt)")
     return out
+
+
+_qkvt_plans = {}
+
+
+def gemm_qkvt_ok(x: torch.Tensor, w: torch.Tensor, split: int) -> bool:
+    """Shapes fz_gemm_qkvt carries: token counts per frame that are multiples of 64 (V^T rows need no zero padding then), a k | v
+    boundary on a multiple of 64 output columns."""
+    return x.dim() == 3 and x.shape[1] % 64 == 0 and split % 64 == 0 and 0 < split < w.shape[0] and x.shape[2] % 8 == 0
+
+
+def gemm_qkvt(x: torch.Tensor, w: torch.Tensor, split: int, tile_cfg: int = 0):
+    """The q | k | V^T projection of a self-attention in ONE launch (fz_gemm_qkvt): x [N, L, K] (unit channel stride, one row
+    stride), w [split + Cv, K] = rows [Wq ; Wk ; Wv] -> (y [N, L, split] = x @ w[:split]^T,  vt [N, Cv, L] = w[split:] @ x[n]^T)."""
+    n, l, k = x.shape
+    o = w.shape[0]
+    cv = o - split
+    key = (x.shape, x.stride(), w.shape, w.stride(0), split, tile_cfg, x.device)
+    plan = _qkvt_plans.get(key)
+    if plan is None:
+        if not gemm_qkvt_ok(x, w, split) or x.stride(2) != 1 or w.stride(1) != 1 or w.shape[1] != k or x.stride(0) != l * x.stride(1):
+            raise ValueError("fz_gemm_qkvt: x [N, L, K] with L % 64 == 0 and a single row stride, w [split + Cv, K], split % 64 == 0")
+        d = N.FzGemmDesc()
+        d.rows, d.in_features, d.out_features = n * l, k, o
+        d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(0), split
+        d.batch, d.epilogue, d.tile_cfg = 1, N.FZ_GEMM_PLAIN, tile_cfg
+        plan = _qkvt_plans[key] = (C.byref(d), d)
+    if x.dtype != torch.float16 or w.dtype != torch.float16 or ((x.data_ptr() | w.data_ptr()) & 15):
+        raise ValueError("fz_gemm_qkvt operands must be fp16 and 16-byte aligned")
+    y = torch.empty(n, l, split, dtype=torch.float16, device=x.device)
+    vt = torch.empty(n, cv, l, dtype=torch.float16, device=x.device)
+    rc = N.lib().fz_gemm_qkvt(plan[0], x.data_ptr(), w.data_ptr(), y.data_ptr(), vt.data_ptr(), split, l, cv * l, l, _stream(x))
+    if rc:
+        N.check(rc, "fz_gemm_qkvt")
+    return y, vt
 
 
 def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, hw: Tuple[int, int], stride: int = 1,

@@ -13,6 +13,7 @@ Differences from the reference, by design:
     text context F times before projecting, attention.py:104).
 """
 import copy
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -58,6 +59,10 @@ def _plan_for(controller, is_cross, place, n, clip, heads, lq, lk, device):
 # SLOWER with it -- the 30 LayerNorm launches it removes per forward (C <= 640 levels) cost less than the statistics loop and the
 # per-row correction add to the 60 GEMM epilogues.
 LN_FUSION = False
+# q | k | V^T of a self-attention in ONE launch (fz_gemm_qkvt: the V columns leave transposed from the same GEMM; the LayerNorm
+# output is read once instead of twice, one launch instead of two) wherever the frame's token count is a multiple of 64 -- every level
+# of a 512^2 clip.  Bit-identical to the two launches (tests/kernel_cases.py: case_gemm_qkvt).  Switch kept for same-box A/B runs.
+QKV_FUSION = os.environ.get("FZ_NO_QKV_FUSION") is None  # (the env switch: same-box A/B runs of bench.py)
 LN_FUSION_MAX_C = 640  # wider rows (K = 1280) want split-K in the consuming GEMM, which the fused epilogue excludes
 
 
@@ -95,6 +100,7 @@ class CrossAttention(nn.Module):
         self._qk = None
         self._qk_fold = 1.0
         self._qkv = None
+        self._qkv_self = None
         self._ctx_kv = None
         self._ln_fold = None  # (id of the norm, LnFold): the consuming projection with its LayerNorm folded in
 
@@ -220,6 +226,7 @@ class CrossAttention(nn.Module):
     def load_state_dict(self, *a, **k):  # packed weights / cached projections must follow the parameters
         self._qk = None
         self._qkv = None
+        self._qkv_self = None
         self._ctx_kv = None
         self._ln_fold = None
         return super().load_state_dict(*a, **k)
@@ -288,10 +295,18 @@ class SparseCausalAttention(CrossAttention):
             kk, vt = skv.extend(hk), skv.extend(hv)
             kw.update(skv.ext)
         else:
-            qk = K.gemm(xn, wqk)
+            wv = self.to_v.packed(xn.dtype, xn.device)[0]
+            if QKV_FUSION and lq % 64 == 0 and (2 * self.inner_dim) % 64 == 0 and xn.is_contiguous():
+                # ONE launch: [Wq ; Wk ; Wv] against the LayerNorm output, the V columns leaving transposed (fz_gemm_qkvt)
+                c = self._qkv_self
+                if c is None or c[0] is not wqk or c[1] is not wv:
+                    c = self._qkv_self = (wqk, wv, torch.cat([wqk, wv], 0).contiguous())
+                qk, vt = K.gemm_qkvt(xn, c[2], 2 * self.inner_dim)
+            else:
+                qk = K.gemm(xn, wqk)
+                # V^T straight out of the projection GEMM (operands swapped: [N, C, L], rows zero-padded to a multiple of 64 keys)
+                vt = K.gemm_vt(xn, wv, K.pad64(lq))
             q, kk = qk[..., : self.inner_dim], qk[..., self.inner_dim:]
-            # V^T straight out of the projection GEMM (operands swapped: [N, C, L], rows zero-padded to a multiple of 64 keys)
-            vt = K.gemm_vt(xn, self.to_v.packed(xn.dtype, xn.device)[0], K.pad64(lq))
         out = torch.empty(n, lq, self.inner_dim, dtype=xn.dtype, device=xn.device)
         n_kv = max(1, len(index_list))
         ctrl = self.controller

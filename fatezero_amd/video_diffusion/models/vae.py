@@ -120,8 +120,9 @@ class AttentionBlock(nn.Module):
         vt = K.gemm_vt(h, wv, lp)                                     # V^T [n, c, lp] straight out of the GEMM (bias added below)
         out = torch.empty(n, l, c, dtype=torch.float16, device=dev)
         # three launches for a chunk of frames (batched q k^T, row softmax, batched P V) instead of three per frame; the [l, l]
-        # score matrix of a 512^2 frame is 32 MB in fp16: chunks of at most 8 frames keep scores + probabilities under 0.6 GB
-        step = max(1, min(n, (1 << 28) // max(1, l * lp)))
+        # score matrix of a 512^2 frame is 32 MB in fp16: chunks of at most 8 frames (2^27 score elements) keep scores +
+        # probabilities at 0.5 GB (+ the -inf padded copy when l is not a multiple of 8)
+        step = max(1, min(n, (1 << 27) // max(1, l * lp)))
         for i0 in range(0, n, step):
             i1 = min(n, i0 + step)
             s = K.gemm_batched(qk[i0:i1, :, :c], qk[i0:i1, :, c:])     # scores [f, l, l] = q k^T

@@ -63,12 +63,12 @@ class _MaskDumper:
         self.errors = []
 
     def _run(self):
-        from PIL import Image
         while True:
             job = self.q.get()
-            try:
+            try:  # EVERYTHING a job can raise sits inside: each get() is answered by exactly one task_done(), or flush() would hang
                 if job is None:
                     return
+                from PIL import Image
                 ev, host, paths = job
                 if ev is not None:
                     ev.synchronize()
@@ -109,20 +109,38 @@ class _MaskDumper:
         self._ensure_thread()
         self.q.put((staged[0], staged[1], list(paths)))
 
-    def flush(self):
+    def flush(self, raise_on_error=False):
+        """Wait for the queued dumps.  A failed dump (disk full, permissions, no PIL) must not cost the caller the finished edit:
+        the errors come back as a list (and as a warning) unless `raise_on_error`."""
         if self.thread is not None:
-            self.q.join()
+            while self.q.unfinished_tasks:  # (q.join() would wait forever for jobs nobody will take if the writer died)
+                if not self.thread.is_alive():
+                    with self.q.mutex:
+                        dropped = len(self.q.queue)
+                        self.q.queue.clear()
+                        self.q.unfinished_tasks = 0
+                        self.q.all_tasks_done.notify_all()
+                    self.errors.append(f"writer thread died; {dropped} queued dump(s) dropped")
+                    break
+                with self.q.all_tasks_done:
+                    if self.q.unfinished_tasks:
+                        self.q.all_tasks_done.wait(0.05)
         errs, self.errors = self.errors, []
         if errs:
-            raise RuntimeError("blend-mask PNG dump failed: " + "; ".join(errs))
+            if raise_on_error:
+                raise RuntimeError("blend-mask PNG dump failed: " + "; ".join(errs))
+            import warnings
+            warnings.warn("blend-mask PNG dump failed (the edit itself is unaffected): " + "; ".join(errs))
+        return errs
 
 
 _DUMPER = _MaskDumper()
 
 
-def flush_mask_dumps():
-    """Wait until every blend-mask PNG queued so far is on disk (the pipeline calls it once after the denoise loop)."""
-    _DUMPER.flush()
+def flush_mask_dumps(raise_on_error=False):
+    """Wait until every blend-mask PNG queued so far is on disk (the pipeline calls it once after the denoise loop).  Returns the list
+    of dump errors (empty when all files were written); warns instead of raising unless `raise_on_error`."""
+    return _DUMPER.flush(raise_on_error)
 
 
 class SpatialBlender:
@@ -152,6 +170,7 @@ class SpatialBlender:
         self.th = th
         self.mask_list = []
         self.applied_mask_list = []  # (extension) what blends the EDITED latents each step: mask[1:], the source mask OR-ed with the target one
+        self.dumped_mask_list = []   # (extension, only filled with save_path) the very rows each PNG was drawn from: mask[-1]
         self._alpha_dev = {}
         self._cache = {}
         self._staged = {}
@@ -189,6 +208,7 @@ class SpatialBlender:
             path += f"step_in_store_{step_in_store:04d}"
         path += f"/mask_{now}_{self.count:02d}.png"
         self.count += 1
+        self.dumped_mask_list.append(mask[-1])
         staged = self._staged.get(cache_key) if cache_key is not None else None
         if staged is None:
             staged = _DUMPER.stage(mask[-1])

@@ -196,6 +196,17 @@ int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch);
 int fz_gemm(const FzGemmDesc* desc, const void* x, const void* w, const void* bias, const void* res, const void* res2,
             void* y, void* workspace, void* stream);
 
+/* The q | k | V^T projection of a self-attention in ONE launch (SparseCausalAttention.forward, attention.py:340-372: to_q, to_k and
+ * to_v all read the same LayerNorm output): w holds the rows [Wq ; Wk ; Wv] (out_features = split_col + C_v), x is read ONCE;
+ *   y [row][o]                 = sum_i x[row][i] * w[o][i]                 for o <  split_col   (row stride desc->ldy >= split_col)
+ *   yt[row / rows_per_frame][o - split_col][row % rows_per_frame] = the same for o >= split_col  -- V^T, the value operand of
+ *                                fz_attn_self, frames yt_frame_stride elements apart, channel rows ldyt elements apart.
+ * desc: rows (all frames), in_features, out_features, ldx, ldw, ldy, tile_cfg; batch <= 1, plain epilogue, no bias / residual.
+ * split_col % 64 == 0 (every UNet width is), rows_per_frame % 8 == 0 and ldyt >= rows_per_frame: a caller whose attention kernel
+ * wants V^T rows zero-padded beyond the frame's tokens (token counts that are not multiples of 64) uses fz_gemm twice instead. */
+int fz_gemm_qkvt(const FzGemmDesc* desc, const void* x, const void* w, void* y, void* yt, int split_col, int64_t rows_per_frame,
+                 int64_t yt_frame_stride, int64_t ldyt, void* stream);
+
 /* LayerNorm fused around fz_gemm (the `norm2 / norm3 / norm_temporal` + Linear pairs of SpatioTemporalTransformerBlock,
  * attention.py:295-337: `attn(norm(x)) + x`).  Two independent halves:
  *   stats_out  the GEMM that PRODUCES a LayerNorm input (out-projection + residual) also writes, per output row, the sum and the

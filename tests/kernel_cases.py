@@ -541,3 +541,26 @@ def case_gemm_vt(device, *, n, l, k, c, lp, tile_cfg=0, seed=0):
     err = (out.float().cpu() - ref).abs().max().item()
     assert err < 4e-3 * max(1.0, float(ref.abs().max())), err
     return {"max_err": err}
+
+
+def case_gemm_qkvt(device, *, n, l, k, c, tile_cfg=0, seed=0, ldx_extra=0):
+    """fz_gemm_qkvt: the q | k | V^T projection of a self-attention in one launch -- q|k token-major [n, l, 2c] and V^T [n, c, l]
+    against fp32 torch, AND bit for bit against the two launches it replaces (fz_gemm on the q|k rows with the same tile -- same K
+    order -- and the operand-swapped fz_gemm transpose_out form on the v rows: the same products, fp32-accumulated in the same K
+    order, rounded once)."""
+    g = torch.Generator().manual_seed(seed)
+    xfull = torch.randn(n, l, k + ldx_extra, generator=g).half().to(device)
+    x = xfull[..., ldx_extra:] if ldx_extra else xfull
+    w = (torch.randn(3 * c, k, generator=g) * k ** -0.5).half().to(device)
+    assert K.gemm_qkvt_ok(x, w, 2 * c)
+    qk, vt = K.gemm_qkvt(x, w, 2 * c, tile_cfg=tile_cfg)
+    assert qk.shape == (n, l, 2 * c) and vt.shape == (n, c, l)
+    ref = x.float().cpu() @ w.float().cpu().t()
+    scale = max(1.0, float(ref.abs().max()))
+    e_qk = float((qk.float().cpu() - ref[..., : 2 * c]).abs().max())
+    e_vt = float((vt.float().cpu() - ref[..., 2 * c:].transpose(1, 2)).abs().max())
+    assert e_qk < 4e-3 * scale and e_vt < 4e-3 * scale, (e_qk, e_vt, scale)
+    qk2 = K.gemm(x, w[: 2 * c], tile_cfg=tile_cfg)
+    vt2 = K.gemm_vt(x, w[2 * c:], l)
+    return {"qk_err": e_qk, "vt_err": e_vt, "qk_bit_equal": bool(torch.equal(qk, qk2)), "vt_bit_equal": bool(torch.equal(vt, vt2)),
+            "vt_max_diff_vs_two_launches": float((vt.float() - vt2.float()).abs().max())}

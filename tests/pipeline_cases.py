@@ -78,7 +78,14 @@ def check_mask_dumps(save_path, ctrl):
             assert int(f.rsplit("_", 1)[1].split(".")[0]) == k
             if blender.prompt_choose == "source":
                 assert "/step_in_store_" in f
-            m = blender.mask_list[k].float().cpu()[:, 0]          # [F, h, w] of 0 / 1
+            # 'source': the PNG shows mask_list's mask[0]; 'both': it shows mask[-1] = (source mask OR target mask)
+            # (spatial_blend.py:39-41,49-50), which the blender keeps in dumped_mask_list -- compared bit for bit either way
+            assert len(blender.dumped_mask_list) == blender.count
+            m = blender.dumped_mask_list[k].float().cpu()          # [F, h, w] of 0 / 1
+            if blender.prompt_choose == "source":
+                assert torch.equal(m, blender.mask_list[k].float().cpu()[:, 0])
+            else:
+                assert bool((m >= blender.mask_list[k].float().cpu()[:, 0]).all())  # OR-ed with the source mask: a superset
             fr, h, w = m.shape
             lo, hi = float(m.min()), float(m.max())
             mn = (m - lo) / max(hi - lo, 1e-5)
@@ -93,12 +100,7 @@ def check_mask_dumps(save_path, ctrl):
             want = grid.mul(255).add(0.5).clamp(0, 255).to(torch.uint8).numpy()
             got = np.asarray(Image.open(f))
             assert got.shape == want.shape + (3,), (f, got.shape, want.shape)
-            if blender.prompt_choose == "both":
-                # the reference dumps mask[1:] = (source mask OR target mask) (spatial_blend.py:39-41,49-50) while mask_list keeps
-                # mask[0] = the source mask: the picture must contain every pixel of the listed mask (and be a 0 / 255 picture)
-                assert set(np.unique(got)) <= {0, 255} and (got[:, :, 0] >= want).all(), f
-            else:
-                assert (got == want[:, :, None]).all(), f
+            assert (got == want[:, :, None]).all(), f
             n_checked += 1
     return n_checked
 
@@ -236,7 +238,6 @@ def check(res):
         if "applied_mask_flips" in res:
             assert res["applied_mask_flips"] <= MASK_FLIP_TOL * res["applied_mask_flips_total"], res
             assert res["edit_err_off_applied_flips"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
-        assert res["edit_err"] <= 1.0 * res["edit_scale"], res  # a flipped pixel jumps by |x - inverted|: never more than the scale
     else:
         assert res["edit_err"] <= (EDIT_TOL_VS_REFERENCE if has_mask else EDIT_MAX_TOL) * res["edit_scale"], res
     if "edit_err_vs_oracle_on_native_maps" in res:
@@ -264,11 +265,26 @@ FULL_SRC = "a silver jeep driving down a curvy road in the countryside,"
 FULL_TGT = "a Porsche car driving down a curvy road in the countryside,"
 
 
+# Blend threshold of the full-width cases.  With procedural weights the normalised 16^2 blend-word score (spatial_blend.py:24-42:
+# sum over words, mean over heads x layers, 3x3 max-pool, / per-frame max) spreads over 0.23 ... 1.0 with its median near 0.57
+# (build_tmp/mask_struct_exp2.py on the CPU oracle), so the teaser's th = 0.3 keeps 99 % of the rows live -- a mask test that tests
+# nothing (round-3 review).  Scaling the blend words' context rows saturates the softmax (100 % ones); the YAML knob that DOES move the
+# split is `blend_th` itself (the reference's configs use 0.3 and 2): 0.55 puts 20-80 % of the rows on either side, asserted below.
+FULL_BLEND_TH = 0.55
+FULL_MASK_BAND = (0.2, 0.8)
+
 FULL_VARIANTS = {
     # BASELINE cfg2 (config/teaser/jeep_posche.yaml): default model config, Replace + blend-masked self-attention
     "replace_blend": dict(
         model_config={"lora": 160}, prompts=(FULL_SRC, FULL_TGT), is_replace=True, cross_replace={"default_": 0.5},
         self_replace=1.0, blend_words=[["silver", "jeep"], ["Porsche", "car"]], eq_params=None),
+    # the JUDGED launch shapes (bench.py's job): F = 8 -> one 8-frame inversion launch and one 16-frame CFG edit launch per layer,
+    # i.e. the 320 x 128 ring tile / 320 x 256 ping-pong tile routing, the flash dispatch order with frames 0 and 1 single-source,
+    # the one-launch GroupNorms "at 8 frames" -- 1 + 1 steps (cross replacement live at step 0: default_ 1.0), Replace + blend mask,
+    # always with the all-fp32 leg (oracle edit on the oracle's own maps): the flip rate against the fp32 reference at this shape
+    "cfg2_8f": dict(
+        model_config={"lora": 160}, prompts=(FULL_SRC, FULL_TGT), is_replace=True, cross_replace={"default_": 1.0},
+        self_replace=1.0, blend_words=[["silver", "jeep"], ["Porsche", "car"]], eq_params=None, F=8, T=1, pure_edit=True),
     # BASELINE cfg1 / cfg3 model config (config/style/sun_flower_van_gogh.yaml:69-73): K/V from the middle frame only, and
     # only where the width reaches 640 (the 320-wide level runs per-frame attention); Refine + Reweight (x10), no mask
     "refine_reweight_mid": dict(
@@ -279,7 +295,7 @@ FULL_VARIANTS = {
 }
 
 
-def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="replace_blend"):
+def run_fullwidth_case(device, F=None, T=None, pure_edit=False, seed=11, variant="replace_blend"):
     """Native pipeline vs the fp32 CPU oracle (oracle.OracleUNet / ddim_inversion / ddim_edit) at REAL width with the same
     procedural weights: F frames, T inversion steps with capture + T CFG edit steps (unet_3d_condition.py:307-446 /
     attention_register.py:23-218 end to end).  F = 3 keeps the frame axis non-degenerate: with [-1, 'first'] the two K/V
@@ -289,6 +305,10 @@ def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="repl
     an assembled UNet.  `variant` picks the model config + controller (FULL_VARIANTS)."""
     from oracle import fatezero_oracle as O
     V = FULL_VARIANTS[variant]
+    F = V.get("F", 3) if F is None else F
+    T = V.get("T", 2) if T is None else T
+    pure_edit = pure_edit or V.get("pure_edit", False)
+    th = [FULL_BLEND_TH, FULL_BLEND_TH]
     mc = dict(V["model_config"])
     src, tgt = V["prompts"]
     unet = UNetPseudo3DConditionModel(sample_size=64, **SD15, **mc)
@@ -329,7 +349,7 @@ def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="repl
     res["map_err"], res["self_map_err"] = worst_cross, worst_self
     kw = dict(prompt=tgt, source_prompt=src, num_inference_steps=T, cross_replace_steps=dict(V["cross_replace"]),
               self_replace_steps=V["self_replace"], use_inversion_attention=True, is_replace_controller=V["is_replace"],
-              blend_th=[0.3, 0.3], save_self_attention=False, guidance_scale=7.5)
+              blend_th=list(th), save_self_attention=False, guidance_scale=7.5)
     if V["blend_words"] is not None:
         kw.update(blend_words=V["blend_words"], blend_self_attention=True)
     if V["eq_params"] is not None:
@@ -341,7 +361,7 @@ def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="repl
 
     def oracle_edit(ost, z):
         c = O.make_edit_controller(tok, [src, tgt], ost, T, V["is_replace"], dict(V["cross_replace"]), V["self_replace"],
-                                   blend_words=V["blend_words"], eq_params=V["eq_params"], blend_th=(0.3, 0.3),
+                                   blend_words=V["blend_words"], eq_params=V["eq_params"], blend_th=tuple(th),
                                    blend_self_attention=V["blend_words"] is not None, save_self_attention=False)
         return O.ddim_edit(ounet, O.DDIMSchedule(T), z, emb_tgt, c, guidance_scale=7.5), c
     # oracle edit on the natively captured maps, from the native inverted latent: isolates the edit pass; masks bit-exact
@@ -357,13 +377,18 @@ def run_fullwidth_case(device, F=3, T=2, pure_edit=False, seed=11, variant="repl
         res["attn_mask_flips_same_maps"], res["attn_mask_total"] = _mask_flips(ctrl.attention_blend.mask_list,
                                                                                 o_ctrl.attention_blend.mask_list)
         res["mask_ones"] = int(sum(int(m.bool().sum()) for m in ctrl.attention_blend.mask_list))
+        res["mask_ones_frac"] = res["mask_ones"] / res["attn_mask_total"]
+        per_mask = [float(m.float().mean()) for m in ctrl.attention_blend.mask_list]
+        res["mask_ones_frac_min_max"] = (min(per_mask), max(per_mask))
     if pure_edit:  # the all-fp32 run: oracle edit on the ORACLE's maps from the oracle's inverted latent
         native2 = pipe(latents=olat[-1].to(device), edit_type="swap", output_type="latent", **kw)["sdimage_output"].images
         p_edit, p_ctrl = oracle_edit(ostore, olat[-1])
         res["edit_err"] = float((native2.float().cpu() - p_edit).abs().max())
+        res["edit_err_q99"] = float(torch.quantile((native2.float().cpu() - p_edit).abs().flatten(), 0.99))
         if V["blend_words"] is not None:
             res["attn_mask_flips"], _ = _mask_flips(pipe.last_edit_controller.attention_blend.mask_list,
                                                     p_ctrl.attention_blend.mask_list)
+            res["attn_mask_flip_rate"] = res["attn_mask_flips"] / res["attn_mask_total"]
     return res
 
 
@@ -380,7 +405,8 @@ def check_fullwidth(res):
     assert res["edit_err_vs_oracle_on_native_maps_q99"] <= EDIT_Q99_TOL * res["edit_scale"], res
     if "attn_mask_flips_same_maps" in res:
         assert res["attn_mask_flips_same_maps"] == 0, res
-        assert 0 < res["mask_ones"] < res["attn_mask_total"], res   # a degenerate (all-0 / all-1) mask would test nothing
+        # a (nearly) all-0 / all-1 mask would test nothing: the live-vs-stored row select must see both kinds of rows in bulk
+        assert FULL_MASK_BAND[0] <= res["mask_ones_frac"] <= FULL_MASK_BAND[1], res
     if "edit_err" in res:
         assert res["edit_err"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
         if "attn_mask_flips" in res:

@@ -68,3 +68,29 @@ int main(){ printf("%zu %zu %zu\n", sizeof(FzAttnSelfDesc), sizeof(FzAttnCrossDe
     assert int(a) == ctypes.sizeof(_native.FzAttnSelfDesc)
     assert int(b) == ctypes.sizeof(_native.FzAttnCrossDesc)
     assert int(c) == ctypes.sizeof(_native.FzGemmDesc)
+
+
+def test_integration_md_stub_matches_the_compiled_header():
+    """INTEGRATION.md shows the ctypes struct a maintainer of the reference would copy.  Extract that very block from the markdown,
+    exec it, and compare field names, field offsets and sizeof with what the C compiler makes of include/fatezero_hip.h -- a short
+    or re-ordered stub would make the kernel read garbage strides."""
+    import tempfile
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"(class FzAttnSelfDesc\(C\.Structure\):.*?\n)\n", md, re.S)
+    assert m, "INTEGRATION.md no longer carries the FzAttnSelfDesc stub"
+    ns = {"C": ctypes}
+    exec(m.group(1), ns)
+    stub = ns["FzAttnSelfDesc"]
+    names = [f[0] for f in stub._fields_]
+    assert names == [f[0] for f in _native.FzAttnSelfDesc._fields_]
+    lines = "\n".join(f'    printf("%zu ", offsetof(FzAttnSelfDesc, {n}));' for n in names)
+    prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "fatezero_hip.h"\nint main(){\n' + lines +
+            '\n    printf("%zu\\n", sizeof(FzAttnSelfDesc)); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        vals = [int(v) for v in subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout.split()]
+    assert [getattr(stub, n).offset for n in names] == vals[:-1]
+    assert ctypes.sizeof(stub) == vals[-1] == ctypes.sizeof(_native.FzAttnSelfDesc)

@@ -38,18 +38,40 @@ def test_rooflines_bookkeeping():
     # 4th field: kv slots really contracted -- frames 0, 1 of every 8-frame clip read their single source frame once (14 of 16 slots)
     summ = {("flash", 8, 2, 14): {"launches": 10, "avg_ms": 0.5, "total_ms": 5.0},
             ("flash", 16, 2, 28): {"launches": 10, "avg_ms": 1.0, "total_ms": 10.0},
-            ("conv3x3", 1e12, 0): {"launches": 4, "avg_ms": 1.0, "total_ms": 4.0},
-            ("capture", 268435456, 0): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2}}
+            ("conv3x3", 1e12, 5e8): {"launches": 4, "avg_ms": 1.0, "total_ms": 4.0},
+            ("gemm_hbm", 6.4e7, 6.4e7): {"launches": 2, "avg_ms": 0.02, "total_ms": 0.04},
+            ("gemm_mfma", 4e11, 1e8): {"launches": 2, "avg_ms": 0.5, "total_ms": 1.0},
+            ("capture", 268435456, 268435456): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2}}
     roof, others = bench.rooflines(summ)
     flops = 4.0 * 4096 * 8192 * 320 * (8 + 16) * 10
     assert abs(roof["achieved"] - flops / 15e-3 / 1e12) < 1e-6 and roof["peak"] == 2500.0 and roof["bound"] == "mfma"
     assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-12 and roof["launches"] == 20
     assert abs(roof["contracted_fraction"] - 0.875) < 1e-12
     assert abs(roof["achieved_over_contracted_tiles"] - 0.875 * roof["achieved"]) < 1e-9
-    byname = {o["kernel"].split(" ")[0]: o for o in others}
-    assert abs(byname["igemm_kernel<..,"]["achieved"] - 1000.0) < 1e-6
-    cap = [o for o in others if o["bound"] == "hbm"][0]
+    conv = [o for o in others if "MODE 1" in o["kernel"]][0]
+    assert abs(conv["achieved"] - 1000.0) < 1e-6 and conv["bound"] == "mfma" and conv["algorithmic_bytes_per_launch"] == 5e8
+    # projection GEMMs are reported per regime: the K <= 640 plain projections against the HBM roof, GEGLU / long-K against MFMA
+    gh = [o for o in others if "HBM class" in o["kernel"]][0]
+    gm = [o for o in others if "MFMA class" in o["kernel"]][0]
+    assert gh["bound"] == "hbm" and gh["peak"] == 8000.0 and abs(gh["achieved"] - 2 * 6.4e7 / 0.04e-3 / 1e9) < 1e-6
+    assert gm["bound"] == "mfma" and abs(gm["achieved"] - 2 * 4e11 / 1e-3 / 1e12) < 1e-6 and abs(gm["algorithmic_GBps"] - 2e8 / 1e-3 / 1e9) < 1e-6
+    cap = [o for o in others if "CAPTURE" in o["kernel"]][0]
     assert abs(cap["achieved"] - 2 * 268435456 / 0.2e-3 / 1e9) < 1e-6 and cap["peak"] == 8000.0
+
+
+def test_gemm_roofline_classes():
+    """K <= 640 plain projections -> HBM class (algorithmic bytes incl. residuals); GEGLU and K >= 1280 -> MFMA class; < 1024 rows: none."""
+    import torch
+    x = torch.zeros(2048, 320, dtype=torch.float16)
+    w = torch.zeros(640, 320, dtype=torch.float16)
+    c = bench.gemm_class(x, w, {})
+    assert c[0] == "gemm_hbm" and c[1] == c[2] == 2.0 * (2048 * 320 + 2048 * 640 + 320 * 640)
+    c = bench.gemm_class(x, w, {"res": x})
+    assert c[2] == 2.0 * (2048 * 320 + 2 * 2048 * 640 + 320 * 640)
+    c = bench.gemm_class(x, torch.zeros(2560, 320, dtype=torch.float16), {"geglu": True})
+    assert c[0] == "gemm_mfma" and c[1] == 2.0 * 2048 * 320 * 2560 and c[2] == 2.0 * (2048 * 320 + 2048 * 1280 + 320 * 2560)
+    assert bench.gemm_class(torch.zeros(2048, 1280, dtype=torch.float16), torch.zeros(320, 1280, dtype=torch.float16), {})[0] == "gemm_mfma"
+    assert bench.gemm_class(torch.zeros(512, 320, dtype=torch.float16), w, {}) is None
 
 
 def test_flash_timer_counts_the_kv_slots_really_contracted(monkeypatch):
@@ -115,17 +137,19 @@ def test_bench_main_two_ranks_auto_promotes_the_frame_sharded_clip():
     assert line["scaling"] == "strong" and line["config"]["parallelism"] == "2-way frame-sharded clip"
     assert line["value"] == fs["value"] and line["ms_per_step"] == fs["ms_per_job"] and "frame_sharded_not_promoted" not in line
     assert line["clips_dp"]["scaling"] == "weak" and line["clips_dp"]["parallelism"] == "dp2 over clips" and line["clips_dp"]["value"] > 0
+    assert line["value_clips_dp"] == line["clips_dp"]["value"] and line["value_frame_sharded"] == fs["value"]  # fixed-definition fields
     ex = fs["exchanges"]
     assert ex["overlapped_with_compute"] > 0 and ex["posted"] == ex["overlapped_with_compute"] + ex["blocking"], ex
 
 
 def test_frame_sharded_promotion_rule():
     def mk():
-        return {"value": 6.8, "ms_per_step": 2350.0, "scaling": "weak", "config": {"parallelism": "dp2 over clips"}}
+        return {"metric": "edited frames/sec", "value": 6.8, "ms_per_step": 2350.0, "scaling": "weak", "config": {"parallelism": "dp2 over clips"}}
     good = {"value": 4.7, "ms_per_job": 1700.0, "outputs_finite": True}
     line = mk()
     assert bench.promote_frame_sharded(line, good, 2) is True
     assert line["value"] == 4.7 and line["ms_per_step"] == 1700.0 and line["scaling"] == "strong"
+    assert "frames sharded over 2 GPUs" in line["metric"] and "value_clips_dp" in line["metric"]  # the changed definition is named
     assert line["clips_dp"] == {"value": 6.8, "ms_per_step": 2350.0, "scaling": "weak", "parallelism": "dp2 over clips"}
     assert line["config"]["parallelism"] == "2-way frame-sharded clip"
     line = mk()  # two GPUs on one clip slower than one GPU on it: reported, not promoted

@@ -238,6 +238,36 @@ def test_gemm_geglu(tile_cfg):
         KC.case_gemm(DEV, rows=300, k=320, o=512, geglu=True, tile_cfg=tile_cfg)  # 10 K steps, ragged row tile, two column tiles
 
 
+@pytest.mark.parametrize("kw", [dict(n=2, l=64, k=64, c=64), dict(n=3, l=128, k=96, c=128, tile_cfg=212222),
+                                dict(n=2, l=256, k=64, c=320, tile_cfg=254222), dict(n=2, l=256, k=64, c=320, tile_cfg=254122),
+                                dict(n=1, l=192, k=40, c=128, tile_cfg=222222, ldx_extra=8), dict(n=2, l=64, k=72, c=128, tile_cfg=224223)])
+def test_gemm_qkvt_one_launch(kw):
+    """q | k | V^T of a self-attention in one launch: the transposed column tiles of every instantiated tile shape, ragged K, a strided
+    x view -- vs fp32 torch and bit for bit vs the two launches it replaces."""
+    r = KC.case_gemm_qkvt(DEV, **kw)
+    assert r["qk_bit_equal"] and r["vt_bit_equal"], r
+
+
+def test_gemm_qkvt_refuses_what_it_cannot_carry():
+    x = torch.zeros(2, 72, 64, dtype=torch.float16)  # 72 tokens per frame: V^T rows would need zero padding to 128
+    w = torch.zeros(192, 64, dtype=torch.float16)
+    assert not K.gemm_qkvt_ok(x, w, 128)
+    with pytest.raises(ValueError):
+        K.gemm_qkvt(x, w, 128)
+    with pytest.raises(RuntimeError):  # a tile whose width does not divide the k | v boundary
+        K.gemm_qkvt(torch.zeros(2, 64, 64, dtype=torch.float16), w, 128, tile_cfg=244222)
+
+
+@pytest.mark.parametrize("rows,o,tile_cfg,split_k", [(300, 136, 212222, 8), (512, 128, 212222, 2), (256, 136, 222222, 4), (700, 640, 254122, 4),
+                                                     (130, 72, 212222, 16)])
+def test_gemm_split_k_slices_mapped_onto_xcds(rows, o, tile_cfg, split_k):
+    """Split-K launches whose workgroup count is a multiple of 8 run on the FLAT grid (csrc/igemm.hip: K slices -> XCDs): whole slices per
+    XCD (split 8, 16), half / quarter slices (split 2, 4), ragged tile counts; the result must not depend on the mapping."""
+    import os
+    a = KC.case_gemm(DEV, rows=rows, k=1024, o=o, n_res=1, tile_cfg=tile_cfg, split_k=split_k)
+    assert a["max_err"] < 4e-3 * 64
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)

@@ -262,6 +262,17 @@ def test_pingpong_loop_bit_equal_to_ring_loop(ring, pp):
         assert torch.equal(K.gemm(x, w, b, tile_cfg=ring), K.gemm(x, w, b, tile_cfg=pp)), (rows, k, o)
 
 
+@pytest.mark.parametrize("kw", [dict(n=8, l=4096, k=320, c=320), dict(n=16, l=4096, k=320, c=320), dict(n=8, l=1024, k=640, c=640),
+                                dict(n=16, l=256, k=1280, c=1280), dict(n=8, l=64, k=1280, c=1280), dict(n=2, l=5184, k=320, c=320),
+                                dict(n=4, l=1024, k=640, c=640, tile_cfg=254222), dict(n=4, l=1024, k=640, c=640, tile_cfg=222222)])
+def test_gemm_qkvt_one_launch(kw):
+    """q | k | V^T of a self-attention in one launch at every SD-1.x level (8- and 16-frame launches, 576^2's 5184 tokens): vs fp32
+    torch and bit for bit vs the two launches it replaces (same products, same K order, fp32 accumulation, one rounding)."""
+    r = KC.case_gemm_qkvt(DEV, **kw)
+    print("qkvt", kw, r)
+    assert r["qk_bit_equal"] and r["vt_bit_equal"], r
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=8, l=4096, k=320, c=320, lp=4096)
     KC.case_gemm_vt(DEV, n=4, l=1024, k=640, c=640, lp=1024)
@@ -292,3 +303,30 @@ def test_frame_shard_kernel_forms(lo, hi):
                                 dict(rows=1000, c=640, o=640, tile_cfg=212222), dict(rows=1000, c=640, o=640, tile_cfg=244222)])
 def test_gemm_layernorm_fusion(kw):
     print(KC.case_gemm_ln(DEV, **kw))
+
+
+def test_launch_stream_follows_torch_current_stream_split_k():
+    """kernels._stream reads PyTorch's current stream of the operand's device PER LAUNCH, and the split-K scratch is keyed on that same
+    handle.  Two side streams each run a split-K GEMM (fp32 slabs + reduce kernel) on their own operands, repeatedly and
+    concurrently: with a stale cached stream handle the launches of stream B would land on stream A -- racing B's operand producer --
+    and with a shared scratch the two reduce kernels would sum each other's slabs."""
+    torch.manual_seed(3)
+    rows, k, o = 512, 2560, 1280  # long K, few rows: the chooser splits K (forced below as well)
+    w = (torch.randn(o, k, device=DEV) * 0.03).half()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs, refs = {}, {}
+    for rep in range(4):
+        for i, s in enumerate((s1, s2)):
+            with torch.cuda.stream(s):
+                x = (torch.randn(rows, k, device=DEV) * (1 + i)).half()  # produced ON the side stream
+                assert K._raw_stream(0) == s.cuda_stream
+                outs[(rep, i)] = K.gemm(x, w, split_k=4)
+                refs[(rep, i)] = x
+    torch.cuda.synchronize()
+    assert len({k_[1] for k_ in K._ws}) >= 2, "each stream must have got its own split-K scratch"
+    for key, y in outs.items():
+        want = refs[key].float() @ w.float().t()
+        err = float((y.float() - want).abs().max()) / float(want.abs().max())
+        assert err < 4e-3, (key, err)
+    # back on the default stream the default handle is used again
+    assert K._raw_stream(0) == torch.cuda.current_stream().cuda_stream

@@ -35,13 +35,16 @@ def test_blend_mask_png_dumps(name, tmp_path):
     assert res["mask_pngs_checked"] > 0
 
 
-@pytest.mark.parametrize("variant", ["replace_blend", "refine_reweight_mid"])
+@pytest.mark.parametrize("variant", ["replace_blend", "refine_reweight_mid", "cfg2_8f"])
 def test_fullwidth_sd15_pipeline_vs_oracle(variant):
     """BASELINE architecture at real width (d = 40 / 80 / 160, lora 160, 64x64 latents), THREE frames (two distinct K/V
     source frames, GroupNorm over three), 2 + 2 steps -- native HIP path vs oracle.OracleUNet / ddim_inversion / ddim_edit:
     cfg2's model config with the bench's controller (Replace + blend-masked self-attention), and cfg1 / cfg3's model config
-    ({SparseCausalAttention_index: ['mid'], least_sc_channel: 640}) with Refine + Reweight.  About 4-5 minutes of CPU oracle
-    time each.  FZ_FULL_PARITY=1 adds the all-fp32 edit run (oracle edit on the oracle's own maps)."""
+    ({SparseCausalAttention_index: ['mid'], least_sc_channel: 640}) with Refine + Reweight.  `cfg2_8f`: the JUDGED launch shapes --
+    F = 8 (one 8-frame inversion launch, one 16-frame CFG edit launch per layer: the tiles, flash dispatch order and one-launch
+    GroupNorms bench.py's job takes), 1 + 1 steps, always with the all-fp32 leg.  The blend threshold is set so that 20-80 % of the
+    mask rows keep the live attention (asserted).  FZ_FULL_PARITY=1 adds the all-fp32 edit run (oracle edit on the oracle's own
+    maps) to the 3-frame cases as well."""
     import os
     res = PC.run_fullwidth_case("cuda", pure_edit=os.environ.get("FZ_FULL_PARITY") == "1", variant=variant)
     print("fullwidth", res)
