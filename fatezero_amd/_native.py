@@ -99,6 +99,8 @@ _SIGS = {
     "fz_transpose_pad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P]),
     "fz_latent_update": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, C.c_int, C.c_int, _P]),
     "fz_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "fz_peer_put": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int, C.c_uint32, _P, _P]),
+    "fz_peer_wait": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_int64, _P]),
     "fz_version": (C.c_char_p, []),
 }
 

@@ -24,6 +24,7 @@
 #include "fz_rt.h"
 #include <type_traits>
 #include <atomic>
+#include <utility>
 #include <stdlib.h>
 #include "../../include/fatezero_hip.h"
 
@@ -79,6 +80,8 @@ struct IgArgs {
     int Cin, taps, kchunks;
     int N, Hi, Wi, Ho, Wo, stride, upsample, fpb;
     int ksplit, tiles_a;
+    int b_fastest;        // tile order inside an XCD's run of tiles: 0 = a-tile fastest (consecutive tiles share their B rows), 1 = b-tile fastest
+    int tiles_b;
     int nt_flat;          // > 0: split-K launch with a FLAT grid of nt_flat * ksplit workgroups, K slices mapped onto XCDs (ig_launch)
     // LayerNorm fused around the GEMM (fz_gemm_ln): the B rows are the RAW LayerNorm input, A holds gamma * W
     const float* ln_in;   // per B row: ln_blocks x (sum, sum of squares) of its 64-channel blocks, or null
@@ -169,7 +172,8 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
         lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
         ks = blockIdx.y;
     }
-    const int ta = lid % g.tiles_a, tb = lid / g.tiles_a;
+    // tile order: which operand the consecutive tiles of an XCD share (ig_launch picks the one that moves fewer bytes into the L2s)
+    const int ta = g.b_fastest ? lid / g.tiles_b : lid % g.tiles_a, tb = g.b_fastest ? lid - ta * g.tiles_b : lid / g.tiles_a;
     const int a0 = ta * C::BA;
     const int64_t b0 = (int64_t)tb * C::BB;
     const int z = blockIdx.z;
@@ -1096,8 +1100,31 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
         if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
 #endif
+    // Tile order.  An XCD runs a contiguous run of `chunk` tiles (of one K slice); with the a-tile fastest the run spans
+    // min(tiles_a, chunk) weight panels and ~chunk / tiles_a row panels, with the b-tile fastest the other way round, and every XCD
+    // fetches what its run spans into its own L2: pick the order with fewer bytes.  Weight-heavy launches (the GEGLU projection of
+    // the 16^2 level: 26 MB of weights against 5 MB of rows; q|k|v 1280 -> 3840) stream 1/8 of the weights per XCD instead of all of
+    // them; row-heavy launches (everything at 64^2) keep the a-fastest order.
+    g.tiles_b = (int)tiles_b;
+    {
+        static const bool order_off = getenv("FZ_IGEMM_NO_TILE_ORDER") != nullptr;  // A/B switch (tuning only)
+        const double wbytes = 2.0 * g.Ma * (double)g.lda, xbytes = 2.0 * (double)g.Nb * g.Cin * (g.taps > 1 ? 1.3 : 1.0);
+        const double xcds_per_slice = g.ksplit >= 8 ? 1.0 : 8.0 / g.ksplit;
+        const double chunk = (double)nt / xcds_per_slice;
+        auto spans = [&](double fast, double slow) {  // fraction of the fast / slow operand panels one XCD's run touches
+            const double f = chunk < fast ? chunk / fast : 1.0;
+            double sl = (chunk / fast + (chunk < fast ? 0.0 : 0.5)) / slow;
+            sl = sl > 1.0 ? 1.0 : (sl < 1.0 / slow ? 1.0 / slow : sl);
+            return std::pair<double, double>(f, sl);
+        };
+        const auto af = spans((double)g.tiles_a, (double)tiles_b), bf = spans((double)tiles_b, (double)g.tiles_a);
+        const double cost_a = wbytes * af.first + xbytes * af.second, cost_b = xbytes * bf.first + wbytes * bf.second;
+        g.b_fastest = (!order_off && batch == 1 && cost_b < 0.8 * cost_a) ? 1 : 0;
+    }
     static const bool xcd_ks_off = getenv("FZ_IGEMM_NO_XCD_KS") != nullptr;  // A/B switch of the K-slice -> XCD mapping (tuning only)
-    const bool flat = g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
+    // (3x3 convolutions only: same-box A/B, profiles/r04_xcd_ks_ab.txt -- convolutions with Cin >= 1280 at the 16^2 / 8^2 levels gain
+    // 3-6 %, the 640-wide ones are even; the small split-K projections and temporal convolutions -- 10-25 us launches -- lost up to 15 %)
+    const bool flat = (MODE == 1 || MODE == 3) && g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
     g.nt_flat = flat ? (int)nt : 0;
     dim3 grid(flat ? (unsigned)(nt * g.ksplit) : (unsigned)nt, flat ? 1u : (unsigned)g.ksplit, (unsigned)batch), block(C::T);
     FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT>), grid, block, lds, stream, g);

@@ -282,6 +282,20 @@ int fz_latent_update(float* z, const void* eps_u, const void* eps_c, float guida
  * acc (float) += x (fp16), n elements. */
 int fz_accumulate(float* acc, const void* x, int64_t n, void* stream);
 
+/* One-sided exchanges between the GPUs that share ONE frame-sharded clip (csrc/peer.hip): every rank owns a symmetric
+ * heap its peers have mapped (hipIpc over xGMI).  The couplings they carry: 5-D GroupNorm statistics (resnet.py:338,369), the halo
+ * frames of the k=3 temporal convolutions (lora.py:31-54), K / V^T of neighbour and anchor frames (attention.py:374-388), K | V of the
+ * temporal attention (attention.py:327-337).
+ *   fz_peer_put   copy `bytes` (a multiple of 16; src and every dst 16-byte aligned) from src to dst[0..n_dst) -- addresses inside the
+ *                 peers' (or the own) heap --, make them visible system-wide, then store `epoch` to flags[0..n_dst): the flag word each
+ *                 receiver reserves for THIS sender.  done_counter: a zero-initialised uint32 in local memory, one per put in flight.
+ *   fz_peer_wait  one workgroup polling flags[r] for every bit r of sender_mask until (int32)(flags[r] - epoch) >= 0; kernels queued
+ *                 behind it on `stream` may read what those senders put.  timeout_us > 0 bounds the spin: on expiry err[0] = 1.
+ * Epochs only grow (wrap-safe comparison); flags are never reset. */
+int fz_peer_put(const void* src, int64_t bytes, void* const* dst, uint32_t* const* flags, int n_dst, uint32_t epoch,
+                uint32_t* done_counter, void* stream);
+int fz_peer_wait(const uint32_t* flags, uint64_t sender_mask, uint32_t epoch, uint32_t* err, int64_t timeout_us, void* stream);
+
 const char* fz_version(void);
 
 #ifdef __cplusplus

@@ -35,20 +35,26 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{out_dir}/{ctr}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == ctr:
-                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"]), int(r.get("Grid_Size", 0) or 0)))
     rows.sort()
     log = json.load(open(f"{out_dir}/launchlog_{ctr}.json"))
     mode0 = [r for r in rows if klass(r[1]) == "MODE0"]
     assert len(mode0) == len(log), (ctr, len(mode0), len(log))
     it = iter(log)
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for did, name, val in rows:
+    shapes = collections.defaultdict(lambda: [0, 0.0])  # per (class, kernel template, grid size): which launch shapes over-fetch
+    for did, name, val, grid in rows:
         c = klass(name)
         if c == "MODE0":
             c = next(it)
         agg[c][0] += 1
         agg[c][1] += val
+        if "igemm_kernel" in name:
+            m = re.search(r"igemm_kernel<([^>]*)>", name)
+            shapes[(c, m.group(1) if m else name[:40], grid)][0] += 1
+            shapes[(c, m.group(1) if m else name[:40], grid)][1] += val
     res[ctr] = agg
+    res[ctr + "_shapes"] = shapes
 classes = {}
 for c in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
     nf, f = res["FETCH_SIZE"].get(c, [0, 0.0])
@@ -57,7 +63,14 @@ for c in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
     classes[c] = {"launches": n, "FETCH_SIZE_KiB_per_launch": f / max(nf, 1), "WRITE_SIZE_KiB_per_launch": w / max(nw, 1),
                   "traffic_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
                   "traffic_GB_per_job": (2.0 * f + w) * 1024.0 / 1e9}
-json.dump({"what": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) over `bench.py --steps 1 --warmup 0 --ddim-steps {ddim}`: "
+shape_rows = []
+for key in sorted(set(res["FETCH_SIZE_shapes"]) | set(res["WRITE_SIZE_shapes"])):
+    nf, f = res["FETCH_SIZE_shapes"].get(key, [0, 0.0])
+    nw, w = res["WRITE_SIZE_shapes"].get(key, [0, 0.0])
+    shape_rows.append({"class": key[0], "igemm_kernel": key[1], "grid_threads": key[2], "launches": max(nf, nw),
+                       "fetch_MB_per_launch": 2.0 * f / max(nf, 1) * 1024 / 1e6, "write_MB_per_launch": w / max(nw, 1) * 1024 / 1e6})
+shape_rows.sort(key=lambda r: -(r["fetch_MB_per_launch"] + r["write_MB_per_launch"]) * r["launches"])
+json.dump({"igemm_launch_shapes": shape_rows[:80], "what": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) over `bench.py --steps 1 --warmup 0 --ddim-steps {ddim}`: "
                    "every dispatch of the job, attributed by kernel name (projection GEMMs: by bench.py's launch log); "
                    "traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; gfx950 tallies a 128-B read request as 64 B)",
            "classes": classes}, open(out_json, "w"), indent=1)

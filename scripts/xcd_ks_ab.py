@@ -25,24 +25,30 @@ def timeit(fn, iters=20, warm=5):
     return st.elapsed_time(en) / iters * 1e3  # us
 
 
-dev = "cuda"
-res = {}
-for (n, hw, cin, cout) in [(8, 32, 640, 640), (8, 32, 1280, 640), (8, 32, 1920, 640), (8, 16, 1280, 1280), (8, 16, 2560, 1280), (8, 16, 1920, 1280),
-                           (8, 8, 1280, 1280), (8, 8, 2560, 1280), (16, 32, 640, 640), (16, 32, 1920, 640), (16, 16, 1280, 1280),
-                           (16, 16, 2560, 1280), (16, 8, 1280, 1280), (16, 8, 2560, 1280)]:
-    x = torch.randn(n, hw * hw, cin).half().to(dev)
-    wt = K.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3) * 0.02).half().to(dev))
-    b = torch.zeros(cout).half().to(dev)
-    res[f"conv n{n} {hw}^2 {cin}->{cout}"] = timeit(lambda: K.conv3x3(x, wt, b, hw=(hw, hw)))
-for (rows, k, o) in [(8192, 2560, 640), (16384, 2560, 640), (2048, 5120, 1280), (4096, 5120, 1280), (512, 5120, 1280), (1024, 5120, 1280),
-                     (2048, 1280, 1280), (4096, 1280, 1280), (512, 1280, 1280), (1024, 1280, 1280), (2048, 1280, 3840), (4096, 1280, 3840)]:
-    x = torch.randn(rows, k).half().to(dev)
-    w = (torch.randn(o, k) * 0.02).half().to(dev)
-    r = torch.randn(rows, o).half().to(dev)
-    res[f"gemm+res {rows}x{k}->{o}"] = timeit(lambda: K.gemm(x, w, None, res=r))
-for (n, tok, cin, cout) in [(8, 256, 1280, 160), (8, 256, 160, 1280), (8, 64, 1280, 160), (8, 64, 160, 1280), (8, 1024, 640, 160), (8, 1024, 160, 640),
-                            (16, 256, 1280, 160), (16, 256, 160, 1280), (16, 1024, 640, 160)]:
-    x = torch.randn(n, tok, cin).half().to(dev)
-    w = (torch.randn(cout, 3, cin) * 0.02).half().to(dev)
-    res[f"tconv n{n} tok{tok} {cin}->{cout}"] = timeit(lambda: K.temporal_conv3(x, w, clip_len=8))
-print(json.dumps({"xcd_ks": os.environ.get("FZ_IGEMM_NO_XCD_KS") is None, "us": {k: round(v, 2) for k, v in res.items()}}))
+def main():
+    dev = "cuda"
+    res = {}
+    for (n, hw, cin, cout) in [(8, 32, 640, 640), (8, 32, 1280, 640), (8, 32, 1920, 640), (8, 16, 1280, 1280), (8, 16, 2560, 1280), (8, 16, 1920, 1280),
+                               (8, 8, 1280, 1280), (8, 8, 2560, 1280), (16, 32, 640, 640), (16, 32, 1920, 640), (16, 16, 1280, 1280),
+                               (16, 16, 2560, 1280), (16, 8, 1280, 1280), (16, 8, 2560, 1280)]:
+        x = torch.randn(n, hw * hw, cin).half().to(dev)
+        wt = K.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3) * 0.02).half().to(dev))
+        b = torch.zeros(cout).half().to(dev)
+        res[f"conv n{n} {hw}^2 {cin}->{cout}"] = timeit(lambda: K.conv3x3(x, wt, b, hw=(hw, hw)))
+    for (rows, k, o) in [(8192, 2560, 640), (16384, 2560, 640), (2048, 5120, 1280), (4096, 5120, 1280), (512, 5120, 1280), (1024, 5120, 1280),
+                         (2048, 1280, 1280), (4096, 1280, 1280), (512, 1280, 1280), (1024, 1280, 1280), (2048, 1280, 3840), (4096, 1280, 3840)]:
+        x = torch.randn(rows, k).half().to(dev)
+        w = (torch.randn(o, k) * 0.02).half().to(dev)
+        r = torch.randn(rows, o).half().to(dev)
+        res[f"gemm+res {rows}x{k}->{o}"] = timeit(lambda: K.gemm(x, w, None, res=r))
+    for (n, tok, cin, cout) in [(8, 256, 1280, 160), (8, 256, 160, 1280), (8, 64, 1280, 160), (8, 64, 160, 1280), (8, 1024, 640, 160), (8, 1024, 160, 640),
+                                (16, 256, 1280, 160), (16, 256, 160, 1280), (16, 1024, 640, 160)]:
+        x = torch.randn(n, tok, cin).half().to(dev)
+        w = (torch.randn(cout, 3, cin) * 0.02).half().to(dev)
+        res[f"tconv n{n} tok{tok} {cin}->{cout}"] = timeit(lambda: K.temporal_conv3(x, w, clip_len=8))
+    print(json.dumps({"xcd_ks": os.environ.get("FZ_IGEMM_NO_XCD_KS") is None, "us": {k: round(v, 2) for k, v in res.items()}}))
+
+
+
+if __name__ == "__main__":
+    main()

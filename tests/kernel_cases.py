@@ -560,7 +560,7 @@ def case_gemm_qkvt(device, *, n, l, k, c, tile_cfg=0, seed=0, ldx_extra=0):
     e_qk = float((qk.float().cpu() - ref[..., : 2 * c]).abs().max())
     e_vt = float((vt.float().cpu() - ref[..., 2 * c:].transpose(1, 2)).abs().max())
     assert e_qk < 4e-3 * scale and e_vt < 4e-3 * scale, (e_qk, e_vt, scale)
-    qk2 = K.gemm(x, w[: 2 * c], tile_cfg=tile_cfg)
+    qk2 = K.gemm(x, w[: 2 * c], tile_cfg=tile_cfg, split_k=1)  # (the fused form never splits K: same summation order)
     vt2 = K.gemm_vt(x, w[2 * c:], l)
     return {"qk_err": e_qk, "vt_err": e_vt, "qk_bit_equal": bool(torch.equal(qk, qk2)), "vt_bit_equal": bool(torch.equal(vt, vt2)),
             "vt_max_diff_vs_two_launches": float((vt.float() - vt2.float()).abs().max())}

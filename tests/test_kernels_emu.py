@@ -260,12 +260,18 @@ def test_gemm_qkvt_refuses_what_it_cannot_carry():
 
 @pytest.mark.parametrize("rows,o,tile_cfg,split_k", [(300, 136, 212222, 8), (512, 128, 212222, 2), (256, 136, 222222, 4), (700, 640, 254122, 4),
                                                      (130, 72, 212222, 16)])
-def test_gemm_split_k_slices_mapped_onto_xcds(rows, o, tile_cfg, split_k):
-    """Split-K launches whose workgroup count is a multiple of 8 run on the FLAT grid (csrc/igemm.hip: K slices -> XCDs): whole slices per
-    XCD (split 8, 16), half / quarter slices (split 2, 4), ragged tile counts; the result must not depend on the mapping."""
-    import os
+def test_gemm_split_k_ragged_tile_counts(rows, o, tile_cfg, split_k):
+    """Split-K projections with workgroup counts that are multiples of 8 (they stay on the 2-D grid: the flat K-slice -> XCD grid is
+    shipped for the convolutions only, below)."""
     a = KC.case_gemm(DEV, rows=rows, k=1024, o=o, n_res=1, tile_cfg=tile_cfg, split_k=split_k)
     assert a["max_err"] < 4e-3 * 64
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,tile_cfg,split_k", [(2, 8, 8, 128, 64, 212222, 8), (2, 16, 16, 64, 128, 222222, 2), (4, 8, 8, 96, 320, 254122, 4),
+                                                             (1, 16, 8, 64, 640, 254222, 8)])
+def test_conv3x3_split_k_slices_mapped_onto_xcds(n, h, w, cin, cout, tile_cfg, split_k):
+    """The same for the convolutions, the launches the flat grid is shipped for (both K orders)."""
+    KC.case_conv3x3(DEV, n=n, h=h, w=w, cin=cin, cout=cout, with_temb=True, with_res=True, fpb=n, tile_cfg=tile_cfg, split_k=split_k)
 
 
 def test_gemm_transposed_output():
