@@ -412,6 +412,31 @@ def rooflines(summ):
     return roof, others
 
 
+def make_frame_shard(fz_dist, frames, transport, heap_gb, device):
+    """FrameShard for this job + the transport that carries its exchanges.  'peer' / 'auto': map the peers' symmetric heaps and run ONE
+    small all-gather through them as a self-test (bounded wait); 'auto' falls back to the collectives when that fails."""
+    shard = fz_dist.FrameShard(frames)
+    used = "rccl"
+    if transport in ("peer", "auto") and shard.world > 1:
+        try:
+            shard.enable_peer_transport(nbytes=int(heap_gb * (1 << 30)), device=device, timeout_us=10_000_000)
+            probe = torch.full((1, shard.n_local, 8), float(shard.rank + 1), device=device)
+            got = shard.all_gather_frames(probe, tag="selftest")
+            torch.cuda.synchronize()
+            shard.heap.check()
+            want = torch.cat([torch.full((1, len(shard.frames_of(r)), 8), float(r + 1)) for r in range(shard.world)], 1)
+            if not torch.equal(got.cpu(), want):
+                raise RuntimeError("peer transport self-test returned wrong data")
+            used = "peer"
+        except Exception as e:  # noqa: BLE001 -- whatever went wrong, the collectives still work
+            if transport == "peer":
+                raise
+            shard.heap = None
+            used = f"rccl (peer transport unavailable: {e!r})"
+    shard.stats = {"posted": 0, "overlapped": 0, "blocking": 0, "device_side": 0}
+    return shard, used
+
+
 def promote_frame_sharded(line, fs, world):
     """`--shard auto`, frames >= 2 x GPUs: the frame-sharded clip becomes the primary number (one clip, strong scaling) and the
     one-clip-per-GPU measurement taken first stays in the line as `clips_dp` -- provided the sharded job completed, is finite, and the
@@ -463,6 +488,11 @@ def main():
                          "(default) measures clips first, then the frame-sharded clip (K timed jobs under a watchdog), and reports the "
                          "frame-sharded number as `value` when frames >= 2 x GPUs, it completed and was not slower than ONE GPU on the clip -- the "
                          "other one rides beside it")
+    ap.add_argument("--transport", choices=["auto", "peer", "rccl"], default="auto",
+                    help="what carries the exchanges of a frame-sharded clip: 'peer' = one-sided puts into peer-mapped symmetric heaps "
+                         "(csrc/peer.hip: no collective call on the data path), 'rccl' = torch.distributed collectives; 'auto' = peer when "
+                         "its self-test round trip succeeds, else rccl (the line says which)")
+    ap.add_argument("--peer-heap-gb", type=float, default=2.0, help="symmetric heap per GPU for --transport peer")
     ap.add_argument("--no-frame-shard-probe", action="store_true",
                     help="N > 1, --shard clips: skip the extra frame-sharded job reported under `frame_sharded` (it runs AFTER the clips "
                          "measurement is complete, under a 120 s watchdog that prints the clips line and exits if the exchange path stalls)")
@@ -516,9 +546,10 @@ def main():
         dist.broadcast(ref, 0)
         assert torch.allclose(ref, chk), "ranks built different weights"
 
+    transport_used = None
     if by_frames:
         from fatezero_amd import dist as fz_dist
-        pipe.frame_shard = fz_dist.FrameShard(args.frames)
+        pipe.frame_shard, transport_used = make_frame_shard(fz_dist, args.frames, args.transport, args.peer_heap_gb, device)
     wsteps = args.warmup_ddim_steps or args.ddim_steps
     for _ in range(args.warmup):
         run_job(pipe, z0, wsteps, device)
@@ -595,7 +626,7 @@ def main():
                            "parallelism": ("single GPU" if world == 1 else
                                            f"{world}-way frame-sharded clip" if by_frames else f"dp{world} over clips"),
                            "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite,
-                           "n_ranks_seen": n_ranks_seen},
+                           "n_ranks_seen": n_ranks_seen, **({"transport": transport_used} if transport_used else {})},
                 "roofline": roof, "rooflines": others, "cpu_baseline": None}
         if n_edit2 is not None:
             line["config_faithful_n_edit_2"] = n_edit2
@@ -622,11 +653,19 @@ def main():
         dog = threading.Timer(120.0 + (12.0 * args.steps if auto_frames else 0.0), bail)
         dog.daemon = True
         dog.start()
+        # the frame-sharded path has never run on more than one GPU: a rank that dies in it (GPU fault -> SIGABRT, then the launcher's
+        # SIGTERM to the others) must not take the finished clips measurement with it
+        import signal
+        for sig in (signal.SIGTERM, signal.SIGABRT):
+            try:
+                signal.signal(sig, lambda *_: bail())
+            except (ValueError, OSError):
+                pass
         fs = None
         try:
             from fatezero_amd import dist as fz_dist
             zc = torch.randn(1, 4, args.frames, L, L, generator=torch.Generator().manual_seed(1234)).to(device)
-            pipe.frame_shard = fz_dist.FrameShard(args.frames)
+            pipe.frame_shard, transport_used = make_frame_shard(fz_dist, args.frames, args.transport, args.peer_heap_gb, device)
             run_job(pipe, zc, 2, device)  # warm-up: RCCL channels, allocator
             njobs = args.steps if auto_frames else 1
             barrier()
@@ -639,8 +678,11 @@ def main():
             st = pipe.frame_shard.stats
             fs = {"value": args.frames * njobs / float(tf.item()), "unit": "frames/s", "ms_per_job": float(tf.item()) * 1e3 / njobs,
                   "jobs_timed": njobs, "scaling": "strong", "parallelism": f"{world}-way frame-sharded clip ({args.frames} frames)",
-                  "outputs_finite": bool(torch.isfinite(out.float()).all()),
-                  "exchanges": {"posted": st["posted"], "overlapped_with_compute": st["overlapped"], "blocking": st["blocking"]}}
+                  "outputs_finite": bool(torch.isfinite(out.float()).all()), "transport": transport_used,
+                  "exchanges": {"posted": st["posted"], "overlapped_with_compute": st["overlapped"], "blocking": st["blocking"],
+                                "device_side": st.get("device_side", 0)}}
+            if pipe.frame_shard.heap is not None:
+                pipe.frame_shard.heap.check()
         except Exception as e:
             fs = {"error": repr(e)}
         if done.acquire(blocking=False):

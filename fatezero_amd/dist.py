@@ -15,8 +15,16 @@ Two ways to use N GPUs:
       frames is recomputed locally instead of exchanged a second time);
     - temporal attention over all F frames per pixel -> all-gather of that layer's K and V.
   CFG, the DDIM update, blend masks (normalised per frame) and the latent blend are per-frame and need nothing.
+
+Two transports carry those exchanges.  "rccl" (torch.distributed collectives / batched isend-irecv; gloo in the CPU tests) is the
+portable one.  "peer" (`FrameShard.enable_peer_transport()`, csrc/peer.hip) is the MI355X-native one: every rank owns a symmetric heap
+that its peers map (hipIpc over xGMI; shared-memory files on the CPU emulation), a sender copies its message straight into the
+receivers' heaps with a tiny kernel that then publishes an epoch flag, a receiver queues a one-workgroup wait kernel in front of the
+consumer -- no collective call, no host round trip: the ~100 small messages per UNet forward cost two tiny launches each instead of an
+RCCL collective each, and the MB-sized ones ride on a side stream under the projections that follow.
 """
 import contextlib
+import math
 import os
 from typing import Callable, List, Optional, Sequence
 
@@ -101,7 +109,15 @@ class FrameShard:
         self.f0, self.f1 = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.n_local = self.f1 - self.f0
         self.max_local = base + (1 if rem else 0)
-        self.stats = {"posted": 0, "overlapped": 0, "blocking": 0}
+        self.stats = {"posted": 0, "overlapped": 0, "blocking": 0, "device_side": 0}
+        self.heap: Optional["PeerHeap"] = None
+
+    def enable_peer_transport(self, nbytes: int = 1 << 30, device=None, timeout_us: int = 20_000_000):
+        """Carry every exchange of this shard through peer-mapped symmetric heaps (csrc/peer.hip) instead of collectives: a collective
+        call over ALL ranks of the group -- they exchange the IPC handles of their heaps here, once."""
+        if self.world > 1 and self.heap is None:
+            self.heap = PeerHeap(self.world, self.rank, nbytes, device, group=self.group, timeout_us=timeout_us)
+        return self
 
     # -- bookkeeping ---------------------------------------------------------------------------------------------
     def frames_of(self, rank: int) -> range:
@@ -132,6 +148,8 @@ class FrameShard:
         import torch.distributed as dist
         if self.world == 1:
             return Pending(self, [], lambda: x_local, tag=tag)
+        if self.heap is not None:
+            return self._peer_all_gather(x_local, tag)
         b = x_local.shape[0]
         rest = tuple(x_local.shape[2:])
         if self.n_local == self.max_local:
@@ -160,6 +178,8 @@ class FrameShard:
                 return g
             return None if zero_outside else min(max(g, 0), self.clip_len - 1)
 
+        if self.heap is not None and self.world > 1:
+            return self._peer_fetch(x_local, wanted, resolve, tag)
         mine = [resolve(g) for g in wanted(self.rank)]
         b, rest = x_local.shape[0], tuple(x_local.shape[2:])
         out = x_local.new_zeros((b, len(mine)) + rest)
@@ -192,6 +212,74 @@ class FrameShard:
     def fetch_frames(self, x_local: torch.Tensor, wanted: Callable[[int], Sequence[int]], *,
                      zero_outside: bool = False, tag: str = "other") -> torch.Tensor:
         return self.fetch_frames_async(x_local, wanted, zero_outside=zero_outside, tag=tag).wait()
+
+    # -- the same two primitives over the peer-mapped heaps (csrc/peer.hip) ---------------------------------------
+    def _peer_all_gather(self, x_local: torch.Tensor, tag: str) -> "PeerPending":
+        heap = self.heap
+        b, rest = x_local.shape[0], tuple(x_local.shape[2:])
+        if self.n_local == self.max_local:
+            mine = x_local.contiguous()
+        else:  # ragged partition: every rank's block has the size of the largest
+            mine = x_local.new_zeros((b, self.max_local) + rest)
+            mine[:, : self.n_local] = x_local
+        block = _round16(mine.numel() * mine.element_size())
+        off = heap.alloc(self.world * block)
+        epoch = heap.next_epoch()
+        heap.put(mine, off + self.rank * block, list(range(self.world)), epoch)  # into every heap, the own one included
+
+        def finish():
+            heap.wait(list(range(self.world)), epoch)
+            blocks = heap.view(off, self.world * block).view(self.world, block)[:, : mine.numel() * mine.element_size()]
+            allb = blocks.contiguous().view(mine.dtype).view((self.world, b, self.max_local) + rest)
+            return torch.cat([allb[r, :, : len(self.frames_of(r))] for r in range(self.world)], dim=1)
+        return PeerPending(self, finish, tag)
+
+    def _peer_fetch(self, x_local: torch.Tensor, wanted, resolve, tag: str) -> "PeerPending":
+        """Every (sender, receiver) pair with frames to move is ONE message: the frames in the receiver's slot order, written into the
+        region of the receiver's heap that the (pure, rank-independent) plan assigns to that sender."""
+        heap = self.heap
+        b, rest = x_local.shape[0], tuple(x_local.shape[2:])
+        frame = b * math.prod(rest) * x_local.element_size()
+        frame_pad = _round16(frame)
+        plan = {}  # receiver -> (resolved slots, {sender: [slot indices]})
+        for r in range(self.world):
+            slots = [resolve(g) for g in wanted(r)]
+            by_sender = {}
+            for i, g in enumerate(slots):
+                if g is not None and self.owner(g) != r:
+                    by_sender.setdefault(self.owner(g), []).append(i)
+            plan[r] = (slots, by_sender)
+        incoming = max((sum(len(v) for v in plan[r][1].values()) for r in range(self.world)), default=0)
+        off = heap.alloc(max(incoming, 1) * frame_pad)  # the same allocation on every rank
+        epoch = heap.next_epoch()
+
+        def region(r, s):  # offset of sender s's frames inside receiver r's allocation (senders in rank order)
+            return off + sum(len(plan[r][1][t]) for t in sorted(plan[r][1]) if t < s) * frame_pad
+        for r in range(self.world):
+            if r == self.rank or self.rank not in plan[r][1]:
+                continue
+            idx = plan[r][1][self.rank]
+            msg = torch.stack([x_local[:, plan[r][0][i] - self.f0] for i in idx], dim=0)  # [n, B, ...]
+            if frame_pad != frame:
+                padded = msg.new_zeros((len(idx), frame_pad // msg.element_size()))
+                padded[:, : frame // msg.element_size()] = msg.reshape(len(idx), -1)
+                msg = padded
+            heap.put(msg.contiguous(), region(r, self.rank), [r], epoch)
+        slots, by_sender = plan[self.rank]
+
+        def finish():
+            out = x_local.new_zeros((b, len(slots)) + rest)
+            for i, g in enumerate(slots):
+                if g is not None and self.f0 <= g < self.f1:
+                    out[:, i] = x_local[:, g - self.f0]
+            if by_sender:
+                heap.wait(sorted(by_sender), epoch)
+                for s_rank, idx in by_sender.items():
+                    raw = heap.view(region(self.rank, s_rank), len(idx) * frame_pad).view(len(idx), frame_pad)[:, :frame]
+                    got = raw.reshape(-1).view(x_local.dtype).view((len(idx), b) + rest)
+                    out[:, idx] = got.transpose(0, 1)
+            return out
+        return PeerPending(self, finish, tag, counted=bool(by_sender) or any(self.rank in plan[r][1] for r in range(self.world)))
 
     def with_halo(self, x_local: torch.Tensor, left: int, right: int, *, zero_outside: bool, tag: str = "halo") -> torch.Tensor:
         """[B, F_local, ...] -> [B, left + F_local + right, ...]: the neighbours' boundary frames on both sides."""
@@ -226,6 +314,171 @@ class Pending:
             self.result = self.finish()
             self.finish, self.reqs, self.keep = None, [], ()
         return self.result
+
+
+def _round16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+class PeerPending:
+    """An exchange over the peer heaps: the puts are already queued (stream-ordered kernels); `wait()` queues the one-workgroup wait
+    kernel on the compute stream and assembles the result from the own heap.  Nothing blocks the host, no collective is called:
+    counted as `device_side` in the shard's statistics."""
+
+    def __init__(self, shard: FrameShard, finish, tag="other", counted=True):
+        self.shard, self.finish, self.tag, self.result = shard, finish, tag, None
+        self.counted = counted
+        if counted:
+            shard.stats["posted"] += 1
+
+    def wait(self) -> torch.Tensor:
+        if self.finish is not None:
+            if self.counted:
+                self.shard.stats["device_side"] += 1
+                by = self.shard.stats.setdefault("by_tag", {}).setdefault(self.tag, {"overlapped": 0, "blocking": 0})
+                by["device_side"] = by.get("device_side", 0) + 1
+            self.result = self.finish()
+            self.finish = None
+        return self.result
+
+
+class PeerHeap:
+    """One rank's symmetric heap (a byte buffer + control words: a flag per sender rank, done counters, an error word) and the mapped
+    heaps of its peers.  On the GPU the buffers are ordinary device allocations shared through HIP IPC (PyTorch's CUDA-IPC tensor
+    reducer: hipIpcGetMemHandle / hipIpcOpenMemHandle, dmabuf mode) -- over xGMI a peer's stores land in this rank's HBM; under the CPU
+    emulation backend they are shared-memory files, so the gloo test ranks exercise the very same protocol.
+
+    Offsets are handed out by a deterministic bump allocator that wraps around: every rank calls `alloc` in the same order with the
+    same sizes (the exchange plans are pure functions of the clip geometry), so an offset means the same message everywhere.  Reuse
+    is safe two exchanges later at the earliest -- a rank passes the wait of exchange e only after every sender has put e, and a
+    sender's put e is queued behind its own consumer of exchange e - 1 -- and the ring is sized for hundreds."""
+    N_FLAGS, N_DONE = 64, 64
+    SIDE_STREAM_BYTES = 256 << 10  # messages at least this large are put from a side stream (they overlap the kernels queued next)
+
+    def __init__(self, world: int, rank: int, nbytes: int, device=None, group=None, timeout_us: int = 20_000_000):
+        import torch.distributed as dist
+        from . import _native as N
+        if world > self.N_FLAGS:
+            raise ValueError("PeerHeap: at most 64 ranks")
+        self.world, self.rank, self.nbytes, self.timeout_us = world, rank, int(nbytes), int(timeout_us)
+        self.cursor, self.epoch, self._put_count = 0, 0, 0
+        self.on_gpu = not N.is_test_backend()
+        self._side = None
+        if self.on_gpu:
+            from torch.multiprocessing.reductions import reduce_tensor
+            device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+            self.ctl = torch.zeros(self.N_FLAGS + self.N_DONE + 8, dtype=torch.int32, device=device)
+            torch.cuda.synchronize(device)
+            handles = [None] * world
+            dist.all_gather_object(handles, (reduce_tensor(self.buf), reduce_tensor(self.ctl)), group=group)
+            self.peer_buf, self.peer_ctl = [], []
+            for r in range(world):
+                if r == rank:
+                    self.peer_buf.append(self.buf)
+                    self.peer_ctl.append(self.ctl)
+                else:
+                    (fb, ab), (fc, ac) = handles[r]
+                    self.peer_buf.append(fb(*ab))
+                    self.peer_ctl.append(fc(*ac))
+        else:
+            token = [f"{os.getpid()}_{os.environ.get('MASTER_PORT', '0')}"]
+            dist.broadcast_object_list(token, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+            base = f"/dev/shm/fz_peer_{token[0]}_"
+
+            def open_(r, create):
+                n_ctl = self.N_FLAGS + self.N_DONE + 8
+                fb, fc = base + f"{r}_buf", base + f"{r}_ctl"
+                if create:
+                    with open(fb, "wb") as f:
+                        f.truncate(self.nbytes)
+                    with open(fc, "wb") as f:
+                        f.truncate(4 * n_ctl)
+                return (torch.from_file(fb, shared=True, size=self.nbytes, dtype=torch.uint8),
+                        torch.from_file(fc, shared=True, size=n_ctl, dtype=torch.int32))
+            mine = open_(rank, True)
+            dist.barrier(group=group)
+            pairs = [mine if r == rank else open_(r, False) for r in range(world)]
+            dist.barrier(group=group)
+            for suffix in ("_buf", "_ctl"):  # the mappings stay valid; the names go
+                try:
+                    os.unlink(base + f"{rank}{suffix}")
+                except OSError:
+                    pass
+            self.buf, self.ctl = mine
+            self.peer_buf = [p[0] for p in pairs]
+            self.peer_ctl = [p[1] for p in pairs]
+        dist.barrier(group=group)
+
+    # -- offsets and epochs: identical sequences on every rank ----------------------------------------------------
+    def alloc(self, nbytes: int) -> int:
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        if nbytes * 3 > self.nbytes:
+            raise ValueError(f"PeerHeap of {self.nbytes} bytes is too small for a {nbytes}-byte exchange (needs 3x)")
+        if self.cursor + nbytes > self.nbytes:
+            self.cursor = 0
+        off = self.cursor
+        self.cursor += nbytes
+        return off
+
+    def next_epoch(self) -> int:
+        self.epoch = (self.epoch + 1) & 0x7FFFFFFF
+        return self.epoch
+
+    def view(self, off: int, nbytes: int) -> torch.Tensor:
+        return self.buf[off: off + nbytes]
+
+    # -- the two kernels ------------------------------------------------------------------------------------------
+    def put(self, msg: torch.Tensor, off: int, ranks: Sequence[int], epoch: int):
+        """Copy `msg` (contiguous) to byte offset `off` of the heaps of `ranks` and publish `epoch` in their flag word for this rank."""
+        import ctypes as C
+        from . import _native as N
+        from . import kernels as K
+        assert msg.is_contiguous()
+        nbytes = msg.numel() * msg.element_size()
+        if nbytes % 16 or msg.data_ptr() % 16:
+            flat = msg.reshape(-1).view(torch.uint8)
+            padded = torch.zeros(_round16(nbytes), dtype=torch.uint8, device=msg.device)
+            padded[:nbytes] = flat
+            msg, nbytes = padded, padded.numel()
+        assert off % 16 == 0 and off + nbytes <= self.nbytes
+        side = None
+        if self.on_gpu and nbytes >= self.SIDE_STREAM_BYTES:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=msg.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream(msg.device))
+        for i0 in range(0, len(ranks), 8):
+            grp = ranks[i0: i0 + 8]
+            dst = (C.c_void_p * len(grp))(*[self.peer_buf[r].data_ptr() + off for r in grp])
+            flg = (C.c_void_p * len(grp))(*[self.peer_ctl[r].data_ptr() + 4 * self.rank for r in grp])
+            # every put but the last of a multi-group message publishes to a scratch flag (puts of one stream run in order)
+            if i0 + 8 < len(ranks):
+                flg = (C.c_void_p * len(grp))(*[self.ctl.data_ptr() + 4 * (self.N_FLAGS + self.N_DONE + 1)] * len(grp))
+            done = self.ctl.data_ptr() + 4 * (self.N_FLAGS + self._put_count % self.N_DONE)
+            self._put_count += 1
+            if side is not None:
+                with torch.cuda.stream(side):
+                    rc = N.lib().fz_peer_put(msg.data_ptr(), nbytes, dst, flg, len(grp), epoch, done, K._stream(msg))
+                msg.record_stream(side)
+            else:
+                rc = N.lib().fz_peer_put(msg.data_ptr(), nbytes, dst, flg, len(grp), epoch, done, K._stream(msg))
+            N.check(rc, "fz_peer_put")
+
+    def wait(self, senders: Sequence[int], epoch: int):
+        from . import _native as N
+        from . import kernels as K
+        mask = 0
+        for r in senders:
+            mask |= 1 << r
+        err = self.ctl.data_ptr() + 4 * (self.N_FLAGS + self.N_DONE)
+        N.check(N.lib().fz_peer_wait(self.ctl.data_ptr(), mask, epoch, err, self.timeout_us, K._stream(self.ctl)), "fz_peer_wait")
+
+    def check(self):
+        """Synchronising: did any wait time out since the last check?"""
+        if int(self.ctl[self.N_FLAGS + self.N_DONE]) != 0:
+            self.ctl[self.N_FLAGS + self.N_DONE] = 0
+            raise RuntimeError("PeerHeap: a peer did not deliver within the time limit (fz_peer_wait timed out)")
 
 
 _active_shard: Optional[FrameShard] = None

@@ -115,7 +115,7 @@ def _run_bench_ranks(world, extra, timeout=600):
 
 def test_bench_main_two_ranks_clips_and_frame_shard_probe():
     """Default sharding (one clip per rank, weak scaling) + the frame-sharded probe that follows it, end to end over gloo."""
-    line = _run_bench_ranks(2, ["--no-kernel-breakdown"])  # (the per-kernel event brackets are single-rank bookkeeping: test_rooflines_bookkeeping)
+    line = _run_bench_ranks(2, ["--no-kernel-breakdown", "--transport", "rccl"])  # (the per-kernel event brackets are single-rank bookkeeping: test_rooflines_bookkeeping)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["n_ranks_seen"] == 2
     assert line["config"]["parallelism"] == "dp2 over clips" and line["config"]["outputs_finite"] is True
     assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 1 / (line["ms_per_step"] / 1e3)) < 1e-6 * line["value"]  # whole-job frames/s
@@ -131,7 +131,7 @@ def test_bench_main_two_ranks_clips_and_frame_shard_probe():
 def test_bench_main_two_ranks_auto_promotes_the_frame_sharded_clip():
     """frames >= 2 x ranks: the default (`--shard auto`) reports the frame-sharded clip as `value` (strong scaling, K timed jobs) and
     keeps the one-clip-per-rank measurement beside it; the exchange counters of the shard travel in the line."""
-    line = _run_bench_ranks(2, ["--frames", "4", "--no-kernel-breakdown", "--no-n-edit2-probe"])
+    line = _run_bench_ranks(2, ["--frames", "4", "--no-kernel-breakdown", "--no-n-edit2-probe", "--transport", "rccl"])
     fs = line["frame_sharded"]
     assert "error" not in fs and fs["jobs_timed"] == 1 and fs["outputs_finite"] is True, fs
     assert line["scaling"] == "strong" and line["config"]["parallelism"] == "2-way frame-sharded clip"
@@ -140,6 +140,18 @@ def test_bench_main_two_ranks_auto_promotes_the_frame_sharded_clip():
     assert line["value_clips_dp"] == line["clips_dp"]["value"] and line["value_frame_sharded"] == fs["value"]  # fixed-definition fields
     ex = fs["exchanges"]
     assert ex["overlapped_with_compute"] > 0 and ex["posted"] == ex["overlapped_with_compute"] + ex["blocking"], ex
+
+
+def test_bench_main_two_ranks_default_transport_is_the_peer_heaps():
+    """Default `--transport auto`: the frame-sharded clip runs over the one-sided peer transport (csrc/peer.hip; shared-memory heaps under
+    the CPU harness) once its self-test round trip succeeded -- the line says so, and every exchange is device-side: no collective call
+    and no blocking wait inside the UNet."""
+    line = _run_bench_ranks(2, ["--frames", "4", "--no-kernel-breakdown", "--no-n-edit2-probe", "--peer-heap-gb", "0.05"])
+    fs = line["frame_sharded"]
+    assert "error" not in fs and fs["outputs_finite"] is True and fs["transport"] == "peer", fs
+    ex = fs["exchanges"]
+    assert ex["device_side"] == ex["posted"] > 0 and ex["blocking"] == 0 and ex["overlapped_with_compute"] == 0, ex
+    assert line["value"] == fs["value"] and line["scaling"] == "strong"
 
 
 def test_frame_sharded_promotion_rule():

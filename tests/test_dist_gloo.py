@@ -123,7 +123,7 @@ def _frame_job_factory(frames, index_list):
     return pipe, job
 
 
-def _frame_worker(rank, world, port, frames, index_list, run_model, q):
+def _frame_worker(rank, world, port, frames, index_list, run_model, q, transport="rccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), FZ_EMU_THREADS="2")
     torch.set_num_threads(2)
@@ -132,6 +132,12 @@ def _frame_worker(rank, world, port, frames, index_list, run_model, q):
     import torch.distributed as dist
     D.init("gloo")
     shard = D.FrameShard(frames)
+    if transport == "peer":
+        # the one-sided transport (csrc/peer.hip) on the CPU emulation: the symmetric heaps are shared-memory files, the put / wait
+        # kernels run on the emulator -- the same protocol (offset plan, epochs, per-sender flag words) the GPUs run over hipIpc
+        from fatezero_amd import _native, build
+        _native.use_test_backend(build.build_emu())
+        shard.enable_peer_transport(nbytes=48 << 20, timeout_us=120_000_000)
     # -- the exchange primitives against slicing of the full tensor ---------------------------------------------
     full = torch.arange(2 * frames * 3, dtype=torch.float32).view(2, frames, 3) + 1.0
     loc = shard.local(full, 1).contiguous()
@@ -147,21 +153,25 @@ def _frame_worker(rank, world, port, frames, index_list, run_model, q):
         pipe, job = _frame_job_factory(frames, index_list)
         assert D.weights_agree(pipe.unet, "cpu")
         pipe.frame_shard = shard
-        shard.stats = {"posted": 0, "overlapped": 0, "blocking": 0}  # (the primitive checks above are not part of a forward)
+        shard.stats = {"posted": 0, "overlapped": 0, "blocking": 0, "device_side": 0}  # (the primitive checks above are not part of a forward)
         res = job()
+        if shard.heap is not None:
+            shard.heap.check()
         store = pipe.store_controller
         n_maps = [t.shape[0] for t in store.attention_store_all_step[0]["down_self"]] if store.attention_store_all_step else []
         if rank == 0:
             q.put((res.clone(), n_maps, shard.n_local, dict(shard.stats)))
+    if shard.heap is not None:
+        shard.heap.check()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _spawn(world, *args):
+def _spawn(world, *args, transport="rccl"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_frame_worker, args=(r, world, port) + args + (q,)) for r in range(world)]
+    port = 31500 + (os.getpid() % 2000) + world + (7 if transport == "peer" else 0)
+    procs = [ctx.Process(target=_frame_worker, args=(r, world, port) + args + (q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=900) if args[2] else None
@@ -234,6 +244,39 @@ def test_frame_sharded_clip_four_ranks_eight_frames():
     finally:
         _native.reset_backend()
     assert n_local == 2 and n_maps and all(n == 2 for n in n_maps), (n_maps, n_local)
+    err = float((got.float() - ref.float()).abs().max())
+    scale = float(ref.float().abs().max())
+    assert torch.isfinite(got.float()).all() and err <= 1.5e-2 * scale, (err, scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the same exchanges over the one-sided peer transport (csrc/peer.hip; shared-memory heaps on the CPU emulation)
+# ---------------------------------------------------------------------------------------------------------------
+def test_peer_transport_exchanges_three_ranks_ragged():
+    _spawn(3, 7, [-1, "first"], False, transport="peer")   # ragged all-gather, a middle rank with two neighbours, anchors
+
+
+def test_peer_transport_exchanges_one_frame_per_rank():
+    _spawn(4, 4, [-1, "first"], False, transport="peer")   # a two-frame halo comes from TWO ranks on each side
+
+
+@pytest.mark.parametrize("frames,index_list", [(5, [-1, "first"])])  # ragged 3 + 2 split
+def test_peer_transport_clip_matches_single_process(frames, index_list):
+    """The whole frame-sharded inversion + edit with EVERY exchange on the peer transport: no collective call and no blocking wait is
+    left inside the UNet (GroupNorm partials and temporal-convolution halos included) -- every exchange is a put kernel at the sender
+    and a one-workgroup wait kernel in front of the consumer."""
+    got, n_maps, n_local, stats = _spawn(2, frames, index_list, True, transport="peer")
+    assert stats["blocking"] == 0 and stats["overlapped"] == 0 and stats["device_side"] == stats["posted"] > 0, stats
+    by = stats["by_tag"]
+    for tag in ("kv", "temporal_attn", "groupnorm", "temporal_conv"):
+        assert by[tag].get("device_side", 0) > 0 and by[tag]["blocking"] == 0, (tag, stats)
+    _, job = _frame_job_factory(frames, index_list)
+    from fatezero_amd import _native
+    try:
+        ref = job()
+    finally:
+        _native.reset_backend()
+    assert n_maps and all(n == n_local for n in n_maps), (n_maps, n_local)
     err = float((got.float() - ref.float()).abs().max())
     scale = float(ref.float().abs().max())
     assert torch.isfinite(got.float()).all() and err <= 1.5e-2 * scale, (err, scale)

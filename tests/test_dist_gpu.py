@@ -60,18 +60,26 @@ def _route_exchanges_through_host(D):
         ff(self, x.cpu(), wanted, zero_outside=zero_outside, tag=tag), x.device)
 
 
-def _worker(rank, world, port, frames, index_list, q):
+def _worker(rank, world, port, frames, index_list, q, transport="host"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from fatezero_amd import _native, dist as D
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _route_exchanges_through_host(D)
+    if transport == "host":
+        _route_exchanges_through_host(D)
     pipe, job = _job(frames, index_list, "cuda")
     assert D.weights_agree(pipe.unet, "cpu")
     pipe.frame_shard = D.FrameShard(frames)
+    if transport == "peer":
+        # the product's one-sided transport on real hardware paths: each rank's symmetric heap is a device allocation the OTHER process
+        # maps through HIP IPC; fz_peer_put stores into the mapped heap, fz_peer_wait polls the flag words (csrc/peer.hip).  (Both
+        # ranks share the box's one GPU: same protocol, the stores stay inside one HBM instead of crossing xGMI.)
+        pipe.frame_shard.enable_peer_transport(nbytes=512 << 20, timeout_us=15_000_000)
     res = job()
+    if pipe.frame_shard.heap is not None:
+        pipe.frame_shard.heap.check()
     assert _native.loaded_path().endswith("libfatezero_hip.so")
     if rank == 0:
         q.put((res, dict(pipe.frame_shard.stats)))
@@ -101,3 +109,30 @@ def test_frame_sharded_clip_on_the_hip_kernels_matches_single_process(frames, in
     assert torch.isfinite(got).all() and err <= 1.5e-2 * scale, (err, scale)
     by = stats["by_tag"]
     assert by["kv"]["blocking"] == 0 and by["temporal_attn"]["blocking"] == 0 and by["kv"]["overlapped"] > 0, stats
+
+
+@pytest.mark.parametrize("frames,index_list", [(4, [-1, "first"]), (5, ["mid", 1])])
+def test_frame_sharded_clip_over_the_peer_transport_matches_single_process(frames, index_list):
+    """The same two-rank run with EVERY exchange on the one-sided peer transport (fz_peer_put / fz_peer_wait over HIP-IPC-mapped
+    heaps): no gloo / RCCL call and no host copy inside the UNet; the statistics show every exchange device-side, none blocking."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, frames, index_list, q, "peer")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, stats = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    _, job = _job(frames, index_list, "cuda")
+    ref = job()
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max())
+    print("frame-sharded over the peer transport", frames, index_list, {"err": err, "scale": scale, "exchanges": stats})
+    assert torch.isfinite(got).all() and err <= 1.5e-2 * scale, (err, scale)
+    assert stats["blocking"] == 0 and stats["overlapped"] == 0 and stats["device_side"] == stats["posted"] > 0, stats
+    for tag in ("kv", "temporal_attn", "groupnorm", "temporal_conv"):
+        assert stats["by_tag"][tag].get("device_side", 0) > 0, (tag, stats)
