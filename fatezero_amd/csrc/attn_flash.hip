@@ -81,7 +81,10 @@ struct FlashOrder {
     unsigned char fl[64];
 };
 
-template <int D, int W, int QB, bool USE_BIAS, int NSTG>
+// NPOLY (trial, scripts/flash_ab.hip): of the 32 exponentials a lane evaluates per query block and key tile, NPOLY go through the
+// polynomial fz_exp2_poly2 (packed FMAs, which co-issue with MFMAs) instead of v_exp_f32 (which does not); the library ships 0 --
+// profiles/r04_flash_exp_split_ab.txt has the A/B.
+template <int D, int W, int QB, bool USE_BIAS, int NSTG, int NPOLY = 0>
 FZ_KERNEL void __launch_bounds__(256, W)
 attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* __restrict__ k,
                   const half_t* __restrict__ vt, half_t* __restrict__ o, FlashOrder ord) {
@@ -342,10 +345,17 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
             for (int u = 0; u < QB; ++u) {
                 float sum = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const float pe = fz_exp2(acc[u][i >> 4][i & 15]);
-                    if (!C::ONES_ROW) sum += pe;
-                    pf[u][i >> 4][(i >> 3) & 1][i & 7] = (half_t)pe;
+                for (int i = 0; i < 32; i += 2) {
+                    constexpr int PSTEP = NPOLY > 0 ? 32 / NPOLY : 0;  // every PSTEP-th pair takes the polynomial
+                    f32x2 pe;
+                    if (NPOLY > 0 && ((i >> 1) % (PSTEP > 0 ? PSTEP : 1)) == 0) {
+                        pe = fz_exp2_poly2(f32x2{acc[u][i >> 4][i & 15], acc[u][i >> 4][(i & 15) + 1]});
+                    } else {
+                        pe = f32x2{fz_exp2(acc[u][i >> 4][i & 15]), fz_exp2(acc[u][i >> 4][(i & 15) + 1])};
+                    }
+                    if (!C::ONES_ROW) sum += pe[0] + pe[1];
+                    pf[u][i >> 4][(i >> 3) & 1][i & 7] = (half_t)pe[0];
+                    pf[u][i >> 4][(i >> 3) & 1][(i & 7) + 1] = (half_t)pe[1];
                 }
                 if (!C::ONES_ROW) l[u] += sum;
             }
@@ -462,7 +472,7 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
     }
 }
 
-template <int D, int W, int QB, bool USE_BIAS = true, int NSTG = 2>
+template <int D, int W, int QB, bool USE_BIAS = true, int NSTG = 2, int NPOLY = 0>
 static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, const void* vt, void* o, void* stream) {
     // 32-bit per-lane byte offsets inside one (frame, head) K / V^T panel
     if (d.k_row_stride >= (1 << 22) || (int64_t)D * d.vt_chan_stride >= (1ll << 30)) return FZ_ERR_UNSUPPORTED;
@@ -481,7 +491,7 @@ static int launch_flash(const FzAttnSelfDesc& d, const void* q, const void* k, c
             }
     }
     dim3 grid(nq * d.heads * d.n_frames), block(256);
-    FZ_LAUNCH((attn_flash_kernel<D, W, QB, USE_BIAS, NSTG>), grid, block, 0, stream, d, (const half_t*)q, (const half_t*)k,
+    FZ_LAUNCH((attn_flash_kernel<D, W, QB, USE_BIAS, NSTG, NPOLY>), grid, block, 0, stream, d, (const half_t*)q, (const half_t*)k,
               (const half_t*)vt, (half_t*)o, ord);
     return fz_last_launch_status();
 }

@@ -307,5 +307,33 @@ FZ_DEVICE float fz_gelu_erf(float x) {
     return x * (x < 0.0f ? q : 1.0f - q);
 }
 
+// 2^x for a PAIR of arguments WITHOUT the transcendental unit: fract / floor split, a cubic minimax polynomial of 2^f on [0, 1) in
+// packed fp32 FMAs (max relative error 7.5e-5: a sixth of an fp16 ulp), v_ldexp.  4.5-5 full-rate VALU instructions per element
+// against one v_exp_f32 -- which, unlike FMAs, does not co-issue with MFMAs (profiles/r01_ubench_valu.txt).  Trial use only:
+// csrc/attn_flash.hip NPOLY, scripts/flash_ab.hip.
+FZ_DEVICE f32x2 fz_exp2_poly2(f32x2 x) {
+#ifdef FZ_EMU
+    const f32x2 fl = {floorf(x[0]), floorf(x[1])};
+#else
+    const f32x2 fl = {__builtin_floorf(x[0]), __builtin_floorf(x[1])};
+#endif
+    const f32x2 fr = x - fl;
+    const f32x2 c0 = {0.9999249577522278f, 0.9999249577522278f}, c1 = {0.6958348155021667f, 0.6958348155021667f};
+    const f32x2 c2 = {0.22606661915779114f, 0.22606661915779114f}, c3 = {0.07802354544401169f, 0.07802354544401169f};
+    f32x2 p = c3 * fr + c2;
+    p = p * fr + c1;
+    p = p * fr + c0;
+    f32x2 r;
+#ifdef FZ_EMU
+    r[0] = ldexpf(p[0], (int)(fl[0] < -200.0f ? -200.0f : fl[0]));
+    r[1] = ldexpf(p[1], (int)(fl[1] < -200.0f ? -200.0f : fl[1]));
+#else
+    // (v_cvt_i32_f32 saturates and v_ldexp_f32 flushes an exponent below the fp32 range to 0: no clamp needed)
+    r[0] = __builtin_amdgcn_ldexpf(p[0], (int)fl[0]);
+    r[1] = __builtin_amdgcn_ldexpf(p[1], (int)fl[1]);
+#endif
+    return r;
+}
+
 static inline int fz_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int fz_round_up(int a, int b) { return fz_ceil_div(a, b) * b; }

@@ -122,7 +122,7 @@ struct IgCfg {
     // other's K loop.  Measured on the epilogue-dominated short-K projections (profiles/r03_igemm_shortk_two_wg_per_cu.txt): 128 x 256
     // gains 5-10 % on the K = 320 / 640 GEGLU launches (64 gelu per lane in the epilogue) and loses 10-40 % on every plain projection;
     // 256 x 128, 128 x 128 and 320 x 128 lose everywhere.  Shipped for those GEGLU launches only (ig_run), the rest are trial ids.
-    static constexpr int WAVES_PER_SIMD = (NW == 8 && LDS_HALVES * 2 * 2 <= 160 * 1024 && TA * TB * 16 <= 80) ? 4 : NW / 4;
+    static constexpr int WAVES_PER_SIMD = (NW == 8 && LDS_HALVES * 2 * 2 <= 160 * 1024 && TA * TB * 16 <= 80) ? 4 : (NW + 3) / 4;
     static_assert((NS - 2) * PER < 64 && NS >= 2, "ring depth");
     static constexpr int CW = GEGLU ? BA / 2 : BA;  // output columns of the tile
     static constexpr int CSTR = CW + 8;
@@ -1201,6 +1201,19 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
         default: break;
     }
     if (!GEGLU) {  // odd TA / TA = 1 cannot pair (h, gate) tiles
+#ifdef FZ_IGEMM_TRIALS
+        // 160 x 128, 4 waves, two workgroups per CU, for the rank-160 down projection of the temporal LoRA pair at 8 frames (128 tiles of
+        // 160 x 256 = half the chip): 22 us against 26 us for 158122 on the 64^2 shape, but the 64 x 128 tile the chooser already takes
+        // there runs 21 us (profiles/r04_tile_154122_ab.txt): nothing to gain, not shipped
+        if constexpr (!LN) {
+            if (cfg == 154122) return ig_launch<1, 5, 4, 1, 64, 2, MODE, false, false>(g, batch, stream);
+        }
+        // 320 x 128 as 5 x 2 waves of 2 x 2 MFMA tiles (TEN waves: 4 MFMAs per 4 fragment reads per k sub-step instead of 5 per 6, 2.5 waves
+        // per SIMD): 3-11 % SLOWER than the 8-wave 5 x 1 form on every conv / projection it carries (profiles/r04_tile_10wave_ab.txt)
+        if constexpr (!LN) {
+            if (cfg == 522222) return ig_launch<5, 2, 2, 2, 64, 2, MODE, false, false>(g, batch, stream);
+        }
+#endif
         switch (cfg) {
             case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false, LN>(g, batch, stream);
             case 254122: return ig_launch<2, 5, 4, 1, 64, 2, MODE, false, LN>(g, batch, stream);

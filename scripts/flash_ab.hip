@@ -32,6 +32,12 @@ int main(int argc, char** argv) {
         {"ring2 [-1,last ]: all frames two sources   <40,W2,QB2>", launch_flash<40, 2, 2, true, 2>, true},
         {"QB1 W4 [-1,first]                          <40,W4,QB1>", launch_flash<40, 4, 1, true, 2>, false},
         {"QB1 W4 [-1,last ]                          <40,W4,QB1>", launch_flash<40, 4, 1, true, 2>, true},
+#ifdef FLASH_AB_POLY  // exp split: NPOLY of every 32 exponentials on packed FMAs (fz_exp2_poly2) instead of the transcendental unit
+        {"exp split  4 / 32 polynomial [-1,first]    <40,W2,QB2>", launch_flash<40, 2, 2, true, 2, 4>, false},
+        {"exp split  8 / 32 polynomial [-1,first]    <40,W2,QB2>", launch_flash<40, 2, 2, true, 2, 8>, false},
+        {"exp split 16 / 32 polynomial [-1,first]    <40,W2,QB2>", launch_flash<40, 2, 2, true, 2, 16>, false},
+        {"exp split 32 / 32 polynomial [-1,first]    <40,W2,QB2>", launch_flash<40, 2, 2, true, 2, 32>, false},
+#endif
 #ifdef FLASH_AB_ALL
         {"ring4 (barrier per two tiles) <40,W2,QB2,bias,4>", launch_flash<40, 2, 2, true, 4>, false},
         {"no bias slot ring2            <40,W2,QB2,fma ,2>", launch_flash<40, 2, 2, false, 2>, false},
@@ -59,7 +65,7 @@ int main(int argc, char** argv) {
             hqk[i] = (_Float16)(rnd() * 1.5f * (is_q ? 0.158113883f * 1.44269504f : 1.0f));
         }
         for (auto& x : hv) x = (_Float16)rnd();
-        _Float16 *qk, *vt, *o[8];
+        _Float16 *qk, *vt, *o[12];
         hipMalloc(&qk, nqk * 2); hipMalloc(&vt, nv * 2);
         for (int v = 0; v < NV; ++v) { hipMalloc(&o[v], no * 2); hipMemset(o[v], 0, no * 2); }
         hipMemcpy(qk, hqk.data(), nqk * 2, hipMemcpyHostToDevice);

@@ -392,6 +392,28 @@ def run_fullwidth_case(device, F=None, T=None, pure_edit=False, seed=11, variant
     return res
 
 
+def run_fullwidth_forward(device, F=16, variant="refine_reweight_mid", seed=13, t=481):
+    """ONE forward of the full-width UNet on an F-frame clip (no controller) against oracle.OracleUNet: the clip lengths of BASELINE
+    cfg3 / cfg4 / cfg5 (16 / 24 / 32 frames) differ from the judged 8 in more than size -- the temporal attention kernel is instantiated
+    per clip length, GroupNorm statistics span F frames, the flash dispatch order and the sparse-causal source frames follow clip_len --
+    and a whole inversion + edit at 16 frames is minutes of CPU oracle; one forward (~45 s at 16 frames) covers those code paths."""
+    from oracle import fatezero_oracle as O
+    mc = dict(FULL_VARIANTS[variant]["model_config"])
+    unet = UNetPseudo3DConditionModel(sample_size=64, **SD15, **mc)
+    shapes = [(k, tuple(v.shape)) for k, v in unet.state_dict().items()]
+    sd = procedural_state_dict(shapes)
+    unet.load_state_dict(sd)
+    unet = unet.half().to(device).eval()
+    ounet = O.OracleUNet(sd, O.UNetConfig(**SD15, model_config=mc))
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(1, 4, F, 64, 64, generator=g)
+    ctx = torch.randn(1, 77, 768, generator=g) * 0.5
+    y = unet(z.to(device).half(), t, ctx.to(device).half()).sample.float().cpu()
+    ref = ounet(z, t, ctx)
+    return {"frames": F, "variant": variant, "err": float((y - ref).abs().max()), "scale": float(ref.abs().max()),
+            "err_q99": float(torch.quantile((y - ref).abs().flatten()[:: max(1, y.numel() // 1000000)], 0.99))}
+
+
 # full SD-1.x width, 2 + 2 steps, 3 frames (measured: inversion 0.10 - 0.11 %, cross maps 0.6e-2 - 0.7e-2, self maps 1e-3, edit on the
 # natively captured maps 0.72 - 0.74 % max / 0.39 - 0.43 % q99)
 FULL_LATENT_TOL = 4e-3

@@ -52,6 +52,16 @@ def test_fullwidth_sd15_pipeline_vs_oracle(variant):
     assert _native.loaded_path().endswith("libfatezero_hip.so")
 
 
+@pytest.mark.parametrize("frames,variant", [(16, "refine_reweight_mid"), (16, "replace_blend")])
+def test_fullwidth_unet_forward_long_clips_vs_oracle(frames, variant):
+    """BASELINE cfg3's clip length (16 frames: its own temporal-attention instantiation, GroupNorm over 16 frames, flash dispatch and
+    sparse-causal sources by clip_len = 16) under both model configs: one full-width UNet forward vs oracle.OracleUNet."""
+    r = PC.run_fullwidth_forward("cuda", F=frames, variant=variant)
+    print("fullwidth forward", r)
+    assert r["err"] <= 1.5e-2 * r["scale"] and r["err_q99"] <= 4e-3 * r["scale"], r
+    assert _native.loaded_path().endswith("libfatezero_hip.so")
+
+
 @pytest.mark.parametrize("name", ["unet_tiny40_default", "unet_tiny40_l72", "unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d"])
 def test_unet_vs_reference_golden(name):
     r = PC.run_unet_golden(name, "cuda")
