@@ -217,10 +217,12 @@ MAP_TOL = 2e-2           # captured cross maps, absolute on probabilities in [0,
                          # a peaky softmax; measured 0.85e-2 - 1.37e-2); given identical q/k the kernels store P within 1.6 fp16
                          # ulp (kernel_cases.py)
 SELF_MAP_TOL = 4e-3      # captured self-attention maps, absolute                (measured 0.3e-3 - 1.7e-3)
-MASK_FLIP_TOL = 1.5e-2   # fraction of mask elements that may differ from the all-fp32 reference run: the mask thresholds a
-                         # normalised score, and the captured fp16 maps carry ~1e-2 of upstream fp16 noise, so pixels
-                         # sitting within ~1% of the threshold flip (measured 0.06 - 0.98 %).  Given IDENTICAL captured maps
-                         # (oracle edit run on the native inversion maps) the attention-blend masks must be bit-exact: 0 flips.
+MASK_FLIP_TOL = 9e-3     # fraction of mask elements that may differ from the all-fp32 reference run: the mask thresholds a
+                         # normalised score, and the captured fp16 maps carry ~1e-2 of upstream fp16 noise, so pixels sitting
+                         # within ~1 % of the threshold flip.  Re-measured in round 4 (profiles/r04_parity_numbers.txt): 0.05 - 0.47 %
+                         # on the recorded scenarios, 0.39 % at the judged 8-frame shape with a 67 %-ones mask; the bound is 2x the
+                         # worst.  Given IDENTICAL captured maps (oracle edit run on the native inversion maps) the attention-blend
+                         # masks are bit-exact: 0 flips, asserted as such.
 EDIT_TOL_SAME_MAPS = 1.5e-2     # edit vs the oracle's edit on the natively captured maps, max   (measured 0.53 - 0.93 %)
 EDIT_TOL_VS_REFERENCE = 6e-2    # edit vs the all-fp32 reference, MAX, when blend masks are in play: a flipped mask pixel moves
                                 # that latent by |x - inverted| -- discrete, of the order of the latent scale (measured 1.7 - 4.7 %)
