@@ -299,7 +299,9 @@ def install_timers(K, timer):
         if mode == K.FZ_ATTN_INJECT and rm is not None:
             m0 = kw.get("mask_frame_off", 0)
             read *= float(1.0 - rm.reshape(-1, rm.shape[-1])[m0: m0 + nf].float().mean())
-        return ("capture" if mode == K.FZ_ATTN_CAPTURE else "inject", nf * per_frame, read)
+        if mode == K.FZ_ATTN_CAPTURE:
+            return ("capture", nf * per_frame, nf * per_frame)
+        return ("inject", nf * per_frame, nf * per_frame, round(read))  # (4th field: the bytes of the rows really read)
     timer.wrap(K, "attn_self", sel_attn)
 
     def sel_conv(x, wt, bias, **kw):
@@ -319,6 +321,12 @@ def install_timers(K, timer):
         tag = gemm_class(x, w, kw)
         return None if tag is None else tag
     timer.wrap(K, "gemm", sel_gemm)
+
+    def sel_qkvt(x, w, split, **kw):  # the fused q | k | V^T projection: a plain projection with N = 3 C (no residual)
+        if not timer.extra:
+            return None
+        return gemm_class(x, w, {})
+    timer.wrap(K, "gemm_qkvt", sel_qkvt)
 
 
 def gemm_class(x, w, kw):
@@ -348,12 +356,12 @@ def install_launch_log(K, path):
     counter rows rocprofv3 writes per dispatch can be attributed to the classes the line reports.  Written at exit."""
     import atexit
     log = []
-    for fn_name in ("gemm", "gemm_vt", "gemm_batched"):
+    for fn_name in ("gemm", "gemm_vt", "gemm_batched", "gemm_qkvt"):
         orig = getattr(K, fn_name)
 
         def wrapped(x, w, *a, _orig=orig, _name=fn_name, **k):
-            if _name == "gemm":
-                tag = gemm_class(x, w, k)
+            if _name in ("gemm", "gemm_qkvt"):
+                tag = gemm_class(x, w, k if _name == "gemm" else {})
                 log.append("gemm_small" if tag is None else tag[0])
             else:
                 log.append(_name)
@@ -412,15 +420,16 @@ def rooflines(summ):
             # with procedural weights the blend-word score is near-uniform and the config's th = 0.3 keeps ~99 % of the rows on the live
             # attention: those rows run QK^T + softmax and read NO stored map, so the launch moves far fewer bytes than the map it is
             # priced on (SURVEY 8(d)'s figure) -- say so, and give the rate over the rows really read
-            ent["stored_rows_fraction"] = alg / work if work else None
-            ent["achieved_over_rows_read"] = ach * alg / work if work else None
+            read = sum((k[3] if len(k) > 3 else k[1]) * v["launches"] for k, v in sel.items())
+            ent["stored_rows_fraction"] = read / work if work else None
+            ent["achieved_over_rows_read"] = ach * read / work if work else None
         if bound == "mfma":  # the same launches against the OTHER roof, so that the class can be read off the line
             ent["algorithmic_GBps"] = alg / (ms * 1e-3) / 1e9
         c = (job_pmc or {}).get("classes", {}).get(name)
         if c is not None:
             ent.update(traffic=c["traffic_bytes_per_launch"], traffic_unit="bytes/launch", traffic_launches=c["launches"],
                        traffic_source=f"{job_src} (in situ, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
-                       traffic_over_algorithmic=c["traffic_bytes_per_launch"] / (alg / n))
+                       traffic_over_algorithmic=(c["traffic_bytes_per_launch"] / (alg / n)) if alg > 0 else None)
         others.append(ent)
     return roof, others
 
@@ -448,6 +457,30 @@ def make_frame_shard(fz_dist, frames, transport, heap_gb, device):
             used = f"rccl (peer transport unavailable: {e!r})"
     shard.stats = {"posted": 0, "overlapped": 0, "blocking": 0, "device_side": 0}
     return shard, used
+
+
+def start_line_insurance(line):
+    """A helper process that prints `line` (the finished measurement) if this process dies before printing one itself: it blocks reading a
+    pipe, exits silently on "done", and prints when the pipe closes without it.  Returns the Popen handle (None if it cannot be started)."""
+    import subprocess
+    try:
+        p = subprocess.Popen([sys.executable, "-c",
+                              "import sys\nline = sys.argv[1]\nmsg = sys.stdin.read()\nif 'done' not in msg:\n    print(line, flush=True)\n",
+                              json.dumps(line)], stdin=subprocess.PIPE, text=True, close_fds=True)
+        return p
+    except OSError:
+        return None
+
+
+def cancel_line_insurance(p):
+    if p is None or p.stdin is None or p.stdin.closed:
+        return
+    try:
+        p.stdin.write("done")
+        p.stdin.close()
+        p.wait(timeout=10)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def promote_frame_sharded(line, fs, world):
@@ -657,17 +690,23 @@ def main():
         import threading
         done = threading.Lock()
 
+        insurance = None
+
         def bail():
             if done.acquire(blocking=False):
                 if rank == 0:
                     line["frame_sharded"] = {"error": "frame-sharded probe exceeded its time limit"}
+                    cancel_line_insurance(insurance)
                     print(json.dumps(line), flush=True)
                 os._exit(0)
         dog = threading.Timer(120.0 + (12.0 * args.steps if auto_frames else 0.0), bail)
         dog.daemon = True
         dog.start()
-        # the frame-sharded path has never run on more than one GPU: a rank that dies in it (GPU fault -> SIGABRT, then the launcher's
-        # SIGTERM to the others) must not take the finished clips measurement with it
+        # the frame-sharded path has never run on more than one GPU: a rank that dies in it (GPU fault -> abort() from a runtime thread,
+        # then the launcher's SIGTERM / SIGKILL to the others) must not take the finished clips measurement with it.  Python-level signal
+        # handlers do not run while the main thread sits in a HIP call, so the insurance is a helper PROCESS that holds the clips line
+        # and prints it when rank 0's end of the pipe closes without a "done" (start_line_insurance); handlers cover the polite cases.
+        insurance = start_line_insurance(dict(line, frame_sharded={"error": "rank 0 died inside the frame-sharded probe"})) if rank == 0 else None
         import signal
         for sig in (signal.SIGTERM, signal.SIGABRT):
             try:
@@ -709,6 +748,7 @@ def main():
         else:
             return
     if rank == 0:
+        cancel_line_insurance(locals().get("insurance"))
         print(json.dumps(line), flush=True)
     if dist is not None:
         # the line is out: a rank stuck in teardown (a peer that died in the probe) must not keep the launcher waiting

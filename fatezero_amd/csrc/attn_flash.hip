@@ -427,7 +427,14 @@ attn_flash_kernel(FzAttnSelfDesc d, const half_t* __restrict__ q, const half_t* 
         FZ_TICK(0);
         const half_t* Ks = smem + (kt & (NSTG - 1)) * C::STAGE;
         tile(kt, r0, Ks);
+#ifdef FZ_FLASH_TIMING  // the stash split into "wait for the prefetched tile" (slot 6) and "registers -> LDS" (slot 4)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FZ_TICK(6);
+#endif
         if (more) stash((kt + AHEAD) & (NSTG - 1));
+#ifdef FZ_FLASH_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         FZ_TICK(4);
         if (NSTG == 2 || (kt & 1) || kt + 1 == ntiles) __syncthreads();
         FZ_TICK(5);

@@ -80,7 +80,8 @@ struct IgArgs {
     int Cin, taps, kchunks;
     int N, Hi, Wi, Ho, Wo, stride, upsample, fpb;
     int ksplit, tiles_a;
-    int b_fastest;        // tile order inside an XCD's run of tiles: 0 = a-tile fastest (consecutive tiles share their B rows), 1 = b-tile fastest
+    int group_b;          // tile order inside an XCD's run of tiles: groups of `group_b` b-tiles, b-tile fastest inside a group, then the a-tiles,
+                          // then the next group (1 = a-tile fastest: consecutive tiles share their B rows; tiles_b = b-tile fastest)
     int tiles_b;
     int nt_flat;          // > 0: split-K launch with a FLAT grid of nt_flat * ksplit workgroups, K slices mapped onto XCDs (ig_launch)
     // LayerNorm fused around the GEMM (fz_gemm_ln): the B rows are the RAW LayerNorm input, A holds gamma * W
@@ -173,7 +174,16 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
         ks = blockIdx.y;
     }
     // tile order: which operand the consecutive tiles of an XCD share (ig_launch picks the one that moves fewer bytes into the L2s)
-    const int ta = g.b_fastest ? lid / g.tiles_b : lid % g.tiles_a, tb = g.b_fastest ? lid - ta * g.tiles_b : lid / g.tiles_a;
+    int ta, tb;
+    if (g.group_b <= 1) {
+        ta = lid % g.tiles_a;
+        tb = lid / g.tiles_a;
+    } else {  // the 32 workgroups an XCD runs at a time then cover a 2-D block of group_b x (32 / group_b) tiles: both panels are re-used in L2
+        const int per = g.group_b * g.tiles_a, gid = lid / per, first = gid * g.group_b;
+        const int gs = g.tiles_b - first < g.group_b ? g.tiles_b - first : g.group_b, in = lid - gid * per;
+        ta = in / gs;
+        tb = first + in - ta * gs;
+    }
     const int a0 = ta * C::BA;
     const int64_t b0 = (int64_t)tb * C::BB;
     const int z = blockIdx.z;
@@ -1100,26 +1110,45 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
         if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
 #endif
-    // Tile order.  An XCD runs a contiguous run of `chunk` tiles (of one K slice); with the a-tile fastest the run spans
-    // min(tiles_a, chunk) weight panels and ~chunk / tiles_a row panels, with the b-tile fastest the other way round, and every XCD
-    // fetches what its run spans into its own L2: pick the order with fewer bytes.  Weight-heavy launches (the GEGLU projection of
-    // the 16^2 level: 26 MB of weights against 5 MB of rows; q|k|v 1280 -> 3840) stream 1/8 of the weights per XCD instead of all of
-    // them; row-heavy launches (everything at 64^2) keep the a-fastest order.
+    // Tile order.  An XCD (32 CUs, its own 4 MB L2) runs ~32 consecutive tiles of the launch order at a time and fetches what those tiles
+    // span into its L2.  With the a-tile fastest that is min(tiles_a, 32) weight panels x 1-2 row panels; with groups of group_b b-tiles
+    // it is a 2-D block of (32 / group_b) weight panels x group_b row panels.  The launcher prices one such round for group_b in
+    // {1, 2, 4, .., 32, tiles_b} (panel bytes = tile rows x K x 2, row panels of a convolution with their halo) and takes the cheapest
+    // when it beats the a-fastest order by 20 %: weight-heavy launches (GEGLU 640 -> 5120 at 32^2: 20 weight panels of 328 KB per row
+    // panel -- 6.5 MB of weights streaming through a 4 MB L2 once per row panel, 294 MB fetched per launch for 27 MB of operands,
+    // profiles/r04_pmc_job.json) get blocks in which both operands are re-used; row-heavy launches (everything at 64^2) keep group_b = 1.
     g.tiles_b = (int)tiles_b;
+    g.group_b = 1;
     {
         static const bool order_off = getenv("FZ_IGEMM_NO_TILE_ORDER") != nullptr;  // A/B switch (tuning only)
-        const double wbytes = 2.0 * g.Ma * (double)g.lda, xbytes = 2.0 * (double)g.Nb * g.Cin * (g.taps > 1 ? 1.3 : 1.0);
-        const double xcds_per_slice = g.ksplit >= 8 ? 1.0 : 8.0 / g.ksplit;
-        const double chunk = (double)nt / xcds_per_slice;
-        auto spans = [&](double fast, double slow) {  // fraction of the fast / slow operand panels one XCD's run touches
-            const double f = chunk < fast ? chunk / fast : 1.0;
-            double sl = (chunk / fast + (chunk < fast ? 0.0 : 0.5)) / slow;
-            sl = sl > 1.0 ? 1.0 : (sl < 1.0 / slow ? 1.0 / slow : sl);
-            return std::pair<double, double>(f, sl);
+        const double kbytes = 2.0 * g.taps * g.Cin / (g.ksplit > 0 ? g.ksplit : 1);
+        const double apanel = C::BA * kbytes, bpanel = C::BB * kbytes * (g.taps == 9 ? 1.5 : 1.0);
+        const double conc = 32.0 * C::WAVES_PER_SIMD * 4 / C::NW;  // workgroups an XCD runs at a time (32 CUs x workgroups per CU)
+        auto cost = [&](double gb) {
+            gb = gb > (double)tiles_b ? (double)tiles_b : gb;
+            double da = conc / gb;  // a round of `conc` consecutive tiles spans da weight panels x db row panels
+            da = da > g.tiles_a ? (double)g.tiles_a : (da < 1.0 ? 1.0 : da);
+            double db = conc / da;
+            db = db > (double)tiles_b ? (double)tiles_b : db;
+            return (da * apanel + db * bpanel) / (da * db);  // bytes fetched per tile of the round
         };
-        const auto af = spans((double)g.tiles_a, (double)tiles_b), bf = spans((double)tiles_b, (double)g.tiles_a);
-        const double cost_a = wbytes * af.first + xbytes * af.second, cost_b = xbytes * bf.first + wbytes * bf.second;
-        g.b_fastest = (!order_off && batch == 1 && cost_b < 0.8 * cost_a) ? 1 : 0;
+        double best = cost(1.0);
+        int best_g = 1;
+        for (int gb = 2; gb <= 64; gb *= 2) {
+            const int gbc = gb > tiles_b ? (int)tiles_b : gb;
+            if (cost((double)gbc) < best) {
+                best = cost((double)gbc);
+                best_g = gbc;
+            }
+        }
+        if (cost((double)tiles_b) < best) {
+            best = cost((double)tiles_b);
+            best_g = (int)tiles_b;
+        }
+        // (8-wave tiles only: in situ -- two kernel-stats profiles per setting, profiles/r04_tile_order_in_situ.txt -- the 3x3 convolutions
+        // gain 2.3 ms per job and the GEGLU projections 3.9 ms, but the 64 x 128 four-wave tile, three workgroups per CU on 10-25 us
+        // launches, LOSES 4.8 ms with a grouped order: it keeps the a-fastest one)
+        if (!order_off && batch == 1 && g.ksplit == 1 && C::NW == 8 && best < 0.8 * cost(1.0)) g.group_b = best_g;
     }
     static const bool xcd_ks_off = getenv("FZ_IGEMM_NO_XCD_KS") != nullptr;  // A/B switch of the K-slice -> XCD mapping (tuning only)
     // (3x3 convolutions only: same-box A/B, profiles/r04_xcd_ks_ab.txt -- convolutions with Cin >= 1280 at the 16^2 / 8^2 levels gain

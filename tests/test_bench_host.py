@@ -41,7 +41,10 @@ def test_rooflines_bookkeeping():
             ("conv3x3", 1e12, 5e8): {"launches": 4, "avg_ms": 1.0, "total_ms": 4.0},
             ("gemm_hbm", 6.4e7, 6.4e7): {"launches": 2, "avg_ms": 0.02, "total_ms": 0.04},
             ("gemm_mfma", 4e11, 1e8): {"launches": 2, "avg_ms": 0.5, "total_ms": 1.0},
-            ("capture", 268435456, 268435456): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2}}
+            ("capture", 268435456, 268435456): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2},
+            # a masked inject whose blend mask is all ones reads NO stored row (4th field 0): must not divide by zero anywhere
+            ("inject", 268435456, 268435456, 0): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2},
+            ("inject", 268435456, 268435456, 67108864): {"launches": 2, "avg_ms": 0.1, "total_ms": 0.2}}
     roof, others = bench.rooflines(summ)
     flops = 4.0 * 4096 * 8192 * 320 * (8 + 16) * 10
     assert abs(roof["achieved"] - flops / 15e-3 / 1e12) < 1e-6 and roof["peak"] == 2500.0 and roof["bound"] == "mfma"
@@ -55,6 +58,8 @@ def test_rooflines_bookkeeping():
     gm = [o for o in others if "MFMA class" in o["kernel"]][0]
     assert gh["bound"] == "hbm" and gh["peak"] == 8000.0 and abs(gh["achieved"] - 2 * 6.4e7 / 0.04e-3 / 1e9) < 1e-6
     assert gm["bound"] == "mfma" and abs(gm["achieved"] - 2 * 4e11 / 1e-3 / 1e12) < 1e-6 and abs(gm["algorithmic_GBps"] - 2e8 / 1e-3 / 1e9) < 1e-6
+    inj = [o for o in others if "INJECT" in o["kernel"]][0]
+    assert abs(inj["stored_rows_fraction"] - 0.125) < 1e-12 and abs(inj["achieved_over_rows_read"] - 0.125 * inj["achieved"]) < 1e-9
     cap = [o for o in others if "CAPTURE" in o["kernel"]][0]
     assert abs(cap["achieved"] - 2 * 268435456 / 0.2e-3 / 1e9) < 1e-6 and cap["peak"] == 8000.0
 
@@ -177,3 +182,24 @@ def test_bench_main_two_ranks_frames_mode():
     assert line["scaling"] == "strong" and line["config"]["parallelism"] == "2-way frame-sharded clip"
     assert abs(line["value"] - 2 * 1 / (line["ms_per_step"] / 1e3)) < 1e-6 * line["value"]  # ONE clip's frames over the job time
     assert line["config"]["outputs_finite"] is True
+
+
+def test_line_insurance_prints_the_finished_measurement_when_rank0_dies():
+    """bench.py guards the never-measured multi-GPU probe with a helper process holding the finished clips line: it prints the line if
+    rank 0 dies without a word (abort() from a GPU fault cannot be caught by Python signal handlers), and stays silent after `done`."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent('''
+        import os, sys
+        sys.path.insert(0, %r)
+        import bench
+        p = bench.start_line_insurance({"value": 1.5, "who": "insured"})
+        if sys.argv[1] == "die":
+            os._exit(9)
+        bench.cancel_line_insurance(p)
+    ''' % ROOT)
+    died = subprocess.run([sys.executable, "-c", code, "die"], capture_output=True, text=True, timeout=60)
+    assert died.returncode == 9 and '"who": "insured"' in died.stdout, (died.stdout, died.stderr)
+    ok = subprocess.run([sys.executable, "-c", code, "ok"], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0 and ok.stdout.strip() == "", (ok.stdout, ok.stderr)

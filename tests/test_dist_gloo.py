@@ -280,3 +280,21 @@ def test_peer_transport_clip_matches_single_process(frames, index_list):
     err = float((got.float() - ref.float()).abs().max())
     scale = float(ref.float().abs().max())
     assert torch.isfinite(got.float()).all() and err <= 1.5e-2 * scale, (err, scale)
+
+
+def test_peer_transport_clip_eight_ranks_one_frame_each():
+    """The driver's 8-GPU configuration in miniature: 8 ranks x 8 frames = ONE frame per rank over the peer transport -- a two-frame
+    temporal-conv halo comes from two ranks on each side, the 'first' anchor is served by rank 0 to everybody, every GroupNorm merges
+    eight ranks' partials, every put addresses up to 8 heaps."""
+    got, n_maps, n_local, stats = _spawn(8, 8, [-1, "first"], True, transport="peer")
+    assert stats["blocking"] == 0 and stats["device_side"] == stats["posted"] > 0, stats
+    _, job = _frame_job_factory(8, [-1, "first"])
+    from fatezero_amd import _native
+    try:
+        ref = job()
+    finally:
+        _native.reset_backend()
+    assert n_local == 1 and n_maps and all(n == 1 for n in n_maps), (n_maps, n_local)
+    err = float((got.float() - ref.float()).abs().max())
+    scale = float(ref.float().abs().max())
+    assert torch.isfinite(got.float()).all() and err <= 1.5e-2 * scale, (err, scale)

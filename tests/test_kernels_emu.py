@@ -274,6 +274,14 @@ def test_conv3x3_split_k_slices_mapped_onto_xcds(n, h, w, cin, cout, tile_cfg, s
     KC.case_conv3x3(DEV, n=n, h=h, w=w, cin=cin, cout=cout, with_temb=True, with_res=True, fpb=n, tile_cfg=tile_cfg, split_k=split_k)
 
 
+def test_gemm_grouped_tile_order_covers_every_tile_once():
+    """Launches of the 8-wave tiles with many weight panels take the 2-D grouped tile order (csrc/igemm.hip ig_launch: groups of group_b
+    b-tiles, b fastest inside a group): 30 a-tiles x 6 b-tiles of the 128 x 256 tile -> groups of 4 and a ragged 2; the GEGLU form on the
+    256 x 256 tile (20 x 3 tiles: b-tile fastest).  Every output element must still be right."""
+    KC.case_gemm(DEV, rows=1500, k=64, o=3840, n_res=1, tile_cfg=224223)
+    KC.case_gemm(DEV, rows=700, k=64, o=5120, geglu=True, tile_cfg=244222)
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)
