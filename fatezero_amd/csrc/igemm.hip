@@ -1151,9 +1151,12 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
         if (!order_off && batch == 1 && g.ksplit == 1 && C::NW == 8 && best < 0.8 * cost(1.0)) g.group_b = best_g;
     }
     static const bool xcd_ks_off = getenv("FZ_IGEMM_NO_XCD_KS") != nullptr;  // A/B switch of the K-slice -> XCD mapping (tuning only)
-    // (3x3 convolutions only: same-box A/B, profiles/r04_xcd_ks_ab.txt -- convolutions with Cin >= 1280 at the 16^2 / 8^2 levels gain
-    // 3-6 %, the 640-wide ones are even; the small split-K projections and temporal convolutions -- 10-25 us launches -- lost up to 15 %)
-    const bool flat = (MODE == 1 || MODE == 3) && g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
+    // Which launches: the kernel-level A/B (profiles/r04_xcd_ks_ab.txt: one launch repeated, its weights resident in Infinity Cache) has the
+    // convolutions with Cin >= 1280 gain 3-6 % and the 10-25 us split-K projections / temporal convolutions LOSE up to 15 %; IN SITU (two
+    // kernel-stats profiles per setting, profiles/r04_xcd_ks_in_situ.txt), where the weights come from HBM, the split-K projections gain
+    // 1.9 ms per job and only the temporal convolutions lose (0.6 ms): every mode but the temporal one takes the flat grid.
+    static const bool xcd_ks_all = getenv("FZ_IGEMM_XCD_KS_ALL") != nullptr;  // trial switch: the temporal convolutions as well
+    const bool flat = (MODE != 2 || xcd_ks_all) && g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
     g.nt_flat = flat ? (int)nt : 0;
     dim3 grid(flat ? (unsigned)(nt * g.ksplit) : (unsigned)nt, flat ? 1u : (unsigned)g.ksplit, (unsigned)batch), block(C::T);
     FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT>), grid, block, lds, stream, g);
@@ -1291,6 +1294,7 @@ static const IgTile kTiles[] = {
 #define FZ_SPLITK_LAUNCH_US 3.0  /* fitted; 9.0 (reduce run time + inter-kernel gap at face value) chose too few splits: 32^2 conv 728 -> 561 TF/s */
 #endif
 static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats, int* cfg_out, int* ksplit_out) {
+    static const double splitk_us = getenv("FZ_IGEMM_SPLITK_US") ? atof(getenv("FZ_IGEMM_SPLITK_US")) : FZ_SPLITK_LAUNCH_US;  // (env: in-situ tuning runs)
     double best = 1e300;
     *cfg_out = 212222;
     *ksplit_out = 1;
@@ -1312,7 +1316,7 @@ static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats,
             double us = (double)rounds * (t.fixed_us + (double)((nkt + sk - 1) / sk) * t_step);
             const double floor_us = bytes / 4.0e6;
             us = us > floor_us ? us : floor_us;
-            if (sk > 1) us += FZ_SPLITK_LAUNCH_US + out_elems * sk * 8.0 / 4.0e6;  // reduce launch: its own run time + the inter-kernel gap
+            if (sk > 1) us += splitk_us + out_elems * sk * 8.0 / 4.0e6;  // reduce launch: its own run time + the inter-kernel gap
             if (us < best) {
                 best = us;
                 *cfg_out = t.cfg;

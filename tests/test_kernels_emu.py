@@ -261,8 +261,8 @@ def test_gemm_qkvt_refuses_what_it_cannot_carry():
 @pytest.mark.parametrize("rows,o,tile_cfg,split_k", [(300, 136, 212222, 8), (512, 128, 212222, 2), (256, 136, 222222, 4), (700, 640, 254122, 4),
                                                      (130, 72, 212222, 16)])
 def test_gemm_split_k_ragged_tile_counts(rows, o, tile_cfg, split_k):
-    """Split-K projections with workgroup counts that are multiples of 8 (they stay on the 2-D grid: the flat K-slice -> XCD grid is
-    shipped for the convolutions only, below)."""
+    """Split-K projections with workgroup counts that are multiples of 8 run on the FLAT grid (csrc/igemm.hip: K slices -> XCDs): whole
+    slices per XCD (split 8, 16), half / quarter slices (split 2, 4), ragged tile counts; the result must not depend on the mapping."""
     a = KC.case_gemm(DEV, rows=rows, k=1024, o=o, n_res=1, tile_cfg=tile_cfg, split_k=split_k)
     assert a["max_err"] < 4e-3 * 64
 
