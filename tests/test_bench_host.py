@@ -203,3 +203,54 @@ def test_line_insurance_prints_the_finished_measurement_when_rank0_dies():
     assert died.returncode == 9 and '"who": "insured"' in died.stdout, (died.stdout, died.stderr)
     ok = subprocess.run([sys.executable, "-c", code, "ok"], capture_output=True, text=True, timeout=60)
     assert ok.returncode == 0 and ok.stdout.strip() == "", (ok.stdout, ok.stderr)
+
+
+def test_bench_main_single_rank_with_the_kernel_breakdown_job():
+    """The default single-GPU path INCLUDING the extra job that brackets the conv / GEMM / capture / inject launches with events and
+    the roofline bookkeeping behind it (the multi-rank tests above skip it): one rank, tiny model, CPU emulation."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_harness.py"), "--steps", "1", "--warmup", "0", "--ddim-steps", "2",
+           "--frames", "2", "--latent-size", "8", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, check=True, timeout=600, capture_output=True, text=True, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and isinstance(line["rooflines"], list) and line["config"]["outputs_finite"] is True
+    assert line["config_faithful_n_edit_2"]["outputs_finite"] is True
+
+
+def test_inject_timer_prices_the_rows_really_read():
+    """A masked inject reads only the stored rows whose blend mask is 0: the timer tag carries the map bytes (SURVEY 8(d)'s figure) and,
+    as a 4th field, the bytes of the rows really read -- 0 for an all-ones mask (procedural weights at th = 0.3), which must survive the
+    roofline bookkeeping (it once divided by it)."""
+    import types
+    import torch
+    from fatezero_amd import kernels as K
+
+    class T(bench.KernelTimer):
+        def wrap(self, module, fn_name, select):
+            if fn_name == "attn_self":
+                self.select = select
+    fake = types.SimpleNamespace(FZ_ATTN_FLASH=K.FZ_ATTN_FLASH, FZ_ATTN_CAPTURE=K.FZ_ATTN_CAPTURE, FZ_ATTN_INJECT=K.FZ_ATTN_INJECT,
+                                 kv_slots=K.kv_slots, attn_self=None, conv3x3=None, gemm=None, gemm_qkvt=None)
+    t = T()
+    t.extra = True
+    bench.install_timers(fake, t)
+    q = torch.empty(16, 1024, 640, device="meta")
+    p = torch.empty(8, 8, 1024, 2048, dtype=torch.float16, device="meta")
+    per_frame = 8 * 1024 * 2048 * 2
+    ones = torch.ones(16, 1024)
+    tag = t.select(q, None, None, None, mode=K.FZ_ATTN_INJECT, p=p, n_frames=8, frame0=8, row_mask=ones, mask_frame_off=8)
+    assert tag == ("inject", 8 * per_frame, 8 * per_frame, 0)
+    half = ones.clone()
+    half[8:, :256] = 0.0
+    tag = t.select(q, None, None, None, mode=K.FZ_ATTN_INJECT, p=p, n_frames=8, frame0=8, row_mask=half, mask_frame_off=8)
+    assert tag == ("inject", 8 * per_frame, 8 * per_frame, round(8 * per_frame * 0.25))
+    assert t.select(q, None, None, None, mode=K.FZ_ATTN_INJECT, p=p, n_frames=8, frame0=8)[3] == 8 * per_frame  # no mask: every row
+    assert t.select(q, None, None, None, mode=K.FZ_ATTN_CAPTURE, p=p, n_frames=8) == ("capture", 8 * per_frame, 8 * per_frame)
+    roof, others = bench.rooflines({tag: {"launches": 3, "avg_ms": 0.1, "total_ms": 0.3},
+                                    ("inject", 8 * per_frame, 8 * per_frame, 0): {"launches": 3, "avg_ms": 0.1, "total_ms": 0.3}})
+    assert roof is None and abs(others[0]["stored_rows_fraction"] - 0.125) < 1e-9
