@@ -96,6 +96,10 @@ struct IgArgs {
     half_t* yt;           // [frames][Ma - vt_split][ldyt] or null
     int64_t yt_bs, ldyt;
     int vt_split, vt_rows;
+    // GroupNorm statistics of the STORED output out of the epilogue (the GS instantiation): Welford partials (count, mean, M2) per
+    // (frame, group, 128-row chunk) in the layout gn_finalize reads, gs_out[frame][gs_groups][gs_chunks][3]
+    float* gs_out;
+    int gs_cpg, gs_groups, gs_chunks, gs_rpf;  // channels per group, groups of the whole tensor, chunks per frame, B rows per frame
 };
 
 template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, int PP = 0>
@@ -144,7 +148,10 @@ struct IgCfg {
 // LN: the fz_gemm_ln form (LayerNorm correction of the B rows / row statistics of the output in the epilogue).  Its own
 // instantiation: with the two blocks merely branched around, the 320- and 256-wide tiles of EVERY mode spilled 152-356 VGPRs.
 // VT: the fz_gemm_qkvt form (column tiles at or beyond g.vt_split store transposed).  Its own instantiation for the same reason.
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false>
+// GS > 0: the output's GroupNorm statistics (groups of GS channels) leave the epilogue as Welford partials -- the consumer's fz_groupnorm
+// then skips its statistics kernel.  Own instantiations per group width (10 / 20: 320 / 640 channels over 32 groups), so that the
+// statistics pass is straight-line code with its LDS loads in flight together.
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false, int GS = 0>
 FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::WAVES_PER_SIMD)) igemm_kernel(IgArgs g) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
@@ -983,10 +990,70 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
                 fz_st_h8(dst, o);
+                if constexpr (GS > 0) fz_st_h8(Cs + pl * C::CSTR + ch * 8, o);  // the staging tile now holds what was STORED
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (co + e < Mo_store) dst[e] = (half_t)f[e];
+            }
+        }
+        if constexpr (GS > 0) {
+            // GroupNorm statistics of the RP x CW values this pass stored (the launcher guarantees whole groups per tile, whole
+            // passes per frame, every access on the vector path).  Deterministic: thread (group, slice) sums its RP / 16 rows of the group's
+            // channels in a fixed order -- shifted by the first value it sees, so that sum-of-squares cancellation stays harmless --, one
+            // thread per group Chan-merges the 16 slices in slice order and writes (count, mean, M2) where gn_finalize expects it.
+            constexpr int SL = 16;
+            static_assert(C::RP % SL == 0, "row slices");
+            constexpr int cpg = GS > 0 ? GS : 2, ngrp = C::CW / cpg;
+            float* red = reinterpret_cast<float*>(smem + C::RP * C::CSTR);
+            __syncthreads();
+            for (int item = tid; item < ngrp * SL; item += C::T) {
+                const int gi = item % ngrp, rs = item / ngrp;
+                const half_t* base = Cs + gi * cpg + rs * C::CSTR;
+                // a slice = RP / SL rows x GS channels, read in batches of <= 20 registers with all loads of a batch in flight before the
+                // first use (a runtime-bounded loop of dependent 4-byte reads cost 5-14 us per launch: every read paid its LDS latency)
+                constexpr int ROWS = GS >= 40 ? 1 : (GS >= 20 ? 2 : 4);
+                static_assert((C::RP / SL) % ROWS == 0 && GS % 2 == 0, "row batches");
+                float p0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int r0 = 0; r0 < C::RP / SL; r0 += ROWS) {
+                    half2_t v[ROWS][GS / 2];
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int c = 0; c < GS / 2; ++c) v[r][c] = *reinterpret_cast<const half2_t*>(base + (r0 + r) * SL * C::CSTR + 2 * c);
+                    if (r0 == 0) p0 = (float)v[0][0][0];
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int c = 0; c < GS / 2; ++c) {
+                            const float d0 = (float)v[r][c][0] - p0, d1 = (float)v[r][c][1] - p0;
+                            s1 += d0 + d1;
+                            s2 += d0 * d0 + d1 * d1;
+                        }
+                }
+                const float n = (float)((C::RP / SL) * cpg);
+                red[(gi * SL + rs) * 3 + 0] = n;
+                red[(gi * SL + rs) * 3 + 1] = p0 + s1 / n;
+                red[(gi * SL + rs) * 3 + 2] = s2 - s1 * s1 / n;
+            }
+            __syncthreads();
+            if (tid < ngrp) {
+                float cnt = red[tid * SL * 3], mean = red[tid * SL * 3 + 1], m2 = red[tid * SL * 3 + 2];
+                for (int q = 1; q < SL; ++q) {  // Chan et al., the order gn_finalize uses
+                    const float nb = red[(tid * SL + q) * 3], mb = red[(tid * SL + q) * 3 + 1], m2b = red[(tid * SL + q) * 3 + 2];
+                    const float tot = cnt + nb, delta = mb - mean;
+                    mean += delta * (nb / tot);
+                    m2 += m2b + delta * delta * (cnt * nb / tot);
+                    cnt = tot;
+                }
+                const int64_t px0 = b0 + ps * C::RP;
+                const int64_t fr = px0 / g.gs_rpf;
+                const int chunk = (int)((px0 - fr * g.gs_rpf) / C::RP);
+                float* out = g.gs_out + ((fr * g.gs_groups + (a0 / cpg + tid)) * g.gs_chunks + chunk) * 3;
+                out[0] = cnt;
+                out[1] = mean;
+                out[2] = m2;
             }
         }
     }
@@ -1087,7 +1154,7 @@ FZ_KERNEL void __launch_bounds__(256) conv3x3_small_cin_kernel(IgArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
-template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false>
+template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false, int GS = 0>
 static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
@@ -1104,7 +1171,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FZ_ERR_LAUNCH;
     if (dev >= 64 || !(attr_set_mask.load(std::memory_order_relaxed) >> dev & 1)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT, GS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
         if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
@@ -1159,7 +1226,11 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     const bool flat = (MODE != 2 || xcd_ks_all) && g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
     g.nt_flat = flat ? (int)nt : 0;
     dim3 grid(flat ? (unsigned)(nt * g.ksplit) : (unsigned)nt, flat ? 1u : (unsigned)g.ksplit, (unsigned)batch), block(C::T);
-    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT>), grid, block, lds, stream, g);
+    if constexpr (GS > 0) {  // the statistics scratch (groups x 16 slices x 3 floats) sits behind the staging tile
+        static_assert((C::RP * C::CSTR + 2 * 3 * 16 * (C::CW / GS)) <= C::LDS_HALVES, "GroupNorm-statistics scratch does not fit");
+        static_assert(C::RP == 128, "the partials' chunk is 128 rows whatever the tile");
+    }
+    FZ_LAUNCH((igemm_kernel<WA, TA, WB, TB, BK, NS, MODE, GEGLU, LN, PP, VT, GS>), grid, block, lds, stream, g);
     return fz_last_launch_status();
 }
 
@@ -1270,6 +1341,29 @@ static int ig_dispatch_vt(int cfg, const IgArgs& g, int batch, void* stream) {
     }
 }
 
+// The GS instantiations (GroupNorm statistics of the output out of the epilogue): the two 320-wide ring tiles -- SD-1.x group widths
+// (10 / 20 / 40 channels) divide 320, and both stage their epilogue in passes of 128 rows -- for the projections (MODE 0: proj_out of a
+// transformer) and the temporal convolutions (MODE 2: the LoRA up convolution that ends a PseudoConv3d).
+template <int MODE, int CPG>
+static int ig_dispatch_gs_w(int cfg, const IgArgs& g, int batch, void* stream) {
+    switch (cfg) {
+        case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false, false, 0, false, CPG>(g, batch, stream);
+        case 254122: return ig_launch<2, 5, 4, 1, 64, 2, MODE, false, false, 0, false, CPG>(g, batch, stream);
+        default: return FZ_ERR_BAD_ARG;
+    }
+}
+template <int MODE>
+static int ig_dispatch_gs(int cfg, const IgArgs& g, int batch, void* stream) {
+    if constexpr (MODE == 0 || MODE == 2) {
+        switch (g.gs_cpg) {
+            case 10: return ig_dispatch_gs_w<MODE, 10>(cfg, g, batch, stream);
+            case 20: return ig_dispatch_gs_w<MODE, 20>(cfg, g, batch, stream);
+            default: break;
+        }
+    }
+    return FZ_ERR_BAD_ARG;
+}
+
 struct IgTile {
     int cfg, ba, bb, bk, wg_per_cu;
     double rate_pf;   // PFLOP/s the whole chip sustains in the K loop of this tile with every CU busy (long-K convolutions)
@@ -1364,6 +1458,21 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
     }
     if (ksplit == 0) ksplit = 1;
     if (g.ln_in != nullptr) ksplit = 1;  // the LayerNorm correction lives in the GEMM's own epilogue
+    bool gs_dropped = false;
+    if (g.gs_out != nullptr) {
+        // Statistics leave the epilogue only where the launch the library would pick ANYWAY is a 320-wide ring tile without split-K
+        // (forcing such a tile onto a launch that wants another one costs more than the statistics kernel it saves): otherwise the
+        // launch runs as usual and the caller is told to compute the statistics itself (FZ_GEMM_NO_STATS).
+        const bool ok = (MODE == 0 || MODE == 2) && !GEGLU && ksplit == 1 && (cfg == 254222 || cfg == 254122) && g.ln_in == nullptr &&
+                        g.st_out == nullptr && g.yt == nullptr && batch == 1;
+        if (ok) {
+            g.ksplit = 1;
+            g.part = nullptr;
+            return ig_dispatch_gs<MODE>(cfg, g, batch, stream);
+        }
+        g.gs_out = nullptr;
+        gs_dropped = true;
+    }
     if (g.yt != nullptr) {               // fz_gemm_qkvt: transposed tiles leave from the GEMM's own epilogue as well
         if (GEGLU || MODE != 0 || ksplit != 1 || g.ln_in != nullptr || g.st_out != nullptr) return FZ_ERR_UNSUPPORTED;
         g.ksplit = 1;
@@ -1390,12 +1499,12 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         if (g.ln_in != nullptr || g.st_out != nullptr) return FZ_ERR_UNSUPPORTED;
         rc = ig_dispatch_cfg<MODE, GEGLU>(cfg, g, batch, stream);
     }
-    if (rc != FZ_OK || ksplit == 1) return rc;
+    if (rc != FZ_OK || ksplit == 1) return rc != FZ_OK ? rc : (gs_dropped ? FZ_GEMM_NO_STATS : FZ_OK);
     const int64_t total = g.Nb * (g.Ma / 4) * batch;
     dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
     FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, batch);
     const int rc2 = fz_last_launch_status();
-    return rc2 != FZ_OK ? rc2 : (stats_dropped ? FZ_GEMM_NO_STATS : FZ_OK);
+    return rc2 != FZ_OK ? rc2 : ((stats_dropped || gs_dropped) ? FZ_GEMM_NO_STATS : FZ_OK);
 }
 
 extern "C" int64_t fz_gemm_workspace_floats(int64_t rows, int out_features, int batch) {
@@ -1578,9 +1687,72 @@ FZ_KERNEL void __launch_bounds__(256) temporal_conv3_small_kernel(IgArgs g) {
     }
 }
 
+// GroupNorm-statistics request of fz_gemm_gn / fz_temporal_conv3_gn -> IgArgs (false: the shape cannot carry it; run without)
+static bool ig_gs_setup(IgArgs& g, float* partial, int groups, int64_t rows_per_frame) {
+    if (partial == nullptr || groups <= 0 || groups > 64 || rows_per_frame <= 0) return false;
+    if (g.Ma % groups || g.Ma % 320 || g.Nb % rows_per_frame || rows_per_frame % 128 || rows_per_frame >= (1ll << 31)) return false;
+    const int cpg = g.Ma / groups;
+    if ((cpg != 10 && cpg != 20) ||  // the instantiated group widths (40 -- 1280 channels -- spilled, and its launches split K anyway)
+        (g.ldy % 8) || (g.ldres % 8) || (g.temb != nullptr && (g.temb_stride % 8))) return false;
+    g.gs_out = partial;
+    g.gs_cpg = cpg;
+    g.gs_groups = groups;
+    g.gs_rpf = (int)rows_per_frame;
+    g.gs_chunks = (int)(rows_per_frame / 128);
+    return true;
+}
+
+extern "C" int fz_gn_epilogue_chunks(int64_t rows_per_frame) { return rows_per_frame % 128 == 0 ? (int)(rows_per_frame / 128) : 0; }
+
+extern "C" int fz_gemm_gn(const FzGemmDesc* d, const void* x, const void* w, const void* bias, const void* res, const void* res2, void* y,
+                          float* gn_partial, int gn_groups, int64_t rows_per_frame, void* stream) {
+    if (!d || !x || !w || !y || !gn_partial || d->rows <= 0 || d->in_features <= 0 || d->out_features <= 0) return FZ_ERR_BAD_ARG;
+    if (d->epilogue != FZ_GEMM_PLAIN || d->transpose_out || d->batch > 1 || d->w_batch_stride) return FZ_ERR_UNSUPPORTED;
+    if (d->ldx < d->in_features || d->ldw < d->in_features || (d->ldx % 8) || (d->ldw % 8) || d->ldy < d->out_features) return FZ_ERR_BAD_ARG;
+    IgArgs g = {};
+    g.taps = 1;
+    g.fpb = 1;
+    g.Cin = d->in_features;
+    g.temb_group = 1;
+    g.a = (const half_t*)w;
+    g.lda = d->ldw;
+    g.Ma = g.Ma_store = d->out_features;
+    g.b = (const half_t*)x;
+    g.ldb = d->ldx;
+    g.Nb = d->rows;
+    g.bias = (const half_t*)bias;
+    g.res = (const half_t*)res;
+    g.res2 = (const half_t*)res2;
+    g.y = (half_t*)y;
+    g.ldy = d->ldy;
+    g.ldres = d->ldres ? d->ldres : d->ldy;
+    const bool want = ig_gs_setup(g, gn_partial, gn_groups, rows_per_frame);
+    const int rc = ig_run<0, false>(g, 1, d->tile_cfg, 1, nullptr, 0, stream);
+    return rc != FZ_OK ? rc : (want ? FZ_OK : FZ_GEMM_NO_STATS);
+}
+
+static int temporal_conv3_impl(const void* x, const void* wt, const void* res, const void* res2, const void* temb, int64_t temb_stride,
+                               void* y, int n, int tokens, int cin, int cout, int clip_len, void* workspace, int64_t workspace_floats,
+                               float* gn_partial, int gn_groups, void* stream);
+
+extern "C" int fz_temporal_conv3_gn(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
+                                    int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len, void* workspace,
+                                    int64_t workspace_floats, float* gn_partial, int gn_groups, void* stream) {
+    if (!gn_partial || gn_groups <= 0) return FZ_ERR_BAD_ARG;
+    return temporal_conv3_impl(x, wt, res, res2, temb, temb_stride, y, n, tokens, cin, cout, clip_len, workspace, workspace_floats,
+                               gn_partial, gn_groups, stream);
+}
+
 extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void* res2, const void* temb,
                                 int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len,
                                 void* workspace, int64_t workspace_floats, void* stream) {
+    return temporal_conv3_impl(x, wt, res, res2, temb, temb_stride, y, n, tokens, cin, cout, clip_len, workspace, workspace_floats, nullptr,
+                               0, stream);
+}
+
+static int temporal_conv3_impl(const void* x, const void* wt, const void* res, const void* res2, const void* temb, int64_t temb_stride,
+                               void* y, int n, int tokens, int cin, int cout, int clip_len, void* workspace, int64_t workspace_floats,
+                               float* gn_partial, int gn_groups, void* stream) {
     if (!x || !wt || !y || n <= 0 || tokens <= 0 || clip_len <= 0 || n % clip_len) return FZ_ERR_BAD_ARG;
     IgArgs g = {};
     g.taps = 3;
@@ -1591,9 +1763,12 @@ extern "C" int fz_temporal_conv3(const void* x, const void* wt, const void* res,
         const int64_t total = (int64_t)n * tokens;
         dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
         FZ_LAUNCH(temporal_conv3_small_kernel, grid, block, 0, stream, g);
-        return fz_last_launch_status();
+        const int rc = fz_last_launch_status();
+        return rc != FZ_OK ? rc : (gn_partial ? FZ_GEMM_NO_STATS : FZ_OK);
     }
-    return ig_run<2, false>(g, 1, 0, 0, (float*)workspace, workspace_floats, stream);
+    const bool want = gn_partial != nullptr && ig_gs_setup(g, gn_partial, gn_groups, tokens);
+    const int rc = ig_run<2, false>(g, 1, 0, 0, (float*)workspace, workspace_floats, stream);
+    return rc != FZ_OK ? rc : ((gn_partial != nullptr && !want) ? FZ_GEMM_NO_STATS : FZ_OK);
 }
 
 extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,

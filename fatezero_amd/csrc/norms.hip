@@ -46,6 +46,7 @@ struct GnArgs {
     int n_frames, span, tokens, C, G, chunks, V, R;
     int tb;          // tokens per chunk
     int fin_span;    // frames merged per stat set by gn_finalize (= span unless the partials were gathered from other ranks)
+    int pchunks;     // partial records per (frame, group) that gn_finalize reads (= chunks unless a producer's epilogue wrote them)
     float eps;
     int silu;
 };
@@ -161,13 +162,13 @@ FZ_DEVICE void chan_merge(float& cnt, float& mean, float& m2, float nb, float mb
 // (span sp, group g) -> (mean, rstd): each lane of ONE full wave Chan-merges a strided subset of the span's partials, then a
 // fixed xor-butterfly merges the 64 lane results (deterministic order -> bitwise reproducible statistics, whoever runs it)
 FZ_DEVICE void gn_finalize_group(const GnArgs& a, int sp, int g, int lane, float* mean_out, float* rstd_out) {
-    const int total = a.fin_span * a.chunks;
+    const int total = a.fin_span * a.pchunks;
     float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
     // partial records of (frame f, group g) are contiguous: consecutive lanes read consecutive 12-byte records; four records
     // per lane are in flight before the first merge (the merge chain is serial, the loads must not be)
     auto rec = [&](int e) -> const float* {
-        const int f = e / a.chunks, c = e - f * a.chunks;
-        return a.partial + (((int64_t)(sp * a.fin_span + f) * a.G + g) * a.chunks + c) * 3;
+        const int f = e / a.pchunks, c = e - f * a.pchunks;
+        return a.partial + (((int64_t)(sp * a.fin_span + f) * a.G + g) * a.pchunks + c) * 3;
     };
     int e = lane;
     for (; e + 192 < total; e += 256) {
@@ -502,6 +503,7 @@ static int gn_setup(GnArgs& a, int n_frames, int span, int tokens, int channels,
     a.n_frames = n_frames; a.span = span; a.fin_span = span; a.tokens = tokens; a.C = channels; a.G = groups;
     a.tb = gn_tb(tokens, channels);
     a.chunks = fz_groupnorm_chunks(tokens, channels);
+    a.pchunks = a.chunks;
     a.V = channels / 8;
     if (a.V > 1024) return FZ_ERR_UNSUPPORTED;
     a.R = a.V >= 256 ? 1 : 256 / a.V;
@@ -589,6 +591,26 @@ extern "C" int fz_groupnorm_apply(const void* x, void* y, const void* gamma, con
     a.stats = stats;
     a.fin_span = frames_per_set;
     FZ_LAUNCH(gn_finalize_kernel, dim3(stat_sets * groups), dim3(64), 0, stream, a);
+    FZ_LAUNCH(gn_apply_kernel, dim3(a.chunks, n_frames), dim3(threads), 0, stream, a);
+    return fz_last_launch_status();
+}
+
+extern "C" int fz_groupnorm_from_partials(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span, int tokens,
+                                          int channels, int groups, float eps, int silu, const float* partial, int partial_chunks,
+                                          float* stats, void* stream) {
+    if (!x || !y || !gamma || !beta || !partial || !stats || partial_chunks <= 0) return FZ_ERR_BAD_ARG;
+    GnArgs a;
+    int threads;
+    size_t smem;
+    const int rc = gn_setup(a, n_frames, span, tokens, channels, groups, threads, smem);
+    if (rc != FZ_OK) return rc;
+    a.x = (const half_t*)x; a.x2 = nullptr; a.C1 = channels;
+    a.y = (half_t*)y; a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta;
+    a.eps = eps; a.silu = silu;
+    a.partial = const_cast<float*>(partial);
+    a.stats = stats;
+    a.pchunks = partial_chunks;
+    FZ_LAUNCH(gn_finalize_kernel, dim3((n_frames / span) * groups), dim3(64), 0, stream, a);
     FZ_LAUNCH(gn_apply_kernel, dim3(a.chunks, n_frames), dim3(threads), 0, stream, a);
     return fz_last_launch_status();
 }

@@ -316,6 +316,50 @@ def groupnorm_apply(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, pa
     return out
 
 
+def groupnorm_from_partial(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, partial: torch.Tensor, *, span: int, groups: int,
+                           eps: float, silu: bool) -> torch.Tensor:
+    """GroupNorm(+SiLU) of x [N, tokens, C] from Welford partials [N, groups, chunks, 3] a producer's epilogue wrote (temporal_conv3 /
+    gemm_gn with gn_groups): merge + normalise, no statistics pass over x (fz_groupnorm_from_partials)."""
+    n, tokens, c = x.shape
+    if not (x.is_contiguous() and x.dtype == torch.float16 and partial.is_contiguous() and partial.dtype == torch.float32
+            and partial.dim() == 4 and partial.shape[0] == n and partial.shape[1] == groups and partial.shape[3] == 3 and n % span == 0):
+        raise ValueError("fz_groupnorm_from_partials: x [N, tokens, C] contiguous fp16, partial [N, groups, chunks, 3] fp32")
+    _chk16(x, gamma, beta)
+    out = torch.empty_like(x)
+    stats = torch.empty(n // span, groups, 2, dtype=torch.float32, device=x.device)
+    N.check(N.lib().fz_groupnorm_from_partials(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, span, tokens, c, groups,
+                                               float(eps), 1 if silu else 0, partial.data_ptr(), partial.shape[2], stats.data_ptr(),
+                                               _stream(x)), "fz_groupnorm_from_partials")
+    return out
+
+
+def gemm_gn(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, res: Optional[torch.Tensor] = None, gn_groups: int,
+            rows_per_frame: int):
+    """y = x @ w^T + bias (+ res) as K.gemm, plus the GroupNorm(gn_groups) Welford partials of y [rows / rows_per_frame, gn_groups,
+    rows_per_frame / 128, 3] out of the same launch (fz_gemm_gn); returns (y, partial or None)."""
+    k, o = x.shape[-1], w.shape[0]
+    rows = x.numel() // k
+    if not gn_epilogue_ok(rows_per_frame, o, gn_groups) or rows % rows_per_frame or not x.is_contiguous():
+        return gemm(x, w, bias, res=res), None
+    _chk16(x, w, bias, res)
+    y = torch.empty(tuple(x.shape[:-1]) + (o,), dtype=torch.float16, device=x.device)
+    if res is not None and (not res.is_contiguous() or res.shape != y.shape):
+        return gemm(x, w, bias, res=res), None
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = rows, k, o
+    d.ldx, d.ldw, d.ldy, d.ldres = k, w.stride(0), o, o
+    d.batch, d.epilogue = 1, N.FZ_GEMM_PLAIN
+    partial = torch.empty(rows // rows_per_frame, gn_groups, rows_per_frame // 128, 3, dtype=torch.float32, device=x.device)
+    rc = N.lib().fz_gemm_gn(C.byref(d), x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                            None if res is None else res.data_ptr(), None, y.data_ptr(), partial.data_ptr(), gn_groups, rows_per_frame,
+                            _stream(x))
+    if rc == N.FZ_GEMM_NO_STATS:
+        return y, None
+    if rc:
+        N.check(rc, "fz_gemm_gn")
+    return y, partial
+
+
 def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
     """nn.Conv2d weight [Cout, Cin, 3, 3] -> [Cout, 9, Cin] fp16 (k = tap*Cin + ci contiguous per cout)."""
     return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).to(torch.float16).contiguous()
@@ -609,9 +653,19 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, 
     return out, (ho, wo)
 
 
+def gn_epilogue_ok(tokens: int, cout: int, groups: int) -> bool:
+    """Can a producer of a [N, tokens, cout] tensor emit its GroupNorm(groups) statistics from its epilogue (fz_gemm_gn /
+    fz_temporal_conv3_gn)?  (whole 128-row chunks per frame, 320-wide tiles holding whole groups of an even width)"""
+    if groups <= 0 or cout % groups or cout % 320 or tokens % 128:
+        return False
+    return cout // groups in (10, 20)  # the instantiated group widths (SD-1.x: 320 / 640 channels over 32 groups)
+
+
 def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Optional[torch.Tensor] = None,
-                   res2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, out=None):
-    """x: [N, tokens, Cin]; wt: [Cout, 3, Cin] (nn.Conv1d weight [Cout, Cin, 3] permuted); -> [N, tokens, Cout] (+res)."""
+                   res2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, out=None, gn_groups: int = 0):
+    """x: [N, tokens, Cin]; wt: [Cout, 3, Cin] (nn.Conv1d weight [Cout, Cin, 3] permuted); -> [N, tokens, Cout] (+res).
+    gn_groups > 0: returns (y, partial) -- partial = the Welford partials [N, gn_groups, tokens / 128, 3] of y's GroupNorm statistics
+    written by the launch's own epilogue (fz_temporal_conv3_gn), or None where the launch the library picks cannot produce them."""
     n, tokens, cin = x.shape
     cout = wt.shape[0]
     if not (x.is_contiguous() and wt.is_contiguous() and wt.shape[1] == 3 and wt.shape[2] == cin and x.dtype == torch.float16):
@@ -626,13 +680,27 @@ def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Opt
         assert temb.shape == (n // clip_len, cout) and temb.stride(1) == 1 and temb.dtype == torch.float16
         ts = temb.stride(0)
     use_ws = cout % 4 == 0 and 2 * n * tokens * cout <= _WS_FLOATS
+    if gn_groups > 0:
+        partial = None
+        if gn_epilogue_ok(tokens, cout, gn_groups):
+            partial = torch.empty(n, gn_groups, tokens // 128, 3, dtype=torch.float32, device=x.device)
+            rc = N.lib().fz_temporal_conv3_gn(x.data_ptr(), wt.data_ptr(), None if res is None else res.data_ptr(),
+                                              None if res2 is None else res2.data_ptr(), None if temb is None else temb.data_ptr(), ts,
+                                              out.data_ptr(), n, tokens, cin, cout, clip_len,
+                                              _ws_ptr(x.device) if use_ws else None, _WS_FLOATS if use_ws else 0,
+                                              partial.data_ptr(), gn_groups, _stream(x))
+            if rc == N.FZ_GEMM_NO_STATS:
+                partial = None
+            elif rc:
+                N.check(rc, "fz_temporal_conv3_gn")
+            return out, partial
     rc = N.lib().fz_temporal_conv3(x.data_ptr(), wt.data_ptr(), None if res is None else res.data_ptr(),
                                    None if res2 is None else res2.data_ptr(), None if temb is None else temb.data_ptr(), ts,
                                    out.data_ptr(), n, tokens, cin, cout, clip_len,
                                    _ws_ptr(x.device) if use_ws else None, _WS_FLOATS if use_ws else 0, _stream(x))
     if rc:
         N.check(rc, "fz_temporal_conv3")
-    return out
+    return (out, None) if gn_groups > 0 else out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):

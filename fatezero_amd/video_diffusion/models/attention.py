@@ -439,6 +439,14 @@ class SpatioTemporalTransformerModel(nn.Module):
         h = group_norm_tokens(self.norm, x, span_frames=False, silu=False)
         h = h.like(self.proj_in.apply(h.data))
         h = self.transformer_blocks[0].forward_tokens(h, ctx)
+        from .resnet import GN_FROM_EPILOGUE
+        if GN_FROM_EPILOGUE and D.active_shard() is None:
+            # the next consumer is a GroupNorm (the following resnet's norm1 / conv_norm_out) with the UNet's group count: where the
+            # projection runs on a 320-wide tile its epilogue writes that norm's statistics partials (fz_gemm_gn)
+            y, part = self.proj_out.apply_gn(h.data, res=x.data, groups=self.norm.num_groups, rows_per_frame=x.data.shape[1])
+            out = x.like(y)
+            out.gn = None if part is None else (part, self.norm.num_groups)
+            return out
         return x.like(self.proj_out.apply(h.data, res=x.data))
 
 
@@ -452,8 +460,17 @@ class _Conv1x1Params(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
         self._packed = None
 
-    def apply(self, x, res=None):
+    def _pack(self, x):
         if self._packed is None or self._packed[0].dtype != x.dtype or self._packed[0].device != x.device:
             self._packed = (self.weight.detach().reshape(self.weight.shape[0], -1).to(device=x.device, dtype=x.dtype).contiguous(),
                             self.bias.detach().to(device=x.device, dtype=x.dtype))
-        return K.gemm(x, self._packed[0], self._packed[1], res=res)
+        return self._packed
+
+    def apply(self, x, res=None):
+        w, b = self._pack(x)
+        return K.gemm(x, w, b, res=res)
+
+    def apply_gn(self, x, res, groups, rows_per_frame):
+        """apply() + the GroupNorm(groups) statistics partials of the result out of the same launch: (y, partial or None)."""
+        w, b = self._pack(x)
+        return K.gemm_gn(x, w, b, res=res, gn_groups=groups, rows_per_frame=rows_per_frame)

@@ -29,7 +29,7 @@ def pack_temporal_weight(w, dtype, device):
     return w.detach().permute(0, 2, 1).to(device=device, dtype=dtype).contiguous()
 
 
-def temporal_conv_tokens(x4, w_native, *, rows_add=None, residual=None, residual2=None):
+def temporal_conv_tokens(x4, w_native, *, rows_add=None, residual=None, residual2=None, gn_groups=0):
     """x4: [B, F, T, Cin] token-major; w_native: [Cout][3][Cin]; zero padded 'same' k=3 convolution over F on the native kernel
     (fz_temporal_conv3).  rows_add: [B, Cout] added per batch element (time embedding and / or the Conv1d bias); residuals
     [B*F, T, Cout].  Returns [B, F, T, Cout]."""
@@ -40,6 +40,9 @@ def temporal_conv_tokens(x4, w_native, *, rows_add=None, residual=None, residual
     x3 = x4.reshape(b * f, t, cin)
     if not x3.is_contiguous():
         x3 = x3.contiguous()
+    if gn_groups > 0:  # (y, partial or None): the GroupNorm statistics of y out of the launch's epilogue (fz_temporal_conv3_gn)
+        y, part = K.temporal_conv3(x3, w_native, clip_len=f, res=residual, res2=residual2, temb=rows_add, gn_groups=gn_groups)
+        return y.view(b, f, t, cout), part
     y = K.temporal_conv3(x3, w_native, clip_len=f, res=residual, res2=residual2, temb=rows_add)
     return y.view(b, f, t, cout)
 
@@ -70,8 +73,9 @@ class LoRALinearLayer(nn.Module):
     def is_noop(self, dtype, device):
         return self._pack(dtype, device)[2]
 
-    def forward_tokens(self, x4, temb=None, residual=None):
-        """x4: [B, F, T, C] -> up(down(x)) + x (+ temb[b] broadcast) (+ residual), same shape."""
+    def forward_tokens(self, x4, temb=None, residual=None, gn_groups=0):
+        """x4: [B, F, T, C] -> up(down(x)) + x (+ temb[b] broadcast) (+ residual), same shape.  gn_groups > 0 (single-GPU path): returns
+        (y, partial or None) -- the GroupNorm statistics partials of y out of the up convolution's epilogue."""
         wdn, wun, is_noop = self._pack(x4.dtype, x4.device)
         b, f, t, c = x4.shape
         if is_noop:
@@ -102,7 +106,7 @@ class LoRALinearLayer(nn.Module):
                 y = y + residual.view(b, f, t, c)
             return y
         d = temporal_conv_tokens(x4, wdn)
-        return temporal_conv_tokens(d, wun, rows_add=temb, residual=x4.reshape(b * f, t, c), residual2=residual)
+        return temporal_conv_tokens(d, wun, rows_add=temb, residual=x4.reshape(b * f, t, c), residual2=residual, gn_groups=gn_groups)
 
     @staticmethod
     def _conv(x_ext, w_native):

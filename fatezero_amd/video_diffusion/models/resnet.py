@@ -6,6 +6,7 @@ resnet.py:338,369); every convolution and projection is the MFMA implicit-GEMM k
 copies, no library GEMM / convolution on the path).
 """
 import copy
+import os
 
 import torch
 from torch import nn
@@ -15,12 +16,20 @@ from ... import kernels as K
 from .lora import LoRALinearLayer, _Conv1dParams, pack_temporal_weight, temporal_conv_tokens
 
 
-class Tokens:
-    """A token-major activation: data [N, H*W, C] fp16 plus its frame geometry."""
-    __slots__ = ("data", "b", "f", "h", "w")
+# GroupNorm statistics out of the producing launch's epilogue (fz_temporal_conv3_gn / fz_gemm_gn) where that launch runs on a 320-wide tile
+# without split-K -- the 64^2 level: the consuming GroupNorm then runs finalize + normalise only (no statistics pass over the tensor).
+# The env switch is for same-box A/B runs of bench.py.
+GN_FROM_EPILOGUE = os.environ.get("FZ_NO_GN_EPILOGUE") is None
 
-    def __init__(self, data, b, f, h, w):
-        self.data, self.b, self.f, self.h, self.w = data, b, f, h, w
+
+class Tokens:
+    """A token-major activation: data [N, H*W, C] fp16 plus its frame geometry.  `gn` (optional): (partial, groups) -- the Welford partials
+    of this tensor's GroupNorm statistics, written by the epilogue of the launch that produced it (fz_temporal_conv3_gn / fz_gemm_gn): the
+    GroupNorm that consumes the tensor then skips its statistics pass.  Never inherited by `like()`: it describes exactly this data."""
+    __slots__ = ("data", "b", "f", "h", "w", "gn")
+
+    def __init__(self, data, b, f, h, w, gn=None):
+        self.data, self.b, self.f, self.h, self.w, self.gn = data, b, f, h, w, gn
 
     @property
     def c(self):
@@ -51,7 +60,7 @@ class CatTokens(Tokens):
 
     def __init__(self, a: Tokens, b: Tokens):
         self.parts, self._cat = (a.data, b.data), None
-        self.b, self.f, self.h, self.w = a.b, a.f, a.h, a.w
+        self.b, self.f, self.h, self.w, self.gn = a.b, a.f, a.h, a.w, None
 
     @property
     def data(self):
@@ -114,8 +123,10 @@ class PseudoConv3d(nn.Module):
             self._packed = (w, bias, wtt, btt)
         return self._packed
 
-    def forward_tokens(self, x: Tokens, residual=None, temb=None, upsample=False) -> Tokens:
+    def forward_tokens(self, x: Tokens, residual=None, temb=None, upsample=False, gn_groups: int = 0) -> Tokens:
         """conv (+ temporal conv) (+ temb[b] per batch element) (+ residual). temb: [B, Cout] view, residual: [N, T, Cout].
+        gn_groups > 0: the caller will GroupNorm the result with that many groups -- where the layer's LAST launch can emit the statistics
+        from its epilogue (the LoRA up convolution on a 320-wide tile) the result carries them (`Tokens.gn`).
         Every spatial convolution of the UNet -- all pyramid levels, conv_in, conv_out, the 1x1 shortcuts -- runs through
         the hand-written implicit-GEMM kernel (fz_conv3x3 / fz_gemm); the elementwise tail (time embedding, residual)
         rides in the epilogue of the LAST linear op of the layer (the temporal conv when it is active)."""
@@ -144,8 +155,12 @@ class PseudoConv3d(nn.Module):
                                     temb=temb if fuse_tail else None, frames_per_batch=x.f,
                                     res=residual if fuse_tail else None)
             fused = fuse_tail
+        gn = None
         if lora is not None and temporal_active:
-            y4 = lora.forward_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), temb=temb, residual=residual)
+            y4 = lora.forward_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), temb=temb, residual=residual, gn_groups=gn_groups)
+            if isinstance(y4, tuple):
+                y4, part = y4
+                gn = None if part is None else (part, gn_groups)
             y = y4.reshape(n, oh * ow, self.out_channels)
             fused = True
         elif plain_t:
@@ -165,7 +180,9 @@ class PseudoConv3d(nn.Module):
                 y = (y.view(x.b, x.f * oh * ow, self.out_channels) + temb[:, None, :]).view(n, oh * ow, self.out_channels)
             if residual is not None:
                 y = y + residual
-        return x.like(y, oh, ow)
+        out = x.like(y, oh, ow)
+        out.gn = gn
+        return out
 
 
 class _NormParams(nn.Module):
@@ -197,6 +214,10 @@ def group_norm_tokens(norm: _NormParams, x: Tokens, *, span_frames: bool, silu: 
         allp = shard.all_gather_frames(part.view(n // x.f, x.f, *part.shape[1:]), tag="groupnorm").contiguous()
         y = K.groupnorm_apply(x.data, g, b, allp, span=x.f, groups=norm.num_groups, eps=norm.eps, silu=silu)
         return x.like(y)
+    if not lazy and x.gn is not None and x.gn[1] == norm.num_groups and x.gn[0].shape[0] == x.data.shape[0]:
+        # the producer's epilogue already wrote the statistics partials: merge + normalise only
+        y = K.groupnorm_from_partial(x.data, g, b, x.gn[0], span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps, silu=silu)
+        return Tokens(y, x.b, x.f, x.h, x.w)
     if isinstance(x, CatTokens) and x._cat is None and x.parts[0].shape[-1] % 8 == 0 and x.parts[1].shape[-1] % 8 == 0:
         y = K.groupnorm_cat(x.parts[0], x.parts[1], g, b, span=(x.f if span_frames else 1), groups=norm.num_groups, eps=norm.eps,
                             silu=silu)
@@ -290,10 +311,11 @@ class ResnetBlockPseudo3D(nn.Module):
             temb_proj = getattr(self, "_temb_cached", None)  # set by the UNet: all blocks' projections in one GEMM
             self._temb_cached = None
         t = temb_proj if temb_proj is not None else self.time_emb_proj.apply(temb_act)  # [B, Cout]
-        h = self.conv1.forward_tokens(h, temb=t)
+        gg = self.norm2.num_groups if GN_FROM_EPILOGUE else 0
+        h = self.conv1.forward_tokens(h, temb=t, gn_groups=gg)
         h = group_norm_tokens(self.norm2, h, span_frames=True, silu=True)
         skip = x if self.conv_shortcut is None else self.conv_shortcut.forward_tokens(x)
-        out = self.conv2.forward_tokens(h, residual=skip.data)
+        out = self.conv2.forward_tokens(h, residual=skip.data, gn_groups=gg)  # (its consumer: the next GroupNorm, same group count)
         if self.output_scale_factor != 1.0:
             out = out.like(out.data / self.output_scale_factor)
         return out

@@ -166,7 +166,8 @@ class UNetPseudo3DConditionModel(nn.Module):
         temb_act = self.time_embed(timestep, x.b, x.data.device)
         self._project_time_embeddings(temb_act)
         ctx = ctx.to(torch.float16)
-        x = self.conv_in.forward_tokens(x)
+        from .resnet import GN_FROM_EPILOGUE
+        x = self.conv_in.forward_tokens(x, gn_groups=self.conv_norm_out.num_groups if GN_FROM_EPILOGUE else 0)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk.forward_tokens(x, temb_act, ctx)

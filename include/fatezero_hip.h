@@ -254,6 +254,27 @@ int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void
                       int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len, void* workspace,
                       int64_t workspace_floats, void* stream);
 
+/* GroupNorm statistics out of the PRODUCING launch's epilogue (resnet.py:338,369 norm1 / norm2, attention.py:110 `self.norm`,
+ * unet_3d_condition.py:439 conv_norm_out: each normalises what a projection or a temporal convolution just stored): fz_gemm_gn /
+ * fz_temporal_conv3_gn are fz_gemm (plain epilogue, no batch) / fz_temporal_conv3 that ALSO write the Welford partials (count, mean, M2)
+ * of the stored tensor per (frame, group, 128-row chunk): gn_partial[frames][gn_groups][rows_per_frame / 128][3] floats (fz_temporal_conv3_gn:
+ * rows_per_frame = tokens); fz_groupnorm_from_partials then normalises without a statistics pass over the tensor.  Deterministic (fixed
+ * summation order).  Returns 0 when the partials were written, FZ_GEMM_NO_STATS (> 0) when the launch the library picks for this shape
+ * cannot produce them (tile narrower than 320 columns, split-K, rows_per_frame % 128 != 0, out_features % 320 != 0, odd group width ...):
+ * y is complete, gn_partial untouched -- run fz_groupnorm. */
+int fz_gn_epilogue_chunks(int64_t rows_per_frame); /* rows_per_frame / 128, or 0 when the epilogue form does not apply */
+int fz_gemm_gn(const FzGemmDesc* desc, const void* x, const void* w, const void* bias, const void* res, const void* res2, void* y,
+               float* gn_partial, int gn_groups, int64_t rows_per_frame, void* stream);
+int fz_temporal_conv3_gn(const void* x, const void* wt, const void* res, const void* res2, const void* temb, int64_t temb_stride, void* y,
+                         int n, int tokens, int cin, int cout, int clip_len, void* workspace, int64_t workspace_floats,
+                         float* gn_partial, int gn_groups, void* stream);
+/* GroupNorm (+SiLU) from partials with `partial_chunks` records per (frame, group) -- fz_groupnorm_apply with an explicit record count
+ * (the partials of fz_groupnorm_stats have fz_groupnorm_chunks(tokens, channels) of them): partial [n_frames][groups][partial_chunks][3],
+ * frame n uses the statistics of frames [n / span * span, + span); stats: float scratch [n_frames / span][groups][2]. */
+int fz_groupnorm_from_partials(const void* x, void* y, const void* gamma, const void* beta, int n_frames, int span, int tokens,
+                               int channels, int groups, float eps, int silu, const float* partial, int partial_chunks, float* stats,
+                               void* stream);
+
 /* LayerNorm over channels, rows = tokens (attention.py:193-233). gamma/beta fp16. */
 int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,
                  float eps, void* stream);

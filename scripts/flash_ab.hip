@@ -20,6 +20,7 @@ struct Variant {
     const char* name;
     LaunchFn fn;
     bool distinct;  // kv slots [-1, 'last'] instead of [-1, 'first']: no frame has coinciding slots (every frame reads 2 x Lkf keys)
+    bool k_head_major = false;  // K as a contiguous [frame][head][key][d] tensor (a key tile = 5 KB contiguous) instead of a slice of q | k rows
 };
 
 int main(int argc, char** argv) {
@@ -32,6 +33,10 @@ int main(int argc, char** argv) {
         {"ring2 [-1,last ]: all frames two sources   <40,W2,QB2>", launch_flash<40, 2, 2, true, 2>, true},
         {"QB1 W4 [-1,first]                          <40,W4,QB1>", launch_flash<40, 4, 1, true, 2>, false},
         {"QB1 W4 [-1,last ]                          <40,W4,QB1>", launch_flash<40, 4, 1, true, 2>, true},
+#ifdef FLASH_AB_KHM
+        {"ring2 [-1,first], K head-major [n][h][key][d]  <40,W2,QB2>", launch_flash<40, 2, 2, true, 2>, false, true},
+        {"ring2 [-1,last ], K head-major [n][h][key][d]  <40,W2,QB2>", launch_flash<40, 2, 2, true, 2>, true, true},
+#endif
 #ifdef FLASH_AB_POLY  // exp split: NPOLY of every 32 exponentials on packed FMAs (fz_exp2_poly2) instead of the transcendental unit
         {"exp split  4 / 32 polynomial [-1,first]    <40,W2,QB2>", launch_flash<40, 2, 2, true, 2, 4>, false},
         {"exp split  8 / 32 polynomial [-1,first]    <40,W2,QB2>", launch_flash<40, 2, 2, true, 2, 8>, false},
@@ -65,8 +70,16 @@ int main(int argc, char** argv) {
             hqk[i] = (_Float16)(rnd() * 1.5f * (is_q ? 0.158113883f * 1.44269504f : 1.0f));
         }
         for (auto& x : hv) x = (_Float16)rnd();
-        _Float16 *qk, *vt, *o[12];
-        hipMalloc(&qk, nqk * 2); hipMalloc(&vt, nv * 2);
+        _Float16 *qk, *vt, *o[12], *khm;
+        hipMalloc(&qk, nqk * 2); hipMalloc(&vt, nv * 2); hipMalloc(&khm, (size_t)F * L * C * 2);
+        {   // the same K values, head-major
+            std::vector<_Float16> hk((size_t)F * L * C);
+            for (int n = 0; n < F; ++n)
+                for (int l = 0; l < L; ++l)
+                    for (int c = 0; c < C; ++c)
+                        hk[(((size_t)n * H + c / D) * L + l) * D + c % D] = hqk[((size_t)n * L + l) * 2 * C + C + c];
+            hipMemcpy(khm, hk.data(), hk.size() * 2, hipMemcpyHostToDevice);
+        }
         for (int v = 0; v < NV; ++v) { hipMalloc(&o[v], no * 2); hipMemset(o[v], 0, no * 2); }
         hipMemcpy(qk, hqk.data(), nqk * 2, hipMemcpyHostToDevice);
         hipMemcpy(vt, hv.data(), nv * 2, hipMemcpyHostToDevice);
@@ -79,7 +92,12 @@ int main(int argc, char** argv) {
                 hipEventRecord(e0);
                 FzAttnSelfDesc dv = d;
                 if (vars[v].distinct) dv.kv_val[1] = d.clip_len - 1;
-                for (int i = 0; i < REP; ++i) vars[v].fn(dv, qk, qk + C, vt, o[v], nullptr);
+                const _Float16* kp = qk + C;
+                if (vars[v].k_head_major) {
+                    dv.k_frame_stride = (int64_t)H * L * D; dv.k_row_stride = D; dv.k_head_stride = (int64_t)L * D;
+                    kp = khm;
+                }
+                for (int i = 0; i < REP; ++i) vars[v].fn(dv, qk, kp, vt, o[v], nullptr);
                 hipEventRecord(e1);
                 hipDeviceSynchronize();
                 float t; hipEventElapsedTime(&t, e0, e1);

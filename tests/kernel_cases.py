@@ -564,3 +564,46 @@ def case_gemm_qkvt(device, *, n, l, k, c, tile_cfg=0, seed=0, ldx_extra=0):
     vt2 = K.gemm_vt(x, w[2 * c:], l)
     return {"qk_err": e_qk, "vt_err": e_vt, "qk_bit_equal": bool(torch.equal(qk, qk2)), "vt_bit_equal": bool(torch.equal(vt, vt2)),
             "vt_max_diff_vs_two_launches": float((vt.float() - vt2.float()).abs().max())}
+
+
+def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, producer="tconv", seed=0):
+    """GroupNorm statistics out of the PRODUCING launch's epilogue (fz_temporal_conv3_gn / fz_gemm_gn -> fz_groupnorm_from_partials): the
+    producer's output must be bit-identical to the plain launch, and GroupNorm(+SiLU) from the epilogue's partials must match both the
+    three-kernel fz_groupnorm on the same tensor (to the rounding of the fp32 statistics: an fp16 ulp) and fp32 torch -- for statistics
+    spanning one frame (the transformer's norm) and the whole clip (the resnet norms).  Returns None when the library's launch for this
+    shape cannot carry the statistics (the caller asserts whether it expected that)."""
+    g = torch.Generator().manual_seed(seed)
+    gam = (1 + 0.1 * torch.randn(cout, generator=g)).half().to(device)
+    bet = (0.1 * torch.randn(cout, generator=g)).half().to(device)
+    if producer == "tconv":
+        x = torch.randn(n, tokens, cin, generator=g).half().to(device)
+        w = (torch.randn(cout, 3, cin, generator=g) * (3 * cin) ** -0.5).half().to(device)
+        r1 = (torch.randn(n, tokens, cout, generator=g) * 3 + 2).half().to(device)   # a non-zero mean: the shifted sums must cope
+        temb = torch.randn(n // clip, cout, generator=g).half().to(device)
+        y0 = K.temporal_conv3(x, w, clip_len=clip, res=r1, temb=temb)
+        y1, part = K.temporal_conv3(x, w, clip_len=clip, res=r1, temb=temb, gn_groups=groups)
+    else:
+        x = torch.randn(n, tokens, cin, generator=g).half().to(device)
+        w = (torch.randn(cout, cin, generator=g) * cin ** -0.5).half().to(device)
+        b = torch.randn(cout, generator=g).half().to(device)
+        r1 = (torch.randn(n, tokens, cout, generator=g) * 2 - 1).half().to(device)
+        y0 = K.gemm(x, w, b, res=r1)
+        y1, part = K.gemm_gn(x, w, b, res=r1, gn_groups=groups, rows_per_frame=tokens)
+    assert torch.equal(y0, y1), "the statistics epilogue must not change what is stored"
+    if part is None:
+        return None
+    assert tuple(part.shape) == (n, groups, tokens // 128, 3)
+    res = {}
+    for span in (1, clip):
+        ref = K.groupnorm(y1, gam, bet, span=span, groups=groups, eps=1e-5, silu=True)
+        got = K.groupnorm_from_partial(y1, gam, bet, part, span=span, groups=groups, eps=1e-5, silu=True)
+        yc = y1.float().cpu()
+        t = F.silu(F.group_norm(yc.view(n // span, span, tokens, cout).permute(0, 3, 1, 2).reshape(n // span, cout, -1), groups,
+                                gam.float().cpu(), bet.float().cpu(), 1e-5))
+        t = t.reshape(n // span, cout, span, tokens).permute(0, 2, 3, 1).reshape(n, tokens, cout)
+        e_ref = float((got.float() - ref.float()).abs().max())
+        e_t = float((got.float().cpu() - t).abs().max())
+        assert e_t < 4e-3 * max(1.0, float(t.abs().max())), (span, e_t)
+        assert e_ref <= 2 * 2.0 ** -10 * max(1.0, float(t.abs().max())), (span, e_ref)  # both round the same fp32 statistics: an ulp or two
+        res[f"span{span}"] = {"vs_three_kernel": e_ref, "vs_torch": e_t}
+    return res

@@ -282,6 +282,18 @@ def test_gemm_grouped_tile_order_covers_every_tile_once():
     KC.case_gemm(DEV, rows=700, k=64, o=5120, geglu=True, tile_cfg=244222)
 
 
+def test_groupnorm_statistics_from_the_producing_epilogue():
+    """fz_temporal_conv3_gn / fz_gemm_gn on shapes whose launch is a 320-wide tile (the 64^2 level: 8 x 4096 rows), and on shapes whose
+    launch is not (small / narrow: the call reports it and the plain launch ran)."""
+    r = KC.case_gn_from_epilogue(DEV, n=8, clip=4, tokens=4096, cin=160, cout=320, producer="tconv")
+    assert r is not None, "the 64^2 LoRA up convolution runs on a 320-wide tile: its epilogue must have written the statistics"
+    r = KC.case_gn_from_epilogue(DEV, n=8, clip=2, tokens=4096, cin=320, cout=320, producer="gemm")   # proj_out of the 64^2 level
+    assert r is not None
+    assert KC.case_gn_from_epilogue(DEV, n=2, clip=2, tokens=128, cin=32, cout=320, producer="tconv") is None    # too few rows: another tile
+    assert KC.case_gn_from_epilogue(DEV, n=2, clip=2, tokens=200, cin=32, cout=320, producer="gemm") is None     # 200 % 128 != 0
+    assert KC.case_gn_from_epilogue(DEV, n=2, clip=2, tokens=128, cin=32, cout=96, groups=8, producer="gemm") is None  # 96 % 320 != 0
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)

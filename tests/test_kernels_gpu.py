@@ -273,6 +273,18 @@ def test_gemm_qkvt_one_launch(kw):
     assert r["qk_bit_equal"] and r["vt_bit_equal"], r
 
 
+@pytest.mark.parametrize("kw", [dict(n=8, clip=8, tokens=4096, cin=160, cout=320), dict(n=16, clip=8, tokens=4096, cin=160, cout=320),
+                                dict(n=16, clip=8, tokens=1024, cin=160, cout=640), dict(n=8, clip=8, tokens=4096, cin=320, cout=320, producer="gemm"),
+                                dict(n=16, clip=8, tokens=4096, cin=320, cout=320, producer="gemm")])
+def test_groupnorm_statistics_from_the_producing_epilogue(kw):
+    """The 64^2-level producers of the bench job (LoRA up convolution at 8 / 16 frames, proj_out) and the 640-wide 32^2 one at 16 frames:
+    output bit-identical to the plain launch, GroupNorm from the epilogue's partials vs the three-kernel form and vs fp32 torch."""
+    r = KC.case_gn_from_epilogue(DEV, **kw)
+    print("gn from epilogue", kw, r)
+    if kw["tokens"] == 4096:
+        assert r is not None, "the 64^2 producers run on 320-wide tiles: the statistics must come from their epilogue"
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=8, l=4096, k=320, c=320, lp=4096)
     KC.case_gemm_vt(DEV, n=4, l=1024, k=640, c=640, lp=1024)
