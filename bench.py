@@ -328,6 +328,12 @@ def install_timers(K, timer):
         return gemm_class(x, w, {})
     timer.wrap(K, "gemm_qkvt", sel_qkvt)
 
+    def sel_gemm_gn(x, w, bias=None, **kw):  # a projection whose epilogue also writes the next GroupNorm's statistics (proj_out + residual)
+        if not timer.extra:
+            return None
+        return gemm_class(x, w, kw)
+    timer.wrap(K, "gemm_gn", sel_gemm_gn)
+
 
 def gemm_class(x, w, kw):
     """Roofline class of one projection GEMM (>= 1024 rows).  The launches fall into two regimes: plain projections with
@@ -356,12 +362,12 @@ def install_launch_log(K, path):
     counter rows rocprofv3 writes per dispatch can be attributed to the classes the line reports.  Written at exit."""
     import atexit
     log = []
-    for fn_name in ("gemm", "gemm_vt", "gemm_batched", "gemm_qkvt"):
+    for fn_name in ("gemm", "gemm_vt", "gemm_batched", "gemm_qkvt", "gemm_gn"):
         orig = getattr(K, fn_name)
 
         def wrapped(x, w, *a, _orig=orig, _name=fn_name, **k):
-            if _name in ("gemm", "gemm_qkvt"):
-                tag = gemm_class(x, w, k if _name == "gemm" else {})
+            if _name in ("gemm", "gemm_qkvt", "gemm_gn"):
+                tag = gemm_class(x, w, k if _name != "gemm_qkvt" else {})
                 log.append("gemm_small" if tag is None else tag[0])
             else:
                 log.append(_name)

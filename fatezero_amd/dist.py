@@ -227,9 +227,16 @@ class FrameShard:
         epoch = heap.next_epoch()
         heap.put(mine, off + self.rank * block, list(range(self.world)), epoch)  # into every heap, the own one included
 
+        nb = mine.numel() * mine.element_size()
+        even = self.clip_len % self.world == 0
+
         def finish():
             heap.wait(list(range(self.world)), epoch)
-            blocks = heap.view(off, self.world * block).view(self.world, block)[:, : mine.numel() * mine.element_size()]
+            if even and nb == block:
+                # equal blocks, no padding: ONE copy out of the heap, [world, B, F/P, ...] -> [B, F, ...]
+                allb = heap.view(off, self.world * block).view(mine.dtype).view((self.world, b, self.max_local) + rest)
+                return allb.transpose(0, 1).reshape((b, self.clip_len) + rest) if b > 1 else allb.reshape((1, self.clip_len) + rest).clone()
+            blocks = heap.view(off, self.world * block).view(self.world, block)[:, :nb]
             allb = blocks.contiguous().view(mine.dtype).view((self.world, b, self.max_local) + rest)
             return torch.cat([allb[r, :, : len(self.frames_of(r))] for r in range(self.world)], dim=1)
         return PeerPending(self, finish, tag)
@@ -362,6 +369,7 @@ class PeerHeap:
             raise ValueError("PeerHeap: at most 64 ranks")
         self.world, self.rank, self.nbytes, self.timeout_us = world, rank, int(nbytes), int(timeout_us)
         self.cursor, self.epoch, self._put_count = 0, 0, 0
+        self._ptrs, self._flag_arrays = None, {}
         self.on_gpu = not N.is_test_backend()
         self._side = None
         if self.on_gpu:
@@ -448,14 +456,22 @@ class PeerHeap:
                 self._side = torch.cuda.Stream(device=msg.device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream(msg.device))
+        if self._ptrs is None:  # base addresses of every heap / control block, read once
+            self._ptrs = ([t.data_ptr() for t in self.peer_buf], [t.data_ptr() for t in self.peer_ctl], self.ctl.data_ptr())
+        bufp, ctlp, myctl = self._ptrs
+        ranks = list(ranks)
         for i0 in range(0, len(ranks), 8):
             grp = ranks[i0: i0 + 8]
-            dst = (C.c_void_p * len(grp))(*[self.peer_buf[r].data_ptr() + off for r in grp])
-            flg = (C.c_void_p * len(grp))(*[self.peer_ctl[r].data_ptr() + 4 * self.rank for r in grp])
-            # every put but the last of a multi-group message publishes to a scratch flag (puts of one stream run in order)
-            if i0 + 8 < len(ranks):
-                flg = (C.c_void_p * len(grp))(*[self.ctl.data_ptr() + 4 * (self.N_FLAGS + self.N_DONE + 1)] * len(grp))
-            done = self.ctl.data_ptr() + 4 * (self.N_FLAGS + self._put_count % self.N_DONE)
+            dst = (C.c_void_p * len(grp))(*[bufp[r] + off for r in grp])
+            last = i0 + 8 >= len(ranks)
+            key = (tuple(grp), last)
+            flg = self._flag_arrays.get(key)
+            if flg is None:
+                # every put but the last of a multi-group message publishes to a scratch flag (puts of one stream run in order)
+                flg = (C.c_void_p * len(grp))(*([ctlp[r] + 4 * self.rank for r in grp] if last else
+                                                [myctl + 4 * (self.N_FLAGS + self.N_DONE + 1)] * len(grp)))
+                self._flag_arrays[key] = flg
+            done = myctl + 4 * (self.N_FLAGS + self._put_count % self.N_DONE)
             self._put_count += 1
             if side is not None:
                 with torch.cuda.stream(side):
@@ -471,8 +487,10 @@ class PeerHeap:
         mask = 0
         for r in senders:
             mask |= 1 << r
-        err = self.ctl.data_ptr() + 4 * (self.N_FLAGS + self.N_DONE)
-        N.check(N.lib().fz_peer_wait(self.ctl.data_ptr(), mask, epoch, err, self.timeout_us, K._stream(self.ctl)), "fz_peer_wait")
+        base = self.ctl.data_ptr()
+        rc = N.lib().fz_peer_wait(base, mask, epoch, base + 4 * (self.N_FLAGS + self.N_DONE), self.timeout_us, K._stream(self.ctl))
+        if rc:
+            N.check(rc, "fz_peer_wait")
 
     def check(self):
         """Synchronising: did any wait time out since the last check?"""
