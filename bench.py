@@ -447,6 +447,14 @@ def make_frame_shard(fz_dist, frames, transport, heap_gb, device):
     used = "rccl"
     if transport in ("peer", "auto") and shard.world > 1:
         try:
+            # kernels will store straight into the other GPUs' memory: only where the runtime says every pair of this node's devices has
+            # peer access (a missing link would be a GPU fault, not an exception)
+            n_dev = torch.cuda.device_count() if hasattr(torch.cuda, "device_count") else 1
+            me = device.index if getattr(device, "index", None) is not None else 0
+            if hasattr(torch.cuda, "can_device_access_peer") and n_dev > 1:
+                for other in range(min(n_dev, shard.world)):
+                    if other != me and not torch.cuda.can_device_access_peer(me, other):
+                        raise RuntimeError(f"no peer access between devices {me} and {other}")
             shard.enable_peer_transport(nbytes=int(heap_gb * (1 << 30)), device=device, timeout_us=10_000_000)
             probe = torch.full((1, shard.n_local, 8), float(shard.rank + 1), device=device)
             got = shard.all_gather_frames(probe, tag="selftest")
