@@ -269,7 +269,7 @@ FULL_TGT = "a Porsche car driving down a curvy road in the countryside,"
 
 # Blend threshold of the full-width cases.  With procedural weights the normalised 16^2 blend-word score (spatial_blend.py:24-42:
 # sum over words, mean over heads x layers, 3x3 max-pool, / per-frame max) spreads over 0.23 ... 1.0 with its median near 0.57
-# (build_tmp/mask_struct_exp2.py on the CPU oracle), so the teaser's th = 0.3 keeps 99 % of the rows live -- a mask test that tests
+# (scripts/mask_struct_exp.py on the CPU oracle), so the teaser's th = 0.3 keeps 99 % of the rows live -- a mask test that tests
 # nothing (round-3 review).  Scaling the blend words' context rows saturates the softmax (100 % ones); the YAML knob that DOES move the
 # split is `blend_th` itself (the reference's configs use 0.3 and 2): 0.55 puts 20-80 % of the rows on either side, asserted below.
 FULL_BLEND_TH = 0.55
