@@ -706,6 +706,40 @@ def temporal_conv3(x: torch.Tensor, wt: torch.Tensor, *, clip_len: int, res: Opt
     return (out, None) if gn_groups > 0 else out
 
 
+def lora_pair_ok(n: int, tokens: int, channels: int, rank: int, clip_len: int) -> bool:
+    """Shapes the one-launch temporal LoRA pair carries (fz_lora_pair_ok: rank 160, channels % 320 == 0, clip_len divides 128 ...)."""
+    return bool(N.lib().fz_lora_pair_ok(n, tokens, channels, rank, clip_len))
+
+
+def lora_pair_preferred(n: int, tokens: int, channels: int, rank: int, clip_len: int) -> bool:
+    """Where the one launch is also faster than temporal_conv3 twice (fz_lora_pair_preferred: launches of >= 256 workgroups)."""
+    return bool(N.lib().fz_lora_pair_preferred(n, tokens, channels, rank, clip_len))
+
+
+def lora_pair(x: torch.Tensor, w_down: torch.Tensor, w_up: torch.Tensor, *, clip_len: int, res2: Optional[torch.Tensor] = None,
+              temb: Optional[torch.Tensor] = None, out=None):
+    """up(down(x)) + x (+ temb per clip) (+ res2) of the temporal LoRA (lora.py:31-54) in one launch: x [N, tokens, C],
+    w_down [rank, 3, C], w_up [C, 3, rank] (the packing of temporal_conv3).  Bit-identical to temporal_conv3 twice."""
+    n, tokens, c = x.shape
+    rank = w_down.shape[0]
+    if not (x.is_contiguous() and w_down.is_contiguous() and w_up.is_contiguous() and x.dtype == torch.float16
+            and w_down.shape == (rank, 3, c) and w_up.shape == (c, 3, rank)):
+        raise ValueError("fz_lora_pair: x [N, tokens, C], w_down [rank, 3, C], w_up [C, 3, rank] must be contiguous fp16")
+    if out is None:
+        out = torch.empty_like(x)
+    if res2 is not None:
+        assert res2.is_contiguous() and res2.shape == out.shape and res2.dtype == torch.float16
+    ts = 0
+    if temb is not None:
+        assert temb.shape == (n // clip_len, c) and temb.stride(1) == 1 and temb.dtype == torch.float16
+        ts = temb.stride(0)
+    rc = N.lib().fz_lora_pair(x.data_ptr(), w_down.data_ptr(), w_up.data_ptr(), None if temb is None else temb.data_ptr(), ts,
+                              None if res2 is None else res2.data_ptr(), out.data_ptr(), n, tokens, c, rank, clip_len, _stream(x))
+    if rc:
+        N.check(rc, "fz_lora_pair")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):
     c = x.shape[-1]
     assert x.is_contiguous() and x.dtype == torch.float16

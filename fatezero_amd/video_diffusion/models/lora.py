@@ -5,6 +5,8 @@ activations [B, F, HW, C] a k=3 temporal conv is an implicit GEMM whose three ta
 at the clip ends = lanes pointing at a page of zeros): fz_temporal_conv3 -- no '(b h w) c f' rearrange is materialised
 and no library GEMM is involved.  Parameter names/shapes are the reference's (`down.weight [r, C, 3]`, `up.weight [C, r, 3]`) so checkpoints load unchanged.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -17,6 +19,10 @@ class _Conv1dParams(nn.Module):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cout, cin, k))
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+
+LORA_PAIR_FUSION = os.environ.get("FZ_NO_LORA_PAIR") is None   # A/B switches (scripts/r04v.sh)
+LORA_PAIR_ALWAYS = os.environ.get("FZ_LORA_PAIR_ALWAYS") is not None  # tests: every shape the launch carries, preferred or not
 
 
 def temporal_conv_native_ok(cin, cout):
@@ -105,6 +111,15 @@ class LoRALinearLayer(nn.Module):
             if residual is not None:
                 y = y + residual.view(b, f, t, c)
             return y
+        if LORA_PAIR_FUSION and (K.lora_pair_preferred(b * f, t, c, wdn.shape[0], f)
+                                 or (LORA_PAIR_ALWAYS and K.lora_pair_ok(b * f, t, c, wdn.shape[0], f))):
+            # both convolutions in one launch (fz_lora_pair) where that is the faster form -- the 64^2 level --: the rank-160
+            # intermediate never leaves the workgroup's LDS.  (The launch cannot emit GroupNorm partials: the consumer runs its own pass.)
+            x3 = x4.reshape(b * f, t, c)
+            if not x3.is_contiguous():
+                x3 = x3.contiguous()
+            y = K.lora_pair(x3, wdn, wun, clip_len=f, res2=residual, temb=temb).view(b, f, t, c)
+            return (y, None) if gn_groups > 0 else y
         d = temporal_conv_tokens(x4, wdn)
         return temporal_conv_tokens(d, wun, rows_add=temb, residual=x4.reshape(b * f, t, c), residual2=residual, gn_groups=gn_groups)
 

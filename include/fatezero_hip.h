@@ -254,6 +254,19 @@ int fz_temporal_conv3(const void* x, const void* wt, const void* res, const void
                       int64_t temb_stride, void* y, int n, int tokens, int cin, int cout, int clip_len, void* workspace,
                       int64_t workspace_floats, void* stream);
 
+/* The temporal LoRA pair of a PseudoConv3d in ONE launch (lora.py:31-54 LoRALinearLayer.forward: `up(down(x)) + x`, called from
+ * resnet.py:57-80): y = conv1d_3(conv1d_3(x, w_down), w_up) + x (+ temb per clip) (+ res2), both convolutions zero padded over the
+ * frame axis of each clip; the rank-`rank` intermediate is rounded to fp16 once and never leaves the workgroup's LDS.  Bit-identical
+ * to fz_temporal_conv3 called twice (without split-K).  x, res2, y: [n][tokens][channels]; w_down [rank][3][channels];
+ * w_up [channels][3][rank]; temb as for fz_temporal_conv3.  fz_lora_pair_ok: 1 where the launch exists (rank == 160,
+ * channels % 320 == 0, channels <= 1280, clip_len divides 128, tokens % (128 / clip_len) == 0); fz_lora_pair returns
+ * FZ_ERR_UNSUPPORTED elsewhere -- call fz_temporal_conv3 twice. */
+int fz_lora_pair_ok(int n, int tokens, int channels, int rank, int clip_len);
+/* 1 where the one launch is also the FASTER form on MI355X (it needs >= 256 workgroups of 128 rows: n * tokens >= 32768) */
+int fz_lora_pair_preferred(int n, int tokens, int channels, int rank, int clip_len);
+int fz_lora_pair(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2, void* y,
+                 int n, int tokens, int channels, int rank, int clip_len, void* stream);
+
 /* GroupNorm statistics out of the PRODUCING launch's epilogue (resnet.py:338,369 norm1 / norm2, attention.py:110 `self.norm`,
  * unet_3d_condition.py:439 conv_norm_out: each normalises what a projection or a temporal convolution just stored): fz_gemm_gn /
  * fz_temporal_conv3_gn are fz_gemm (plain epilogue, no batch) / fz_temporal_conv3 that ALSO write the Welford partials (count, mean, M2)

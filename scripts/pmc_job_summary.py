@@ -18,6 +18,8 @@ def klass(name):
         return ("capture" if m.group(2) == "1" else "inject") if m else "attn_self"
     if "igemm_reduce" in name:
         return "splitk_reduce"
+    if "lora_pair_kernel" in name:  # both temporal LoRA convolutions in one launch (csrc/lora_pair.hip)
+        return "temporal_conv"
     if "igemm_kernel" in name:
         m = re.search(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)", name)
         mode = int(m.group(7))

@@ -607,3 +607,44 @@ def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, prod
         assert e_ref <= 2 * 2.0 ** -10 * max(1.0, float(t.abs().max())), (span, e_ref)  # both round the same fp32 statistics: an ulp or two
         res[f"span{span}"] = {"vs_three_kernel": e_ref, "vs_torch": e_t}
     return res
+
+
+def case_lora_pair(device, *, batch, clip, tokens, c, with_temb=True, with_res2=True, seed=0, up_scale=1.0):
+    """fz_lora_pair (up(down(x)) + x (+ temb) (+ res2) of the temporal LoRA in one launch, lora.py:31-54) against (1) fz_temporal_conv3
+    called twice -- bit for bit: same fp16 rounding of the rank-160 intermediate, same K order, same epilogue order -- and (2) fp32 torch
+    conv1d with the intermediate rounded to fp16."""
+    g = torch.Generator().manual_seed(seed)
+    n, rank = batch * clip, 160
+    x = torch.randn(n, tokens, c, generator=g).half().to(device)
+    wd = (torch.randn(rank, c, 3, generator=g) * (3 * c) ** -0.5).half()
+    wu = (torch.randn(c, rank, 3, generator=g) * up_scale * (3 * rank) ** -0.5).half()
+    temb = torch.randn(batch, c, generator=g).half().to(device) if with_temb else None
+    res2 = torch.randn(n, tokens, c, generator=g).half().to(device) if with_res2 else None
+    wdn, wun = wd.permute(0, 2, 1).contiguous().to(device), wu.permute(0, 2, 1).contiguous().to(device)
+    assert K.lora_pair_ok(n, tokens, c, rank, clip)
+    y = K.lora_pair(x, wdn, wun, clip_len=clip, res2=res2, temb=temb)
+
+    def conv_no_split(xi, wt, res=None, r2=None, rows=None):  # fz_temporal_conv3 without a workspace: no split-K, one K order
+        from fatezero_amd import _native as N
+        out = torch.empty(n, tokens, wt.shape[0], dtype=torch.float16, device=device)
+        rc = N.lib().fz_temporal_conv3(xi.data_ptr(), wt.data_ptr(), None if res is None else res.data_ptr(),
+                                       None if r2 is None else r2.data_ptr(), None if rows is None else rows.data_ptr(),
+                                       0 if rows is None else rows.stride(0), out.data_ptr(), n, tokens, xi.shape[2], wt.shape[0], clip,
+                                       None, 0, K._stream(xi))
+        assert rc == 0, rc
+        return out
+
+    y2 = conv_no_split(conv_no_split(x, wdn), wun, res=x, r2=res2, rows=temb)
+    same = torch.equal(y, y2)
+    assert same, float((y.float() - y2.float()).abs().max())
+    xr = x.float().cpu().reshape(batch, clip, tokens, c).permute(0, 2, 3, 1).reshape(batch * tokens, c, clip)
+    dr = F.conv1d(xr, wd.float(), None, padding=1).half().float()
+    yr = F.conv1d(dr, wu.float(), None, padding=1).reshape(batch, tokens, c, clip).permute(0, 3, 1, 2).reshape(n, tokens, c)
+    yr = yr + x.float().cpu()
+    if with_temb:
+        yr = yr + temb.float().cpu().repeat_interleave(clip, 0)[:, None, :]
+    if with_res2:
+        yr = yr + res2.float().cpu()
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
+    return {"max_err": err, "bit_identical_to_two_launches": same}

@@ -300,6 +300,23 @@ def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=1, l=200, k=32, c=32, lp=256, tile_cfg=222222)
 
 
+def test_lora_pair_one_launch():
+    """fz_lora_pair (both temporal LoRA convolutions in one launch) on the emulator: bit-identical to fz_temporal_conv3 twice; clip
+    lengths 1 ... 16 (tokens per workgroup 128 ... 8), every channel count of the UNet, with / without the time-embedding row and the
+    second residual; and the shapes it refuses."""
+    for kw in [dict(batch=1, clip=8, tokens=32, c=320), dict(batch=2, clip=4, tokens=64, c=640, with_temb=False),
+               dict(batch=1, clip=16, tokens=16, c=320, with_res2=False), dict(batch=2, clip=1, tokens=128, c=320),
+               dict(batch=1, clip=2, tokens=64, c=1280)]:
+        assert KC.case_lora_pair(DEV, **kw)["bit_identical_to_two_launches"]
+    assert not K.lora_pair_ok(6, 64, 320, 160, 3)      # 3 frames do not divide the 128-row tile
+    assert not K.lora_pair_ok(8, 40, 320, 160, 8)      # 40 tokens: not a multiple of 128 / 8
+    assert not K.lora_pair_ok(8, 64, 160, 160, 8)      # channels % 320
+    assert not K.lora_pair_ok(8, 64, 320, 2, 8)        # conv_out's rank-2 pair stays on the direct kernel
+    x = torch.zeros(6, 64, 320, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        K.lora_pair(x, torch.zeros(160, 3, 320, dtype=torch.float16), torch.zeros(320, 3, 160, dtype=torch.float16), clip_len=3)
+
+
 def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=3, tokens=20, cin=64, cout=32, with_res=False)
     KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)

@@ -292,6 +292,16 @@ def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=3, l=1296, k=320, c=320, lp=1344)
 
 
+@pytest.mark.parametrize("kw", [dict(batch=2, clip=8, tokens=4096, c=320), dict(batch=1, clip=16, tokens=1024, c=640),
+                                dict(batch=2, clip=8, tokens=256, c=1280), dict(batch=1, clip=8, tokens=64, c=1280, with_temb=False),
+                                dict(batch=1, clip=4, tokens=1024, c=320, with_res2=False), dict(batch=3, clip=1, tokens=128, c=640)],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_lora_pair_one_launch(kw):
+    """fz_lora_pair: bit-identical to fz_temporal_conv3 twice, and fp32 torch within fp16 rounding."""
+    r = KC.case_lora_pair(DEV, **kw)
+    assert r["bit_identical_to_two_launches"]
+
+
 def test_temporal_conv3():
     KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=320, cout=160, with_res=False)
     KC.case_temporal_conv3(DEV, batch=2, clip=8, tokens=4096, cin=160, cout=320, with_res=True)
