@@ -101,6 +101,8 @@ _SIGS = {
                                     _P]),
     "fz_lora_pair_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "fz_lora_pair_preferred": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fz_lora_pair_gn_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fz_lora_pair_gn": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "fz_lora_pair": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "fz_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "fz_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),

@@ -34,8 +34,9 @@ struct LoraPairArgs {
     const half_t* temb;  // [N / F] rows of C values, temb_stride apart, or null
     const half_t* res2;  // [N][tokens][C] or null
     half_t* y;           // [N][tokens][C]
+    float* gs_out;       // GS instantiations: Welford partials [N][gs_groups][gs_chunks][3] of y's GroupNorm statistics
     int64_t temb_stride;
-    int N, tokens, C, F, tok_blk, blocks_per_clip;
+    int N, tokens, C, F, tok_blk, blocks_per_clip, gs_groups, gs_chunks;
 };
 
 // LDS map (halves).  Phase 1 ring and {Dl, phase 2 ring} alias: D is written after the last phase-1 tile was consumed.
@@ -49,9 +50,12 @@ struct LoraPairArgs {
 #define LP_NS1 3
 #define LP_NS2 4
 #define LP_LDS_HALVES (LP_RING2 + LP_NS2 * LP_STAGE2)
-static_assert(LP_NS1 * LP_STAGE1 <= LP_LDS_HALVES && LP_DL_HALVES <= LP_RING2 && 64 * LP_CSTR <= LP_NS2 * LP_STAGE2, "LDS map");
+static_assert(LP_NS1 * LP_STAGE1 <= LP_LDS_HALVES && LP_DL_HALVES <= LP_RING2 && 64 * LP_CSTR + 512 * 3 * 2 <= LP_NS2 * LP_STAGE2, "LDS map");
 static_assert(LP_LDS_HALVES * 2 <= 160 * 1024, "LDS");
 
+// GS = channels per GroupNorm group (0: no statistics; 10 / 20: the launch also writes the Welford partials of what it stores, as the GS
+// instantiations of csrc/igemm.hip do -- one record per (frame, group, min(64, 128 / F)-row piece of the workgroup's tile)).
+template <int GS>
 FZ_KERNEL void __launch_bounds__(512, 2) lora_pair_kernel(LoraPairArgs g) {
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
@@ -254,6 +258,60 @@ FZ_KERNEL void __launch_bounds__(512, 2) lora_pair_kernel(LoraPairArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (half_t)fv[e];
                 fz_st_h8(g.y + px * C + co, o);
+                if constexpr (GS > 0) fz_st_h8(Cs + pl * LP_CSTR + ch * 8, o);  // the staging tile now holds what was STORED
+            }
+            if constexpr (GS > 0) {
+                // GroupNorm statistics of the 64 rows x 320 columns this pass stored.  Thread (group gi, row slice rs) sums RPT consecutive
+                // rows of the group's GS channels, shifted by the first value it sees (all LDS loads in flight before the first use); one
+                // thread per (frame piece, group) Chan-merges the piece's slices in slice order.  Deterministic.
+                constexpr int NGRP = 320 / GS, RPT = NGRP / 8, SL = 64 / RPT;
+                static_assert(NGRP * SL == 512 && GS % 2 == 0, "one (group, slice) item per thread");
+                float* red = reinterpret_cast<float*>(Cs + 64 * LP_CSTR);
+                __syncthreads();
+                {
+                    const int gi = tid % NGRP, rs = tid / NGRP;
+                    const half_t* base = Cs + gi * GS + rs * RPT * LP_CSTR;
+                    half2_t v[RPT][GS / 2];
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                        for (int c = 0; c < GS / 2; ++c) v[r][c] = *reinterpret_cast<const half2_t*>(base + r * LP_CSTR + 2 * c);
+                    const float p0 = (float)v[0][0][0];
+                    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                        for (int c = 0; c < GS / 2; ++c) {
+                            const float d0 = (float)v[r][c][0] - p0, d1 = (float)v[r][c][1] - p0;
+                            s1 += d0 + d1;
+                            s2 += d0 * d0 + d1 * d1;
+                        }
+                    const float n = (float)(RPT * GS);
+                    red[(gi * SL + rs) * 3 + 0] = n;
+                    red[(gi * SL + rs) * 3 + 1] = p0 + s1 / n;
+                    red[(gi * SL + rs) * 3 + 2] = s2 - s1 * s1 / n;
+                }
+                __syncthreads();
+                const int rows_rec = TOK < 64 ? TOK : 64;       // rows of one frame inside this pass
+                const int spr = rows_rec / RPT;                 // slices per record
+                if (tid < NGRP * (64 / rows_rec)) {
+                    const int gi = tid % NGRP, piece = tid / NGRP;
+                    const float* q0 = red + (gi * SL + piece * spr) * 3;
+                    float cnt = q0[0], mean = q0[1], m2 = q0[2];
+                    for (int q = 1; q < spr; ++q) {  // Chan et al., the order gn_finalize uses
+                        const float nb = q0[q * 3], mb = q0[q * 3 + 1], m2b = q0[q * 3 + 2];
+                        const float tot = cnt + nb, delta = mb - mean;
+                        mean += delta * (nb / tot);
+                        m2 += m2b + delta * delta * (cnt * nb / tot);
+                        cnt = tot;
+                    }
+                    const int r0 = ps * 64 + piece * rows_rec, f = r0 / TOK;
+                    const int chunk = tblk * (TOK > 64 ? TOK / 64 : 1) + (r0 - f * TOK) / 64;
+                    float* out = g.gs_out + (((int64_t)(clip * F + f) * g.gs_groups + at * NGRP + gi) * g.gs_chunks + chunk) * 3;
+                    out[0] = cnt;
+                    out[1] = mean;
+                    out[2] = m2;
+                }
             }
         }
         __syncthreads();  // the staging tile is read: the next slice's prologue may refill the ring
@@ -273,8 +331,18 @@ extern "C" int fz_lora_pair_preferred(int n, int tokens, int channels, int rank,
     return (int64_t)n * tokens / LP_ROWS >= 256 ? 1 : 0;
 }
 
-extern "C" int fz_lora_pair(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2,
-                            void* y, int n, int tokens, int channels, int rank, int clip_len, void* stream) {
+// records per (frame, group) of the statistics form, or 0 where it does not exist: group width 10 / 20 (320 / 640 channels in 32 groups),
+// >= 4 rows of a frame per workgroup (clip_len <= 32)
+extern "C" int fz_lora_pair_gn_chunks(int n, int tokens, int channels, int rank, int clip_len, int gn_groups) {
+    if (gn_groups <= 0 || channels % gn_groups || !fz_lora_pair_ok(n, tokens, channels, rank, clip_len)) return 0;
+    const int cpg = channels / gn_groups, tok = LP_ROWS / clip_len;
+    if ((cpg != 10 && cpg != 20) || tok < 4) return 0;
+    return tokens / tok * (tok > 64 ? tok / 64 : 1);
+}
+
+static int lora_pair_launch(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2,
+                            void* y, int n, int tokens, int channels, int rank, int clip_len, float* gn_partial, int gn_groups,
+                            void* stream) {
     if (!x || !w_down || !w_up || !y) return FZ_ERR_BAD_ARG;
     if (!fz_lora_pair_ok(n, tokens, channels, rank, clip_len)) return FZ_ERR_UNSUPPORTED;
     if (temb != nullptr && (temb_stride % 8)) return FZ_ERR_UNSUPPORTED;
@@ -285,19 +353,47 @@ extern "C" int fz_lora_pair(const void* x, const void* w_down, const void* w_up,
     g.N = n; g.tokens = tokens; g.C = channels; g.F = clip_len;
     g.tok_blk = LP_ROWS / clip_len;
     g.blocks_per_clip = tokens / g.tok_blk;
+    int gs = 0;
+    if (gn_partial != nullptr) {
+        g.gs_chunks = fz_lora_pair_gn_chunks(n, tokens, channels, rank, clip_len, gn_groups);
+        if (g.gs_chunks == 0) return FZ_ERR_UNSUPPORTED;
+        g.gs_out = gn_partial; g.gs_groups = gn_groups;
+        gs = channels / gn_groups;
+    }
     const int64_t blocks = (int64_t)(n / clip_len) * g.blocks_per_clip;
     if (blocks <= 0 || blocks >= (1ll << 31)) return FZ_ERR_BAD_ARG;
     const size_t lds = (size_t)LP_LDS_HALVES * sizeof(half_t);
+    void (*kern)(LoraPairArgs) = gs == 10 ? &lora_pair_kernel<10> : (gs == 20 ? &lora_pair_kernel<20> : &lora_pair_kernel<0>);
 #ifndef FZ_EMU
-    static unsigned long long attr_mask = 0;
+    static unsigned long long attr_mask[3] = {0, 0, 0};
+    const int ki = gs == 10 ? 1 : (gs == 20 ? 2 : 0);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FZ_ERR_LAUNCH;
-    if (dev >= 64 || !((attr_mask >> dev) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (dev >= 64 || !((attr_mask[ki] >> dev) & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FZ_ERR_LAUNCH;
-        if (dev < 64) attr_mask |= 1ull << dev;
+        if (dev < 64) attr_mask[ki] |= 1ull << dev;
     }
 #endif
-    FZ_LAUNCH(lora_pair_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+    if (gs == 10) {
+        FZ_LAUNCH(lora_pair_kernel<10>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+    } else if (gs == 20) {
+        FZ_LAUNCH(lora_pair_kernel<20>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+    } else {
+        FZ_LAUNCH(lora_pair_kernel<0>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+    }
+    (void)kern;
     return fz_last_launch_status();
+}
+
+extern "C" int fz_lora_pair(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2,
+                            void* y, int n, int tokens, int channels, int rank, int clip_len, void* stream) {
+    return lora_pair_launch(x, w_down, w_up, temb, temb_stride, res2, y, n, tokens, channels, rank, clip_len, nullptr, 0, stream);
+}
+
+extern "C" int fz_lora_pair_gn(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2,
+                               void* y, int n, int tokens, int channels, int rank, int clip_len, float* gn_partial, int gn_groups,
+                               void* stream) {
+    if (!gn_partial) return FZ_ERR_BAD_ARG;
+    return lora_pair_launch(x, w_down, w_up, temb, temb_stride, res2, y, n, tokens, channels, rank, clip_len, gn_partial, gn_groups, stream);
 }

@@ -159,19 +159,27 @@ FZ_DEVICE void chan_merge(float& cnt, float& mean, float& m2, float nb, float mb
     }
 }
 
-// (span sp, group g) -> (mean, rstd): each lane of ONE full wave Chan-merges a strided subset of the span's partials, then a
-// fixed xor-butterfly merges the 64 lane results (deterministic order -> bitwise reproducible statistics, whoever runs it)
-FZ_DEVICE void gn_finalize_group(const GnArgs& a, int sp, int g, int lane, float* mean_out, float* rstd_out) {
-    const int total = a.fin_span * a.pchunks;
-    float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
-    // partial records of (frame f, group g) are contiguous: consecutive lanes read consecutive 12-byte records; four records
-    // per lane are in flight before the first merge (the merge chain is serial, the loads must not be)
+// Chan-merge of the records [e0, e1) of (span sp, group g) by one full wave: lane l takes e0 + l, e0 + l + 64, ... in that order (eight, then
+// four records per lane in flight before the first merge: the merge chain is serial, the loads must not be), then the fixed butterfly.
+FZ_DEVICE void gn_merge_range(const GnArgs& a, int sp, int g, int lane, int e0, int e1, float& cnt, float& mean, float& m2) {
+    cnt = 0.0f; mean = 0.0f; m2 = 0.0f;
+    // partial records of (frame f, group g) are contiguous: consecutive lanes read consecutive 12-byte records
     auto rec = [&](int e) -> const float* {
         const int f = e / a.pchunks, c = e - f * a.pchunks;
         return a.partial + (((int64_t)(sp * a.fin_span + f) * a.G + g) * a.pchunks + c) * 3;
     };
-    int e = lane;
-    for (; e + 192 < total; e += 256) {
+    int e = e0 + lane;
+    for (; e + 448 < e1; e += 512) {
+        float r[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* pp = rec(e + 64 * u);
+            r[u][0] = pp[0]; r[u][1] = pp[1]; r[u][2] = pp[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) chan_merge(cnt, mean, m2, r[u][0], r[u][1], r[u][2]);
+    }
+    for (; e + 192 < e1; e += 256) {
         float r[4][3];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -181,7 +189,7 @@ FZ_DEVICE void gn_finalize_group(const GnArgs& a, int sp, int g, int lane, float
 #pragma unroll
         for (int u = 0; u < 4; ++u) chan_merge(cnt, mean, m2, r[u][0], r[u][1], r[u][2]);
     }
-    for (; e < total; e += 64) {
+    for (; e < e1; e += 64) {
         const float* pp = rec(e);
         chan_merge(cnt, mean, m2, pp[0], pp[1], pp[2]);
     }
@@ -194,6 +202,13 @@ FZ_DEVICE void gn_finalize_group(const GnArgs& a, int sp, int g, int lane, float
         chan_merge(c0, me0, q0, c1, me1, q1);
         cnt = c0; mean = me0; m2 = q0;
     }
+}
+
+// (span sp, group g) -> (mean, rstd) by ONE full wave over all of the span's partials (deterministic order -> bitwise reproducible
+// statistics, whoever runs it)
+FZ_DEVICE void gn_finalize_group(const GnArgs& a, int sp, int g, int lane, float* mean_out, float* rstd_out) {
+    float cnt, mean, m2;
+    gn_merge_range(a, sp, g, lane, 0, a.fin_span * a.pchunks, cnt, mean, m2);
     const float var = m2 / cnt;  // biased, as torch.nn.GroupNorm
     *mean_out = mean;
     *rstd_out = 1.0f / sqrtf(var + a.eps);
@@ -206,6 +221,26 @@ FZ_KERNEL void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {  // one wave
     if (threadIdx.x == 0) {
         a.stats[(sp * a.G + g) * 2 + 0] = mean;
         a.stats[(sp * a.G + g) * 2 + 1] = rstd;
+    }
+}
+
+// The same for spans with thousands of records (the partials of fz_lora_pair_gn: one record per (frame, group, 128 / clip_len tokens)): four
+// waves per (span, group), each over a contiguous quarter of the records, merged in wave order.
+#define GN_WIDE_RECORDS 1024
+FZ_KERNEL void __launch_bounds__(256) gn_finalize_wide_kernel(GnArgs a) {
+    FZ_SHARED float part[4][3];
+    const int sp = (int)blockIdx.x / a.G, g = (int)blockIdx.x % a.G;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int total = a.fin_span * a.pchunks, per = (total + 3) / 4;
+    float cnt, mean, m2;
+    gn_merge_range(a, sp, g, lane, min(wave * per, total), min((wave + 1) * per, total), cnt, mean, m2);
+    if (lane == 0) { part[wave][0] = cnt; part[wave][1] = mean; part[wave][2] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = part[0][0]; mean = part[0][1]; m2 = part[0][2];
+        for (int w = 1; w < 4; ++w) chan_merge(cnt, mean, m2, part[w][0], part[w][1], part[w][2]);
+        a.stats[(sp * a.G + g) * 2 + 0] = mean;
+        a.stats[(sp * a.G + g) * 2 + 1] = 1.0f / sqrtf(m2 / cnt + a.eps);
     }
 }
 
@@ -610,7 +645,11 @@ extern "C" int fz_groupnorm_from_partials(const void* x, void* y, const void* ga
     a.partial = const_cast<float*>(partial);
     a.stats = stats;
     a.pchunks = partial_chunks;
-    FZ_LAUNCH(gn_finalize_kernel, dim3((n_frames / span) * groups), dim3(64), 0, stream, a);
+    if ((int64_t)span * partial_chunks > GN_WIDE_RECORDS) {
+        FZ_LAUNCH(gn_finalize_wide_kernel, dim3((n_frames / span) * groups), dim3(256), 0, stream, a);
+    } else {
+        FZ_LAUNCH(gn_finalize_kernel, dim3((n_frames / span) * groups), dim3(64), 0, stream, a);
+    }
     FZ_LAUNCH(gn_apply_kernel, dim3(a.chunks, n_frames), dim3(threads), 0, stream, a);
     return fz_last_launch_status();
 }

@@ -717,9 +717,11 @@ def lora_pair_preferred(n: int, tokens: int, channels: int, rank: int, clip_len:
 
 
 def lora_pair(x: torch.Tensor, w_down: torch.Tensor, w_up: torch.Tensor, *, clip_len: int, res2: Optional[torch.Tensor] = None,
-              temb: Optional[torch.Tensor] = None, out=None):
+              temb: Optional[torch.Tensor] = None, out=None, gn_groups: int = 0):
     """up(down(x)) + x (+ temb per clip) (+ res2) of the temporal LoRA (lora.py:31-54) in one launch: x [N, tokens, C],
-    w_down [rank, 3, C], w_up [C, 3, rank] (the packing of temporal_conv3).  Bit-identical to temporal_conv3 twice."""
+    w_down [rank, 3, C], w_up [C, 3, rank] (the packing of temporal_conv3).  Bit-identical to temporal_conv3 twice.
+    gn_groups > 0: returns (y, partial) -- the Welford partials [N, gn_groups, chunks, 3] of y's GroupNorm statistics out of the same launch
+    (fz_lora_pair_gn), or (y, None) where that form does not exist."""
     n, tokens, c = x.shape
     rank = w_down.shape[0]
     if not (x.is_contiguous() and w_down.is_contiguous() and w_up.is_contiguous() and x.dtype == torch.float16
@@ -733,11 +735,18 @@ def lora_pair(x: torch.Tensor, w_down: torch.Tensor, w_up: torch.Tensor, *, clip
     if temb is not None:
         assert temb.shape == (n // clip_len, c) and temb.stride(1) == 1 and temb.dtype == torch.float16
         ts = temb.stride(0)
-    rc = N.lib().fz_lora_pair(x.data_ptr(), w_down.data_ptr(), w_up.data_ptr(), None if temb is None else temb.data_ptr(), ts,
-                              None if res2 is None else res2.data_ptr(), out.data_ptr(), n, tokens, c, rank, clip_len, _stream(x))
+    args = (x.data_ptr(), w_down.data_ptr(), w_up.data_ptr(), None if temb is None else temb.data_ptr(), ts,
+            None if res2 is None else res2.data_ptr(), out.data_ptr(), n, tokens, c, rank, clip_len)
+    if gn_groups > 0:
+        chunks = N.lib().fz_lora_pair_gn_chunks(n, tokens, c, rank, clip_len, gn_groups)
+        if chunks > 0:
+            partial = torch.empty(n, gn_groups, chunks, 3, dtype=torch.float32, device=x.device)
+            N.check(N.lib().fz_lora_pair_gn(*args, partial.data_ptr(), gn_groups, _stream(x)), "fz_lora_pair_gn")
+            return out, partial
+    rc = N.lib().fz_lora_pair(*args, _stream(x))
     if rc:
         N.check(rc, "fz_lora_pair")
-    return out
+    return (out, None) if gn_groups > 0 else out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None):

@@ -22,6 +22,7 @@ class _Conv1dParams(nn.Module):
 
 
 LORA_PAIR_FUSION = os.environ.get("FZ_NO_LORA_PAIR") is None   # A/B switches (scripts/r04v.sh)
+LORA_PAIR_GN = os.environ.get("FZ_NO_LORA_PAIR_GN") is None
 LORA_PAIR_ALWAYS = os.environ.get("FZ_LORA_PAIR_ALWAYS") is not None  # tests: every shape the launch carries, preferred or not
 
 
@@ -114,10 +115,13 @@ class LoRALinearLayer(nn.Module):
         if LORA_PAIR_FUSION and (K.lora_pair_preferred(b * f, t, c, wdn.shape[0], f)
                                  or (LORA_PAIR_ALWAYS and K.lora_pair_ok(b * f, t, c, wdn.shape[0], f))):
             # both convolutions in one launch (fz_lora_pair) where that is the faster form -- the 64^2 level --: the rank-160
-            # intermediate never leaves the workgroup's LDS.  (The launch cannot emit GroupNorm partials: the consumer runs its own pass.)
+            # intermediate never leaves the workgroup's LDS
             x3 = x4.reshape(b * f, t, c)
             if not x3.is_contiguous():
                 x3 = x3.contiguous()
+            if gn_groups > 0 and LORA_PAIR_GN:   # + the GroupNorm partials of y out of the same launch (fz_lora_pair_gn)
+                y, part = K.lora_pair(x3, wdn, wun, clip_len=f, res2=residual, temb=temb, gn_groups=gn_groups)
+                return y.view(b, f, t, c), part
             y = K.lora_pair(x3, wdn, wun, clip_len=f, res2=residual, temb=temb).view(b, f, t, c)
             return (y, None) if gn_groups > 0 else y
         d = temporal_conv_tokens(x4, wdn)

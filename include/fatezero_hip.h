@@ -266,6 +266,13 @@ int fz_lora_pair_ok(int n, int tokens, int channels, int rank, int clip_len);
 int fz_lora_pair_preferred(int n, int tokens, int channels, int rank, int clip_len);
 int fz_lora_pair(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2, void* y,
                  int n, int tokens, int channels, int rank, int clip_len, void* stream);
+/* fz_lora_pair that ALSO writes the Welford partials (count, mean, M2) of y's GroupNorm statistics (resnet.py:338,369: the norm that follows
+ * the convolution), for fz_groupnorm_from_partials: gn_partial[n][gn_groups][chunks][3] floats with chunks = fz_lora_pair_gn_chunks(...)
+ * records per (frame, group) -- one per min(64, 128 / clip_len)-row piece of a workgroup's tile; 0 where the form does not exist (group
+ * width other than 10 / 20 channels, clip_len > 32), and fz_lora_pair_gn then returns FZ_ERR_UNSUPPORTED.  y is bit-identical to fz_lora_pair's. */
+int fz_lora_pair_gn_chunks(int n, int tokens, int channels, int rank, int clip_len, int gn_groups);
+int fz_lora_pair_gn(const void* x, const void* w_down, const void* w_up, const void* temb, int64_t temb_stride, const void* res2, void* y,
+                    int n, int tokens, int channels, int rank, int clip_len, float* gn_partial, int gn_groups, void* stream);
 
 /* GroupNorm statistics out of the PRODUCING launch's epilogue (resnet.py:338,369 norm1 / norm2, attention.py:110 `self.norm`,
  * unet_3d_condition.py:439 conv_norm_out: each normalises what a projection or a temporal convolution just stored): fz_gemm_gn /

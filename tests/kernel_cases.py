@@ -609,7 +609,7 @@ def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, prod
     return res
 
 
-def case_lora_pair(device, *, batch, clip, tokens, c, with_temb=True, with_res2=True, seed=0, up_scale=1.0):
+def case_lora_pair(device, *, batch, clip, tokens, c, with_temb=True, with_res2=True, seed=0, up_scale=1.0, gn_groups=0):
     """fz_lora_pair (up(down(x)) + x (+ temb) (+ res2) of the temporal LoRA in one launch, lora.py:31-54) against (1) fz_temporal_conv3
     called twice -- bit for bit: same fp16 rounding of the rank-160 intermediate, same K order, same epilogue order -- and (2) fp32 torch
     conv1d with the intermediate rounded to fp16."""
@@ -647,4 +647,26 @@ def case_lora_pair(device, *, batch, clip, tokens, c, with_temb=True, with_res2=
         yr = yr + res2.float().cpu()
     err = (y.float().cpu() - yr).abs().max().item()
     assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
-    return {"max_err": err, "bit_identical_to_two_launches": same}
+    res = {"max_err": err, "bit_identical_to_two_launches": same}
+    if gn_groups > 0:
+        # fz_lora_pair_gn: the same y, plus Welford partials from which GroupNorm(+SiLU) must match the three-kernel fz_groupnorm on the same
+        # tensor (to the rounding of the fp32 statistics) and fp32 torch, for statistics over one frame and over the clip
+        y3, part = K.lora_pair(x, wdn, wun, clip_len=clip, res2=res2, temb=temb, gn_groups=gn_groups)
+        assert torch.equal(y3, y), "the statistics epilogue must not change what is stored"
+        res["partial"] = None if part is None else tuple(part.shape)
+        if part is not None:
+            gam = (1 + 0.1 * torch.randn(c, generator=g)).half().to(device)
+            bet = (0.1 * torch.randn(c, generator=g)).half().to(device)
+            for span in (1, clip):
+                ref = K.groupnorm(y, gam, bet, span=span, groups=gn_groups, eps=1e-5, silu=True)
+                got = K.groupnorm_from_partial(y, gam, bet, part, span=span, groups=gn_groups, eps=1e-5, silu=True)
+                yc = y.float().cpu()
+                t = F.silu(F.group_norm(yc.view(n // span, span, tokens, c).permute(0, 3, 1, 2).reshape(n // span, c, -1), gn_groups,
+                                        gam.float().cpu(), bet.float().cpu(), 1e-5))
+                t = t.reshape(n // span, c, span, tokens).permute(0, 2, 3, 1).reshape(n, tokens, c)
+                e_ref = float((got.float() - ref.float()).abs().max())
+                e_t = float((got.float().cpu() - t).abs().max())
+                assert e_t < 4e-3 * max(1.0, float(t.abs().max())), (span, e_t)
+                assert e_ref <= 2 * 2.0 ** -10 * max(1.0, float(t.abs().max())), (span, e_ref)
+                res[f"gn_span{span}"] = {"vs_three_kernel": e_ref, "vs_torch": e_t}
+    return res

@@ -304,10 +304,14 @@ def test_lora_pair_one_launch():
     """fz_lora_pair (both temporal LoRA convolutions in one launch) on the emulator: bit-identical to fz_temporal_conv3 twice; clip
     lengths 1 ... 16 (tokens per workgroup 128 ... 8), every channel count of the UNet, with / without the time-embedding row and the
     second residual; and the shapes it refuses."""
-    for kw in [dict(batch=1, clip=8, tokens=32, c=320), dict(batch=2, clip=4, tokens=64, c=640, with_temb=False),
-               dict(batch=1, clip=16, tokens=16, c=320, with_res2=False), dict(batch=2, clip=1, tokens=128, c=320),
-               dict(batch=1, clip=2, tokens=64, c=1280)]:
-        assert KC.case_lora_pair(DEV, **kw)["bit_identical_to_two_launches"]
+    for kw in [dict(batch=1, clip=8, tokens=32, c=320, gn_groups=32), dict(batch=2, clip=4, tokens=64, c=640, with_temb=False, gn_groups=32),
+               dict(batch=1, clip=16, tokens=16, c=320, with_res2=False, gn_groups=32), dict(batch=2, clip=1, tokens=256, c=320, gn_groups=32),
+               dict(batch=1, clip=2, tokens=64, c=1280), dict(batch=1, clip=32, tokens=8, c=320, gn_groups=32)]:
+        r = KC.case_lora_pair(DEV, **kw)   # gn_groups: + fz_lora_pair_gn's partials -> GroupNorm like the three-kernel form (span 1 and clip)
+        assert r["bit_identical_to_two_launches"] and (not kw.get("gn_groups") or r["partial"] is not None)
+    assert KC.case_lora_pair(DEV, batch=1, clip=2, tokens=64, c=1280, gn_groups=32)["partial"] is None   # 40 channels per group: no statistics form
+    # 8 frames x 2048 tokens: 128 records per (frame, group), 1024 per clip -> still the one-wave finalize; x 4096 tokens -> the four-wave one
+    assert KC.case_lora_pair(DEV, batch=1, clip=8, tokens=4096, c=320, gn_groups=32)["partial"] == (8, 32, 256, 3)
     assert not K.lora_pair_ok(6, 64, 320, 160, 3)      # 3 frames do not divide the 128-row tile
     assert not K.lora_pair_ok(8, 40, 320, 160, 8)      # 40 tokens: not a multiple of 128 / 8
     assert not K.lora_pair_ok(8, 64, 160, 160, 8)      # channels % 320
@@ -355,3 +359,35 @@ def test_igemm_with_early_landing_dma(monkeypatch):
         KC.case_gemm(DEV, rows=70, k=k, o=72, tile_cfg=254218)
     KC.case_temporal_conv3(DEV, batch=1, clip=4, tokens=70, cin=32, cout=64, with_res=True)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)
+
+
+def test_resnet_block_over_the_one_launch_lora_pair():
+    """ResnetBlockPseudo3D at 320 channels through its three temporal-LoRA forms -- fz_temporal_conv3 twice, fz_lora_pair, fz_lora_pair_gn
+    (the second GroupNorm and the next block's first one then normalise from the launch's partials) -- agree to an fp16 ulp of the output
+    (the two-launch form may split K; the GroupNorm statistics round differently)."""
+    from fatezero_amd.video_diffusion.models import lora as L
+    from fatezero_amd.video_diffusion.models import resnet as R
+    torch.manual_seed(0)
+    blk = R.ResnetBlockPseudo3D(in_channels=320, out_channels=320, temb_channels=64, groups=32, model_config={"lora": 160}).half()
+    for m in blk.modules():
+        if isinstance(m, L.LoRALinearLayer):
+            torch.nn.init.normal_(m.up.weight, std=0.05)   # (the reference initialises `up` with zeros: the pair would be skipped)
+    for name, p in blk.named_parameters():
+        if p.dim() == 4:
+            torch.nn.init.normal_(p, std=(p.shape[1] * 9) ** -0.5)
+    b, f, h, w = 1, 8, 4, 4
+    x = R.Tokens(torch.randn(b * f, h * w, 320).half(), b, f, h, w)
+    temb = torch.randn(b, 64).half()
+    saved = (L.LORA_PAIR_FUSION, L.LORA_PAIR_ALWAYS, L.LORA_PAIR_GN)
+    outs = {}
+    try:
+        for mode in ("two", "pair", "pair_gn"):
+            L.LORA_PAIR_FUSION, L.LORA_PAIR_ALWAYS, L.LORA_PAIR_GN = mode != "two", True, mode == "pair_gn"
+            o = blk.forward_tokens(x, temb)
+            assert (o.gn is not None) == (mode == "pair_gn")   # the block's output carries partials for the NEXT GroupNorm
+            outs[mode] = o.data.float()
+    finally:
+        L.LORA_PAIR_FUSION, L.LORA_PAIR_ALWAYS, L.LORA_PAIR_GN = saved
+    scale = float(outs["two"].abs().max())
+    for mode in ("pair", "pair_gn"):
+        assert float((outs["two"] - outs[mode]).abs().max()) <= 2 * 2.0 ** -10 * max(1.0, scale), mode

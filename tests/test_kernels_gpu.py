@@ -294,12 +294,16 @@ def test_gemm_transposed_output():
 
 @pytest.mark.parametrize("kw", [dict(batch=2, clip=8, tokens=4096, c=320), dict(batch=1, clip=16, tokens=1024, c=640),
                                 dict(batch=2, clip=8, tokens=256, c=1280), dict(batch=1, clip=8, tokens=64, c=1280, with_temb=False),
-                                dict(batch=1, clip=4, tokens=1024, c=320, with_res2=False), dict(batch=3, clip=1, tokens=128, c=640)],
+                                dict(batch=1, clip=4, tokens=1024, c=320, with_res2=False), dict(batch=3, clip=1, tokens=128, c=640),
+                                dict(batch=1, clip=8, tokens=4096, c=320, gn_groups=32), dict(batch=2, clip=16, tokens=4096, c=320, gn_groups=32),
+                                dict(batch=1, clip=8, tokens=4096, c=640, gn_groups=32), dict(batch=2, clip=2, tokens=256, c=640, gn_groups=32)],
                          ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_lora_pair_one_launch(kw):
-    """fz_lora_pair: bit-identical to fz_temporal_conv3 twice, and fp32 torch within fp16 rounding."""
+    """fz_lora_pair: bit-identical to fz_temporal_conv3 twice, and fp32 torch within fp16 rounding; gn_groups: fz_lora_pair_gn's partials
+    normalise like the three-kernel GroupNorm (thousands of records per statistics set: the four-wave finalize)."""
     r = KC.case_lora_pair(DEV, **kw)
     assert r["bit_identical_to_two_launches"]
+    assert not kw.get("gn_groups") or r["partial"] is not None
 
 
 def test_temporal_conv3():
