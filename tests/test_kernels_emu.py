@@ -306,7 +306,8 @@ def test_lora_pair_one_launch():
     second residual; and the shapes it refuses."""
     for kw in [dict(batch=1, clip=8, tokens=32, c=320, gn_groups=32), dict(batch=2, clip=4, tokens=64, c=640, with_temb=False, gn_groups=32),
                dict(batch=1, clip=16, tokens=16, c=320, with_res2=False, gn_groups=32), dict(batch=2, clip=1, tokens=256, c=320, gn_groups=32),
-               dict(batch=1, clip=2, tokens=64, c=1280), dict(batch=1, clip=32, tokens=8, c=320, gn_groups=32)]:
+               dict(batch=1, clip=2, tokens=64, c=1280), dict(batch=1, clip=32, tokens=8, c=320, gn_groups=32),
+               dict(batch=3, clip=2, tokens=192, c=320, gn_groups=32), dict(batch=1, clip=128, tokens=3, c=320)]:   # (one token per frame and workgroup)
         r = KC.case_lora_pair(DEV, **kw)   # gn_groups: + fz_lora_pair_gn's partials -> GroupNorm like the three-kernel form (span 1 and clip)
         assert r["bit_identical_to_two_launches"] and (not kw.get("gn_groups") or r["partial"] is not None)
     assert KC.case_lora_pair(DEV, batch=1, clip=2, tokens=64, c=1280, gn_groups=32)["partial"] is None   # 40 channels per group: no statistics form
