@@ -440,12 +440,26 @@ def rooflines(summ):
     return roof, others
 
 
+def _all_ranks_ok(ok, device):
+    """Collective agreement on a local success flag: True only when EVERY rank of the default group reports success (a rank that falls back to
+    the collectives while its peers stay on the peer transport would deadlock the first exchange of the UNet)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 def make_frame_shard(fz_dist, frames, transport, heap_gb, device):
     """FrameShard for this job + the transport that carries its exchanges.  'peer' / 'auto': map the peers' symmetric heaps and run ONE
-    small all-gather through them as a self-test (bounded wait); 'auto' falls back to the collectives when that fails."""
+    small all-gather through them as a self-test (bounded wait); 'auto' falls back to the collectives when that fails.  The outcome of
+    every stage (peer access, heap mapping + self-test) is AGREED over the process group (all_reduce MIN of a success flag): all ranks
+    take the same transport, whichever rank saw the failure."""
     shard = fz_dist.FrameShard(frames)
     used = "rccl"
     if transport in ("peer", "auto") and shard.world > 1:
+        why = None
         try:
             # kernels will store straight into the other GPUs' memory: only where the runtime says every pair of this node's devices has
             # peer access (a missing link would be a GPU fault, not an exception)
@@ -455,20 +469,31 @@ def make_frame_shard(fz_dist, frames, transport, heap_gb, device):
                 for other in range(min(n_dev, shard.world)):
                     if other != me and not torch.cuda.can_device_access_peer(me, other):
                         raise RuntimeError(f"no peer access between devices {me} and {other}")
-            shard.enable_peer_transport(nbytes=int(heap_gb * (1 << 30)), device=device, timeout_us=10_000_000)
-            probe = torch.full((1, shard.n_local, 8), float(shard.rank + 1), device=device)
-            got = shard.all_gather_frames(probe, tag="selftest")
-            torch.cuda.synchronize()
-            shard.heap.check()
-            want = torch.cat([torch.full((1, len(shard.frames_of(r)), 8), float(r + 1)) for r in range(shard.world)], 1)
-            if not torch.equal(got.cpu(), want):
-                raise RuntimeError("peer transport self-test returned wrong data")
+        except Exception as e:  # noqa: BLE001
+            why = repr(e)
+        if not _all_ranks_ok(why is None, device):  # before the collective heap exchange: nobody enters it alone
+            why = why or "a peer rank has no peer access"
+        else:
+            try:
+                shard.enable_peer_transport(nbytes=int(heap_gb * (1 << 30)), device=device, timeout_us=10_000_000)
+                probe = torch.full((1, shard.n_local, 8), float(shard.rank + 1), device=device)
+                got = shard.all_gather_frames(probe, tag="selftest")
+                torch.cuda.synchronize()
+                shard.heap.check()
+                want = torch.cat([torch.full((1, len(shard.frames_of(r)), 8), float(r + 1)) for r in range(shard.world)], 1)
+                if not torch.equal(got.cpu(), want):
+                    raise RuntimeError("peer transport self-test returned wrong data")
+            except Exception as e:  # noqa: BLE001 -- whatever went wrong, the collectives still work
+                why = repr(e)
+            if not _all_ranks_ok(why is None, device):
+                why = why or "the peer transport self-test failed on another rank"
+        if why is None:
             used = "peer"
-        except Exception as e:  # noqa: BLE001 -- whatever went wrong, the collectives still work
+        else:
             if transport == "peer":
-                raise
+                raise RuntimeError(f"--transport peer: {why}")
             shard.heap = None
-            used = f"rccl (peer transport unavailable: {e!r})"
+            used = f"rccl (peer transport unavailable: {why})"
     shard.stats = {"posted": 0, "overlapped": 0, "blocking": 0, "device_side": 0}
     return shard, used
 
@@ -548,10 +573,11 @@ def main():
                          "(default) measures clips first, then the frame-sharded clip (K timed jobs under a watchdog), and reports the "
                          "frame-sharded number as `value` when frames >= 2 x GPUs, it completed and was not slower than ONE GPU on the clip -- the "
                          "other one rides beside it")
-    ap.add_argument("--transport", choices=["auto", "peer", "rccl"], default="auto",
+    ap.add_argument("--transport", choices=["auto", "peer", "rccl"], default="rccl",
                     help="what carries the exchanges of a frame-sharded clip: 'peer' = one-sided puts into peer-mapped symmetric heaps "
                          "(csrc/peer.hip: no collective call on the data path), 'rccl' = torch.distributed collectives; 'auto' = peer when "
-                         "its self-test round trip succeeds, else rccl (the line says which)")
+                         "its self-test round trip succeeds on EVERY rank, else rccl (the line says which).  Default rccl: the peer transport "
+                         "has met HIP IPC between two processes on one GPU but never xGMI -- opt in with --transport auto / peer")
     ap.add_argument("--peer-heap-gb", type=float, default=2.0, help="symmetric heap per GPU for --transport peer")
     ap.add_argument("--no-frame-shard-probe", action="store_true",
                     help="N > 1, --shard clips: skip the extra frame-sharded job reported under `frame_sharded` (it runs AFTER the clips "

@@ -1038,7 +1038,9 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
                 red[(gi * SL + rs) * 3 + 2] = s2 - s1 * s1 / n;
             }
             __syncthreads();
-            if (tid < ngrp) {
+            // (a pass that lies wholly beyond Nb -- the second 128-row pass of the last 256-row tile when Nb % 256 == 128 -- holds stale
+            //  staging rows and has no record to write: its frame index would be n_frames)
+            if (tid < ngrp && b0 + ps * C::RP < g.Nb) {
                 float cnt = red[tid * SL * 3], mean = red[tid * SL * 3 + 1], m2 = red[tid * SL * 3 + 2];
                 for (int q = 1; q < SL; ++q) {  // Chan et al., the order gn_finalize uses
                     const float nb = red[(tid * SL + q) * 3], mb = red[(tid * SL + q) * 3 + 1], m2b = red[(tid * SL + q) * 3 + 2];
@@ -1626,6 +1628,16 @@ extern "C" int fz_gemm_qkvt(const FzGemmDesc* d, const void* x, const void* w, v
     g.ldyt = ldyt;
     g.vt_split = split_col;
     g.vt_rows = (int)rows_per_frame;
+    if (d->tile_cfg != 0) {  // a pinned tile must not straddle the k | v boundary either (ig_choose checks this for its own picks only)
+        int ba = 0;
+        switch (d->tile_cfg) {
+            case 254222: case 254122: ba = 320; break;
+            case 224223: case 222222: ba = 128; break;
+            case 212222: ba = 64; break;
+            default: return FZ_ERR_BAD_ARG;
+        }
+        if (split_col % ba) return FZ_ERR_BAD_ARG;
+    }
     return ig_run<0, false>(g, 1, d->tile_cfg, 1, nullptr, 0, stream);
 }
 

@@ -370,6 +370,7 @@ class PeerHeap:
         self.world, self.rank, self.nbytes, self.timeout_us = world, rank, int(nbytes), int(timeout_us)
         self.cursor, self.epoch, self._put_count = 0, 0, 0
         self._ptrs, self._flag_arrays = None, {}
+        self._side_event = None  # completion of the newest side-stream put (puts must publish their epochs in order, see put())
         self.on_gpu = not N.is_test_backend()
         self._side = None
         if self.on_gpu:
@@ -450,12 +451,20 @@ class PeerHeap:
             padded[:nbytes] = flat
             msg, nbytes = padded, padded.numel()
         assert off % 16 == 0 and off + nbytes <= self.nbytes
+        # A receiver waits with `flag >= epoch` on ONE flag word per sender, so a sender's puts must complete in the order of their
+        # epochs: a small put (epoch e + 1, main stream) overtaking a large one (epoch e, side stream) would let wait(e) pass before
+        # the panel has landed, and the late put would then move the flag BACK to e.  Side-stream puts are ordered among themselves
+        # (one stream) and behind everything queued on the main stream at their post (wait_stream); a main-stream put waits for the
+        # newest side-stream put's event.  Re-use of a heap region is ordered by the same chain.
         side = None
         if self.on_gpu and nbytes >= self.SIDE_STREAM_BYTES:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=msg.device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream(msg.device))
+        elif self.on_gpu and self._side_event is not None:
+            torch.cuda.current_stream(msg.device).wait_event(self._side_event)
+            self._side_event = None
         if self._ptrs is None:  # base addresses of every heap / control block, read once
             self._ptrs = ([t.data_ptr() for t in self.peer_buf], [t.data_ptr() for t in self.peer_ctl], self.ctl.data_ptr())
         bufp, ctlp, myctl = self._ptrs
@@ -476,6 +485,7 @@ class PeerHeap:
             if side is not None:
                 with torch.cuda.stream(side):
                     rc = N.lib().fz_peer_put(msg.data_ptr(), nbytes, dst, flg, len(grp), epoch, done, K._stream(msg))
+                    self._side_event = side.record_event()
                 msg.record_stream(side)
             else:
                 rc = N.lib().fz_peer_put(msg.data_ptr(), nbytes, dst, flg, len(grp), epoch, done, K._stream(msg))

@@ -189,10 +189,15 @@ class P2pDDIMSpatioTemporalPipeline(SpatioTemporalStableDiffusionPipeline):
         attention_util.register_attention_control(self, edit_controller)
         self.last_edit_controller = edit_controller
         sdimage_output = self.sd_ddim_pipeline(controller=edit_controller, **kwargs)
-        spatial_blend.flush_mask_dumps()  # the blend-mask PNGs (save_path) were queued off-loop: all on disk from here on
+        # the blend-mask PNGs (save_path) were queued off-loop: all on disk from here on.  A failed dump (disk full, no PIL, dead writer)
+        # does not cost the caller the finished edit, but it is not silent either: the errors ride in the result (`mask_dump_errors`)
+        # beside the warning; FZ_STRICT_MASK_DUMPS=1 restores the reference's behaviour (its synchronous save_image raises)
+        dump_errors = spatial_blend.flush_mask_dumps(raise_on_error=os.environ.get("FZ_STRICT_MASK_DUMPS") == "1")
         mask_list = edit_controller.latent_blend.mask_list if hasattr(edit_controller.latent_blend, "mask_list") else None
         attention_output = self._attention_strips(kwargs["prompt"], edit_controller)
         dict_output = {"sdimage_output": sdimage_output, "attention_output": attention_output, "mask_list": mask_list}
+        if dump_errors:
+            dict_output["mask_dump_errors"] = dump_errors
         attention_util.register_attention_control(self, self.empty_controller)
         return dict_output
 

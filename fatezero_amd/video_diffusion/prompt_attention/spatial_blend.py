@@ -113,18 +113,21 @@ class _MaskDumper:
         """Wait for the queued dumps.  A failed dump (disk full, permissions, no PIL) must not cost the caller the finished edit:
         the errors come back as a list (and as a warning) unless `raise_on_error`."""
         if self.thread is not None:
+            import queue
+            import time
             while self.q.unfinished_tasks:  # (q.join() would wait forever for jobs nobody will take if the writer died)
                 if not self.thread.is_alive():
-                    with self.q.mutex:
-                        dropped = len(self.q.queue)
-                        self.q.queue.clear()
-                        self.q.unfinished_tasks = 0
-                        self.q.all_tasks_done.notify_all()
+                    dropped = 0
+                    while True:  # answer every job nobody will take any more, through the queue's own protocol
+                        try:
+                            self.q.get_nowait()
+                        except queue.Empty:
+                            break
+                        self.q.task_done()
+                        dropped += 1
                     self.errors.append(f"writer thread died; {dropped} queued dump(s) dropped")
                     break
-                with self.q.all_tasks_done:
-                    if self.q.unfinished_tasks:
-                        self.q.all_tasks_done.wait(0.05)
+                time.sleep(0.01)
         errs, self.errors = self.errors, []
         if errs:
             if raise_on_error:

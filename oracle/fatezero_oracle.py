@@ -301,8 +301,26 @@ def _batch_to_heads(t, h):
     return t.reshape(bh // h, h, s, d).permute(0, 2, 1, 3).reshape(bh // h, s, d * h)
 
 
+# Opt-in (tests of the long-clip geometries only; OFF for every pinned comparison): layers with more than 32 x 32 query tokens are never
+# stored nor edited by any controller of this path (attention_store.py:84 / attention_util.py:104: `attn.shape[-2] <= 32 ** 2`), so
+# their attention is plain softmax(scale Q K^T) V.  Materialising P for them -- what the reference does without xformers -- costs
+# 2 GB per 64^2 layer of a 16-frame clip and ~50 s per UNet forward on 8 cores; with this switch those layers run torch's fused fp32
+# scaled_dot_product_attention instead (the reference's own xformers branch does the equivalent, attention_register.py:112-116,198-204),
+# and the controller only does its per-layer bookkeeping.  tests/test_oracle_golden.py pins the switch against the materialised form.
+FAST_LARGE_ATTENTION = False
+
+
 def controlled_attention(q, k, v, heads, scale, controller, is_cross, place):
     """attention_register.py:23-59: S=scale*QK^T, softmax, P<-controller(P[BF,h,Lq,Lk]), O=PV."""
+    if FAST_LARGE_ATTENTION and q.shape[1] > 32 ** 2 and (controller is None or isinstance(controller, StoreController)):
+        b, lq, dim = q.shape
+        q4 = q.reshape(b, lq, heads, dim // heads).transpose(1, 2)
+        k4 = k.reshape(b, k.shape[1], heads, dim // heads).transpose(1, 2)
+        v4 = v.reshape(b, v.shape[1], heads, dim // heads).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q4, k4, v4, scale=scale)
+        if controller is not None:
+            controller.cur_att_layer += 1  # AttentionControl.__call__ (attention_store.py:38-49) minus the no-op forward
+        return o.transpose(1, 2).reshape(b, lq, dim)
     q, k, v = _heads_to_batch(q, heads), _heads_to_batch(k, heads), _heads_to_batch(v, heads)
     # attention_register.py:28-34: the scale rides in the GEMM (baddbmm, beta = 0 over an uninitialised tensor) -- no separate pass over
     # the [B F heads, Lq, Lk] scores (3.2 GB in fp32 for three frames of the 64^2 level)
@@ -319,8 +337,12 @@ def controlled_attention(q, k, v, heads, scale, controller, is_cross, place):
 class OracleUNet:
     """Functional forward of UNetPseudo3DConditionModel.forward (unet_3d_condition.py:307-446)."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: UNetConfig):
-        self.sd = {k: v.float() for k, v in state_dict.items()}
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: UNetConfig, device=None):
+        """`device` (default: the CPU, where every pinned comparison runs): where torch executes this restatement.  The long-clip /
+        full-width multi-step parity cases of tests/pipeline_cases.py run the SAME fp32 code on the GPU through torch's own fp32 library
+        kernels (minutes of CPU work each otherwise); tests/test_pipeline_gpu.py pins that execution against the CPU one first."""
+        self.device = torch.device("cpu" if device is None else device)
+        self.sd = {k: v.float().to(self.device) for k, v in state_dict.items()}
         self.cfg = cfg
 
     # -- primitives ---------------------------------------------------------------------------
@@ -421,8 +443,8 @@ class OracleUNet:
         """Timesteps(320, flip_sin_to_cos=True, shift 0) + TimestepEmbedding [3P]; unet_3d_condition.py:338-362."""
         c0 = self.cfg.block_out_channels[0]
         half = c0 // 2
-        t = torch.as_tensor([float(timestep)], dtype=torch.float32).expand(batch)
-        freq = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        t = torch.as_tensor([float(timestep)], dtype=torch.float32).expand(batch).to(self.device)
+        freq = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).to(self.device)
         e = t[:, None] * freq[None]
         e = torch.cat([torch.cos(e), torch.sin(e)], dim=-1)
         e = self._lin(e, "time_embedding.linear_1")
@@ -431,7 +453,7 @@ class OracleUNet:
     # -- forward --------------------------------------------------------------------------------
     def __call__(self, sample, timestep, ctx, controller=None):
         cfg = self.cfg
-        sample, ctx = sample.float(), ctx.float()
+        sample, ctx = sample.float().to(self.device), ctx.float().to(self.device)
         emb = self.time_embedding(timestep, sample.shape[0])
         x = self._pseudo_conv3d(sample, "conv_in")
         skips = [x]
@@ -526,7 +548,7 @@ class StoreController:
 
 def blend_get_mask(maps, alpha, th, use_pool, h, w, prompt_choose):
     """spatial_blend.py:24-56 (SpatialBlender.get_mask) without the PNG dump. maps [P,L*heads,F,r,r,77]."""
-    maps = (maps * alpha).sum(-1).mean(1)
+    maps = (maps * alpha.to(maps.device)).sum(-1).mean(1)
     if use_pool:
         maps = F.max_pool2d(maps, (3, 3), (1, 1), padding=(1, 1))
     mask = F.interpolate(maps, size=(h, w))
@@ -603,6 +625,14 @@ class EditController(StoreController):
         self.use_inversion_attention = use_inversion_attention
         self.pos = {k: 0 for k in _KEYS}
 
+    def _consts_to(self, device):
+        """The controller's constants follow the maps' device (a no-op on the CPU, where they are built)."""
+        if self.cross_replace_alpha.device != device:
+            self.cross_replace_alpha = self.cross_replace_alpha.to(device)
+            self.mapper = None if self.mapper is None else self.mapper.to(device)
+            self.alphas = None if self.alphas is None else self.alphas.to(device)
+            self.equalizer = None if self.equalizer is None else self.equalizer.to(device)
+
     def replace_cross_attention(self, base, cur):
         if self.mode == "replace":  # attention_util.py:213-223
             out = torch.einsum("thpw,bwn->bthpn", base, self.mapper)
@@ -617,12 +647,13 @@ class EditController(StoreController):
     def forward(self, attn, is_cross, place):
         super().forward(attn, is_cross, place)
         if attn.shape[-2] <= 32 ** 2:
+            self._consts_to(attn.device)
             key = f"{place}_{'cross' if is_cross else 'self'}"
             pos = self.pos[key]
             all_step = self.store.attention_store_all_step
             sis = len(all_step) - self.cur_step - 1 if self.use_inversion_attention else self.cur_step
             step_dict = all_step[sis]
-            base = step_dict[key][pos]
+            base = step_dict[key][pos].to(attn.device)
             self.pos[key] += 1
             if is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]):
                 f = attn.shape[0]
@@ -652,9 +683,9 @@ class EditController(StoreController):
                 sis = len(self.store.latents_store) - self.cur_step
             else:
                 sis = self.cur_step
-            inverted = self.store.latents_store[sis]
+            inverted = self.store.latents_store[sis].to(x_t.device)
             sd = self.store.attention_store_all_step[sis]
-            blend = {k: [torch.cat([a[None], self.attention_store[k][i][None]], dim=0)
+            blend = {k: [torch.cat([a[None].to(x_t.device), self.attention_store[k][i][None]], dim=0)
                          for i, a in enumerate(sd[k])] for k in ("down_cross", "mid_cross", "up_cross")}
             x_t = self.latent_blend(blend, x_t=torch.cat([inverted, x_t], dim=0))[1:]
         return x_t
@@ -696,6 +727,7 @@ def ddim_inversion(unet: OracleUNet, sched: DDIMSchedule, latent, cond_emb, stor
     """ddim_clean2noisy_loop (p2p_ddim:132-148) with LOW_RESOURCE=True (p2p_ddim:80)."""
     if store is not None:
         store.LOW_RESOURCE = True
+    latent = latent.to(getattr(unet, "device", latent.device))
     all_latent = [latent]
     latent = latent.clone()
     T = len(sched.timesteps)
@@ -713,6 +745,7 @@ def ddim_inversion(unet: OracleUNet, sched: DDIMSchedule, latent, cond_emb, stor
 
 def ddim_edit(unet: OracleUNet, sched: DDIMSchedule, latents, text_emb, controller, guidance_scale=7.5):
     """sd_ddim_pipeline denoise loop (p2p_ddim:386-421), text_emb = [uncond; cond]."""
+    latents = latents.to(getattr(unet, "device", latents.device))
     for t in sched.timesteps:
         t = int(t)
         inp = torch.cat([latents] * 2)

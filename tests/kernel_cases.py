@@ -609,6 +609,42 @@ def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, prod
     return res
 
 
+def case_gn_epilogue_ragged_last_tile(device, *, frames=3, cin=64, cout=320, groups=32, seed=0):
+    """fz_gemm_gn pinned to the 320 x 256 tile (two statistics passes of 128 rows) on a launch with 128 * odd rows: the LAST tile's second
+    pass lies wholly beyond the rows and must write no record (it used to write groups * chunks * 3 floats past the end of `partial`, from
+    stale staging rows).  Canary floats behind the partials, records against fp64 statistics of the stored tensor."""
+    from fatezero_amd import _native as N
+    import ctypes as C
+    g = torch.Generator().manual_seed(seed)
+    tokens = 128
+    rows = frames * tokens
+    assert (rows // 128) % 2 == 1
+    x = torch.randn(frames, tokens, cin, generator=g).half().to(device)
+    w = (torch.randn(cout, cin, generator=g) * cin ** -0.5).half().to(device)
+    b = torch.randn(cout, generator=g).half().to(device)
+    y = torch.empty(frames, tokens, cout, dtype=torch.float16, device=device)
+    n_rec = frames * groups * (tokens // 128) * 3
+    buf = torch.full((n_rec + 4096,), -777.0, dtype=torch.float32, device=device)
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = rows, cin, cout
+    d.ldx, d.ldw, d.ldy, d.ldres = cin, cin, cout, cout
+    d.batch, d.epilogue, d.tile_cfg = 1, N.FZ_GEMM_PLAIN, 254222
+    rc = N.lib().fz_gemm_gn(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), buf.data_ptr(), groups, tokens,
+                            K._stream(x))
+    assert rc == 0, rc
+    assert bool((buf[n_rec:] == -777.0).all()), "statistics records written beyond the last frame"
+    part = buf[:n_rec].view(frames, groups, 1, 3).cpu().double()
+    yc = y.float().cpu().double().view(frames, tokens, groups, cout // groups)
+    cnt = float(tokens * (cout // groups))
+    mean = yc.mean(dim=(1, 3))
+    m2 = ((yc - mean[:, None, :, None]) ** 2).sum(dim=(1, 3))
+    assert bool((part[..., 0, 0] == cnt).all())
+    assert torch.allclose(part[..., 0, 1], mean, rtol=1e-4, atol=1e-4) and torch.allclose(part[..., 0, 2], m2, rtol=1e-3, atol=1e-2)
+    ref = x.float().cpu() @ w.float().cpu().t() + b.float().cpu()
+    assert float((y.float().cpu() - ref).abs().max()) < 4e-3 * max(1.0, float(ref.abs().max()))
+    return {"records": n_rec // 3}
+
+
 def case_lora_pair(device, *, batch, clip, tokens, c, with_temb=True, with_res2=True, seed=0, up_scale=1.0, gn_groups=0):
     """fz_lora_pair (up(down(x)) + x (+ temb) (+ res2) of the temporal LoRA in one launch, lora.py:31-54) against (1) fz_temporal_conv3
     called twice -- bit for bit: same fp16 rounding of the rank-160 intermediate, same K order, same epilogue order -- and (2) fp32 torch

@@ -133,11 +133,11 @@ def test_bench_main_two_ranks_clips_and_frame_shard_probe():
     assert fs["scaling"] == "strong" and fs["outputs_finite"] is True and fs["value"] > 0
 
 
-def test_bench_main_two_ranks_default_transport_is_the_peer_heaps():
-    """Default `--transport auto`: the frame-sharded clip runs over the one-sided peer transport (csrc/peer.hip; shared-memory heaps under
-    the CPU harness) once its self-test round trip succeeded -- the line says so, and every exchange is device-side: no collective call
-    and no blocking wait inside the UNet."""
-    line = _run_bench_ranks(2, ["--frames", "4", "--no-kernel-breakdown", "--no-n-edit2-probe", "--peer-heap-gb", "0.05"])
+def test_bench_main_two_ranks_transport_auto_is_the_peer_heaps():
+    """`--transport auto` (opt-in: the default is rccl until the peer transport has met xGMI): the frame-sharded clip runs over the one-sided
+    peer transport (csrc/peer.hip; shared-memory heaps under the CPU harness) once its self-test round trip succeeded ON EVERY RANK
+    (agreed by an all_reduce) -- the line says so, and every exchange is device-side: no collective call and no blocking wait inside the UNet."""
+    line = _run_bench_ranks(2, ["--frames", "4", "--no-kernel-breakdown", "--no-n-edit2-probe", "--peer-heap-gb", "0.05", "--transport", "auto"])
     fs = line["frame_sharded"]
     assert "error" not in fs and fs["outputs_finite"] is True and fs["transport"] == "peer", fs
     ex = fs["exchanges"]

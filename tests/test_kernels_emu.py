@@ -294,6 +294,24 @@ def test_groupnorm_statistics_from_the_producing_epilogue():
     assert KC.case_gn_from_epilogue(DEV, n=2, clip=2, tokens=128, cin=32, cout=96, groups=8, producer="gemm") is None  # 96 % 320 != 0
 
 
+def test_groupnorm_statistics_epilogue_ragged_last_tile():
+    """128 * odd rows on the 320 x 256 tile: the last tile's second statistics pass is beyond the rows and writes nothing (advisor, round 4)."""
+    r = KC.case_gn_epilogue_ragged_last_tile(DEV)
+    assert r["records"] == 3 * 32
+    KC.case_gn_epilogue_ragged_last_tile(DEV, frames=5, cin=320)
+
+
+def test_gemm_qkvt_rejects_a_pinned_tile_across_the_kv_boundary():
+    """fz_gemm_qkvt with an explicit tile_cfg whose width does not divide the k | v boundary: FZ_ERR_BAD_ARG, nothing launched."""
+    x = torch.zeros(1, 64, 64, dtype=torch.float16, device=DEV)
+    w = torch.zeros(3 * 64, 64, dtype=torch.float16, device=DEV)
+    K.gemm_qkvt(x, w, 128, tile_cfg=212222)  # 64-wide tile: divides 128
+    with pytest.raises(RuntimeError):
+        K.gemm_qkvt(x, w, 128, tile_cfg=254222)  # 320 does not divide 128
+    with pytest.raises(RuntimeError):
+        K.gemm_qkvt(x, w, 128, tile_cfg=123456)  # not a qkvt tile at all
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)

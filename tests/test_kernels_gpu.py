@@ -285,6 +285,24 @@ def test_groupnorm_statistics_from_the_producing_epilogue(kw):
         assert r is not None, "the 64^2 producers run on 320-wide tiles: the statistics must come from their epilogue"
 
 
+def test_groupnorm_statistics_epilogue_ragged_last_tile():
+    """128 * odd rows on the 320 x 256 tile: the last tile's second statistics pass is beyond the rows and writes nothing (advisor, round 4)."""
+    r = KC.case_gn_epilogue_ragged_last_tile(DEV)
+    assert r["records"] == 3 * 32
+    KC.case_gn_epilogue_ragged_last_tile(DEV, frames=5, cin=320)
+
+
+def test_gemm_qkvt_rejects_a_pinned_tile_across_the_kv_boundary():
+    """fz_gemm_qkvt with an explicit tile_cfg whose width does not divide the k | v boundary: FZ_ERR_BAD_ARG, nothing launched."""
+    x = torch.zeros(1, 64, 64, dtype=torch.float16, device=DEV)
+    w = torch.zeros(3 * 64, 64, dtype=torch.float16, device=DEV)
+    K.gemm_qkvt(x, w, 128, tile_cfg=212222)  # 64-wide tile: divides 128
+    with pytest.raises(RuntimeError):
+        K.gemm_qkvt(x, w, 128, tile_cfg=254222)  # 320 does not divide 128
+    with pytest.raises(RuntimeError):
+        K.gemm_qkvt(x, w, 128, tile_cfg=123456)  # not a qkvt tile at all
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=8, l=4096, k=320, c=320, lp=4096)
     KC.case_gemm_vt(DEV, n=4, l=1024, k=640, c=640, lp=1024)
