@@ -190,3 +190,38 @@ def test_pipeline_matches_reference(tok, name):
             got_a = torch.stack(ctrl.latent_blend.applied_mask_list).bool().numpy()
             want_a = unpack_bits(gz["latent_applied_mask_bits"], gz["latent_applied_mask_shape"])
             assert got_a.shape == want_a.shape and (got_a != want_a).sum() == 0
+
+
+def test_fused_large_attention_switch_matches_the_materialised_oracle():
+    """oracle.FAST_LARGE_ATTENTION (used by the long-clip GPU cases only): levels with more than 32 x 32 query tokens -- which no controller of
+    this path stores or edits -- through torch's fused fp32 attention instead of a materialised P.  Same outputs, same stored maps, same
+    controller bookkeeping as the materialising form: 40^2 latents (1600 > 1024 tokens at the first level), 2 frames, capture inversion."""
+    import torch
+    from oracle import fatezero_oracle as O
+    from oracle.weights import procedural_state_dict
+    from pipeline_cases import TINY
+    from fatezero_amd.video_diffusion.models import UNetPseudo3DConditionModel
+    mc = {"lora": 16}
+    shapes = [(k, tuple(v.shape)) for k, v in UNetPseudo3DConditionModel(sample_size=64, **TINY["tiny16"], **mc).state_dict().items()]
+    u = O.OracleUNet(procedural_state_dict(shapes), O.UNetConfig(**TINY["tiny16"], model_config=mc))
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(1, 4, 2, 40, 40, generator=g)
+    emb = torch.randn(1, 77, 64, generator=g) * 0.5
+    outs = []
+    for fast in (False, True):
+        O.FAST_LARGE_ATTENTION = fast
+        try:
+            st = O.StoreController()
+            lat = O.ddim_inversion(u, O.DDIMSchedule(2), z, emb, st)
+        finally:
+            O.FAST_LARGE_ATTENTION = False
+        outs.append((lat[-1], st))
+    (za, sa), (zb, sb) = outs
+    assert float((za - zb).abs().max()) <= 1e-5 * float(za.abs().max())
+    assert sa.cur_step == sb.cur_step == 2 and sa.cur_att_layer == sb.cur_att_layer
+    for d0, d1 in zip(sa.attention_store_all_step, sb.attention_store_all_step):
+        assert {k: len(v) for k, v in d0.items()} == {k: len(v) for k, v in d1.items()}
+        assert sum(len(v) for v in d0.values()) > 0 and max(t.shape[-2] for v in d0.values() for t in v) <= 1024
+        for k in d0:
+            for a, b in zip(d0[k], d1[k]):
+                assert float((a - b).abs().max()) <= 1e-5  # probabilities in [0, 1]: fp32 summation order upstream

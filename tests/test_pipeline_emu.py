@@ -45,3 +45,13 @@ def test_unet_tiny40_layernorm_fusion_emu(monkeypatch):
     r = PC.run_unet_golden("unet_tiny40_default", "cpu")
     print(r)
     assert r["err"] <= 1.5e-2 * r["scale"], r
+
+
+@pytest.mark.skipif(__import__("os").environ.get("FZ_FULL_PARITY") != "1", reason="5 minutes of emulation: opt in with FZ_FULL_PARITY=1")
+def test_whole_job_with_every_window_toggling_mini_emu():
+    """(opt-in) The harness of the long-clip / window-transition cases (pipeline_cases.run_geometry_case: cfg3 / cfg4 / cfg5 / full-width cfg2 on
+    MI355X) on a miniature: tiny16, 2 frames, 64^2 latents, T = 6 -- cross-replace, self-replace and latent-blend windows all open and
+    close inside the run; per-step latents, masks, applied masks vs the CPU oracle."""
+    res = PC.run_geometry_case("mini_emu", "cpu")
+    print(res)
+    PC.check_geometry(res)

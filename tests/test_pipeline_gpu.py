@@ -62,6 +62,73 @@ def test_fullwidth_unet_forward_long_clips_vs_oracle(frames, variant):
     assert _native.loaded_path().endswith("libfatezero_hip.so")
 
 
+def test_oracle_executed_on_the_gpu_matches_the_cpu_oracle():
+    """The long-clip / multi-step cases below run the oracle's fp32 code (oracle/fatezero_oracle.py, unchanged) on the GPU through torch's
+    own fp32 library kernels, with the fused-attention switch for the levels no controller touches: pin THAT execution against the CPU
+    execution of the materialising oracle first -- one capture-inversion forward and one controlled CFG edit forward (Replace + blend
+    mask + latent blend) at tiny40 width, 3 frames, 64^2 latents: outputs, every stored map, masks."""
+    import torch
+    from oracle import fatezero_oracle as O
+    from oracle.weights import procedural_state_dict
+    from helpers import ReplayTokenizer, load_json
+    from fatezero_amd.video_diffusion.models import UNetPseudo3DConditionModel
+    mc = {"lora": 16}
+    shapes = [(k, tuple(v.shape)) for k, v in UNetPseudo3DConditionModel(sample_size=64, **PC.TINY["tiny40"], **mc).state_dict().items()]
+    sd = procedural_state_dict(shapes)
+    cfg = O.UNetConfig(**PC.TINY["tiny40"], model_config=mc)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 4, 3, 64, 64, generator=g)
+    emb = torch.randn(2, 77, 64, generator=g) * 0.5
+    src, tgt = load_json("host_constants.json")["teaser_posche"]["prompts"]
+    T = 2
+
+    def run(device, fast):
+        O.FAST_LARGE_ATTENTION = fast
+        try:
+            u = O.OracleUNet(sd, cfg, device=device)
+            st = O.StoreController()
+            lat = O.ddim_inversion(u, O.DDIMSchedule(T), z, emb[1:], st)
+            c = O.make_edit_controller(ReplayTokenizer(), [src, tgt], st, T, True, {"default_": 1.0}, 1.0,
+                                       blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=(0.55, 0.55), blend_self_attention=True,
+                                       blend_latents=True, save_self_attention=False)
+            c.latent_blend.start_blend, c.latent_blend.end_blend = -1, 99  # live at every step of this 2-step run
+            out = O.ddim_edit(u, O.DDIMSchedule(T), lat[-1], emb, c, guidance_scale=7.5)
+            return lat[-1].cpu(), st, out.cpu(), c
+        finally:
+            O.FAST_LARGE_ATTENTION = False
+    zc, stc, oc, cc = run("cpu", False)
+    zg, stg, og, cg = run("cuda", True)
+    scale = float(oc.abs().max())
+    e_inv, e_edit = float((zc - zg).abs().max()), float((oc - og).abs().max())
+    e_map = max(float((a - b.cpu()).abs().max()) for d0, d1 in zip(stc.attention_store_all_step, stg.attention_store_all_step)
+                for k in d0 for a, b in zip(d0[k], d1[k]))
+    flips = sum(int((a.bool() != b.bool().cpu()).sum()) for a, b in zip(cc.attention_blend.mask_list, cg.attention_blend.mask_list))
+    aflips = sum(int((a.bool() != b.bool().cpu()).sum()) for a, b in zip(cc.latent_blend.applied_mask_list, cg.latent_blend.applied_mask_list))
+    total = sum(m.numel() for m in cc.attention_blend.mask_list)
+    print("oracle on cuda (fused large attention) vs oracle on cpu (materialised):", dict(inv=e_inv, edit=e_edit, maps=e_map, scale=scale,
+          mask_flips=flips, applied_flips=aflips, mask_total=total))
+    assert len(cc.latent_blend.applied_mask_list) == T and total > 0
+    assert e_inv <= 2e-4 * float(zc.abs().max()) and e_map <= 2e-5, (e_inv, e_map)
+    assert flips <= 2e-4 * total and aflips <= 8, (flips, aflips)    # fp32 summation order at a hard threshold
+    assert e_edit <= 1e-3 * scale or aflips > 0, (e_edit, scale)
+
+
+GEOMETRY = ["cfg3_style_16f", "cfg4_attribute_24f_latentblend", "cfg5_shape_32f_l72", "cfg2_fullwidth_8f_latentblend"]
+
+
+@pytest.mark.parametrize("name", GEOMETRY)
+def test_whole_job_long_clips_and_window_transitions_vs_oracle(name):
+    """BASELINE cfg3 (16 frames, ['mid'] / least_sc_channel, Refine + Reweight, blend_th [2, 2]: every row stored), cfg4's synthetic
+    variant (24 frames, Replace + blend words + latent blend), cfg5 (32 frames at 72^2 latents, Replace + blend, th 0.3: rows stay live)
+    at tiny40 width and true geometry with T = 10, and cfg2 + latent blend at FULL width, 8 frames, T = 4: whole capture inversion +
+    CFG edit with the cross-replace, self-replace and latent-blend windows opening and closing inside the run; latents per step, captured
+    maps at the first and last step, attention-blend masks (bit-exact on identical maps), applied latent masks, and the all-fp32 leg."""
+    res = PC.run_geometry_case(name, "cuda", oracle_device="cuda")
+    print("geometry", res)
+    PC.check_geometry(res)
+    assert _native.loaded_path().endswith("libfatezero_hip.so")
+
+
 @pytest.mark.parametrize("name", ["unet_tiny40_default", "unet_tiny40_l72", "unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d"])
 def test_unet_vs_reference_golden(name):
     r = PC.run_unet_golden(name, "cuda")
