@@ -110,10 +110,12 @@ PMC_JOB_FILES = ("r05_pmc_job.json", "r04_pmc_job.json")  # newest in-situ pass 
 FLASH_CALIB_REF_US = 455.0
 
 
-def measure_box(K, device, n=12):
+def measure_box(K, device, n=12, hot=False):
     """Box calibration, nothing of the job in it: (1) ONE fixed launch of the judged kernel -- attn_flash d = 40, 8 frames x Lq 4096 x Lk
-    8192, uniform random operands -- median of n launches after 3 warm-ups, HIP events on the launch stream; (2) a device-to-device copy
-    of 1 GiB (1 GiB read + 1 GiB written), median of 5."""
+    8192, uniform random operands -- median of n launches after 60 untimed ones, HIP events on the launch stream; (2) a device-to-device
+    copy of 1 GiB (1 GiB read + 1 GiB written), median of 5.  hot: only (1), called straight behind the timed region -- the chip at the
+    power / clock state the job leaves it in (1.09 kW, ~2.06 GHz) instead of the cool 2.4 GHz a fresh process finds: the launch reads
+    ~12 % longer there, and THAT figure is what the headline is normalised with."""
     out = {}
     try:
         g = torch.Generator().manual_seed(7)
@@ -122,19 +124,23 @@ def measure_box(K, device, n=12):
         vt = torch.randn(8, 320, 4096, generator=g).half().to(device)
         o = torch.empty_like(q)
         kw = dict(clip_len=8, heads=8, index_list=[-1, "first"], mode=K.FZ_ATTN_FLASH, scale=40 ** -0.5, q_log2_scaled=True)
+        for i in range(60):  # ~30 ms of the same launch first: the clocks leave idle before anything is timed
+            K.attn_self(q, k, vt, o, **kw)
         ev = []
-        for i in range(n + 3):
+        for i in range(n):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             K.attn_self(q, k, vt, o, **kw)
             e.record()
             ev.append((s, e))
         torch.cuda.synchronize()
-        us = sorted(s.elapsed_time(e) * 1e3 for s, e in ev[3:])
+        us = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
         out["flash_calib_us"] = us[len(us) // 2]
         out["flash_calib_us_min_max"] = [us[0], us[-1]]
-        out["flash_calib"] = "attn_flash_kernel<40>, 8 frames x 4096 x 8192, random operands, median of %d launches" % n
+        out["flash_calib"] = "attn_flash_kernel<40>, 8 frames x 4096 x 8192, random operands, median of %d launches after 60 untimed ones" % n
         out["flash_calib_ref_us"] = FLASH_CALIB_REF_US
+        if hot:
+            return {"flash_calib_hot_us": out["flash_calib_us"], "flash_calib_hot_us_min_max": out["flash_calib_us_min_max"]}
         a = torch.empty(1 << 29, dtype=torch.float16, device=device)
         b = torch.empty_like(a)
         ev = []
@@ -154,41 +160,54 @@ def measure_box(K, device, n=12):
 
 
 class SmiSampler:
-    """Shader clock (MHz) and socket power (W) of the device, sampled every `period` s on a helper thread while the timed region runs:
-    hwmon files of the amdgpu device when they exist (one small read each), `rocm-smi --showclocks --showpower` otherwise."""
+    """Shader clock (MHz) and socket power (W) of the device under test, sampled every `period` s on a helper thread while the timed region
+    runs.  The box's sysfs lists EVERY amdgpu device of the node (the process sees one): the hwmon directory is picked by the PCI address
+    torch reports for the device, else the card drawing the most power during the region is the one reported (`picked_by`).  hwmon files
+    (one small read each); `rocm-smi --showclocks --showpower` when there is no hwmon."""
 
     def __init__(self, index=0, period=0.5):
         import threading
         self.index, self.period = index, period
-        self.samples, self._stop = [], threading.Event()
+        self.samples, self._stop = {}, threading.Event()
         self._thread = threading.Thread(target=self._run, name="fz-smi", daemon=True)
-        self.source = None
-        self._hw = self._find_hwmon(index)
+        self.source, self.picked_by = None, None
+        self._hw = self._find_hwmons()
+        self._mine = self._pci_hwmon(index)
 
     @staticmethod
-    def _find_hwmon(index):
+    def _find_hwmons():
         import glob
-        cards = []
+        out = []
         for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
                 if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
                     continue
             except OSError:
                 continue
-            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
-            if hw:
-                cards.append(hw[0])
-        return cards[index] if index < len(cards) else None
+            out += sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))[:1]
+        return out
 
-    def _read_hwmon(self):
+    @staticmethod
+    def _pci_hwmon(index):
+        import glob
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hw = sorted(glob.glob(f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*"))
+            return os.path.realpath(hw[0]) if hw else None
+        except Exception:  # noqa: BLE001
+            return None
+
+    @staticmethod
+    def _read_hwmon(hw):
         mhz = w = None
         try:
-            mhz = float(open(os.path.join(self._hw, "freq1_input")).read()) / 1e6
+            mhz = float(open(os.path.join(hw, "freq1_input")).read()) / 1e6
         except (OSError, ValueError):
             pass
         for name in ("power1_average", "power1_input"):
             try:
-                w = float(open(os.path.join(self._hw, name)).read()) / 1e6
+                w = float(open(os.path.join(hw, name)).read()) / 1e6
                 break
             except (OSError, ValueError):
                 continue
@@ -198,25 +217,29 @@ class SmiSampler:
         import re
         import subprocess
         try:
-            txt = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower"], capture_output=True, text=True,
-                                 timeout=10).stdout
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
         except Exception:  # noqa: BLE001
-            return None, None
-        m = re.search(r"sclk clock level[^(]*\((\d+)Mhz\)", txt)
-        pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
-        return (float(m.group(1)) if m else None), (float(pw.group(1)) if pw else None)
+            return {}
+        out = {}
+        for m in re.finditer(r"GPU\[(\d+)\]\s*:\s*sclk clock level[^(]*\((\d+)Mhz\)", txt):
+            out.setdefault("smi%s" % m.group(1), [None, None])[0] = float(m.group(2))
+        for m in re.finditer(r"GPU\[(\d+)\]\s*:[^\n]*Power \(W\):\s*([0-9.]+)", txt):
+            out.setdefault("smi%s" % m.group(1), [None, None])[1] = float(m.group(2))
+        return {k: tuple(v) for k, v in out.items()}
 
     def _run(self):
         while not self._stop.is_set():
-            mhz = w = None
-            if self._hw is not None:
-                mhz, w = self._read_hwmon()
-                self.source = "hwmon"
-            if mhz is None and w is None:
-                mhz, w = self._read_smi()
+            got = {}
+            for hw in self._hw:
+                mhz, w = self._read_hwmon(hw)
+                if mhz is not None or w is not None:
+                    got[os.path.realpath(hw)] = (mhz, w)
+            self.source = "hwmon"
+            if not got:
+                got = self._read_smi()
                 self.source = "rocm-smi"
-            if mhz is not None or w is not None:
-                self.samples.append((mhz, w))
+            for k, v in got.items():
+                self.samples.setdefault(k, []).append(v)
             self._stop.wait(self.period)
 
     def start(self):
@@ -226,12 +249,21 @@ class SmiSampler:
     def stop(self):
         self._stop.set()
         self._thread.join(timeout=15)
-        mhz = sorted(m for m, _ in self.samples if m)
-        w = sorted(p for _, p in self.samples if p)
 
         def stat(v):
+            v = sorted(x for x in v if x)
             return None if not v else {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
-        return {"samples": len(self.samples), "source": self.source, "sclk_MHz": stat(mhz), "socket_power_W": stat(w)}
+        key = None
+        if self._mine is not None and self._mine in self.samples:
+            key, self.picked_by = self._mine, "pci address of the torch device"
+        elif self.samples:  # the card under load
+            key = max(self.samples, key=lambda k: (stat([w for _, w in self.samples[k]]) or {"median": 0.0})["median"])
+            self.picked_by = "highest median power among %d devices" % len(self.samples)
+        if key is None:
+            return {"samples": 0, "source": self.source, "sclk_MHz": None, "socket_power_W": None}
+        sm = self.samples[key]
+        return {"samples": len(sm), "source": self.source, "device": key, "picked_by": self.picked_by, "devices_seen": len(self.samples),
+                "sclk_MHz": stat([m for m, _ in sm]), "socket_power_W": stat([w for _, w in sm])}
 
 
 def pmc_job_traffic():
@@ -299,21 +331,27 @@ def stored_rows_fraction(pipe):
     return 1.0 - float(sum(float(m.float().sum()) for m in ml) / sum(m.numel() for m in ml))
 
 
-def pick_split_threshold(pipe, z0, device, steps=4, candidates=(0.3, 0.4, 0.5, 0.55, 0.6, 0.65, 0.7, 0.8, 0.9)):
-    """With the bench's procedural weights the normalised blend-word score is near-uniform and the config's blend_th = 0.3 leaves ~100 % of
-    the rows on the LIVE attention: the 275 masked-inject launches of a job then read no stored map (round-4 review).  The YAML knob that
-    moves the split is blend_th itself (the tests use 0.55 for the same reason): short `steps`-step jobs over a few thresholds, the one
-    whose stored-row share lands closest to one half is used for the kernel-breakdown job and the `split_mask_job` beside the primary."""
+def pick_split_threshold(pipe, z0, device, steps=10, iters=10):
+    """With the bench's procedural weights the normalised blend-word score is near-uniform (>= 0.9 of its per-frame maximum almost
+    everywhere) and the config's blend_th = 0.3 leaves 100 % of the rows on the LIVE attention: the 275 masked-inject launches of a job
+    then read no stored map (round-4 review).  The YAML knob that moves the split is blend_th itself (the tests use 0.55 for the same
+    reason): the stored-row share is monotone in it, so bisect it on short `steps`-step jobs (the same timestep range, coarser) towards
+    one half; the threshold found is used for the `split_mask_job` beside the primary and for the kernel-breakdown job."""
+    lo, hi, seen = 0.3, 0.9995, {}
     best = None
-    seen = {}
-    for th in candidates:
+    for _ in range(iters):
+        th = 0.5 * (lo + hi)
         run_job(pipe, z0, steps, device, blend_th=th)
         f = stored_rows_fraction(pipe)
         if f is None:
             return None, seen
-        seen[th] = f
+        seen[round(th, 6)] = f
         if best is None or abs(f - 0.5) < abs(seen[best] - 0.5):
-            best = th
+            best = round(th, 6)
+        if f < 0.5:
+            lo = th
+        else:
+            hi = th
     return best, seen
 
 
@@ -826,6 +864,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     smi = sampler.stop() if sampler is not None else None
+    box_hot = measure_box(K, device, hot=True) if not args.no_box else None  # straight behind the timed jobs: the chip still in the job's state
     per_job_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     n_edit2 = None
     if args.n_edit == 1 and not args.no_n_edit2_probe and not by_frames:
@@ -912,11 +951,12 @@ def main():
                                       "how": "HIP events at the job boundaries of the timed region (launch stream, no sync inside)"}
         if box is not None:
             box["during_timed_region"] = smi
+            box.update(box_hot or {})
             line["box"] = box
-            if box.get("flash_calib_us"):
-                # the headline as it would read on a box whose calibration launch takes FLASH_CALIB_REF_US (first-order: the job follows
-                # the chip's sustained clock, which is what the calibration launch measures)
-                line["value_normalised"] = value * box["flash_calib_us"] / FLASH_CALIB_REF_US
+            if box.get("flash_calib_hot_us"):
+                # the headline as it would read on a box whose hot calibration launch takes FLASH_CALIB_REF_US (first order: the job
+                # follows the chip's sustained clock under the job's power draw, which is what the hot calibration launch measures)
+                line["value_normalised"] = value * box["flash_calib_hot_us"] / FLASH_CALIB_REF_US
         if split is not None:
             line["split_mask_job"] = split
         if n_edit2 is not None:

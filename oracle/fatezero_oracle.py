@@ -324,7 +324,7 @@ def controlled_attention(q, k, v, heads, scale, controller, is_cross, place):
     q, k, v = _heads_to_batch(q, heads), _heads_to_batch(k, heads), _heads_to_batch(v, heads)
     # attention_register.py:28-34: the scale rides in the GEMM (baddbmm, beta = 0 over an uninitialised tensor) -- no separate pass over
     # the [B F heads, Lq, Lk] scores (3.2 GB in fp32 for three frames of the 64^2 level)
-    scores = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(-1, -2), beta=0, alpha=scale)
+    scores = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device), q, k.transpose(-1, -2), beta=0, alpha=scale)
     probs = scores.softmax(dim=-1)
     del scores
     if controller is not None:

@@ -543,12 +543,13 @@ GEOMETRY_CASES = {
     # words + `blend_latents: True` (config/teaser/jeep_posche_local_latent_blend.yaml:38-39)
     "cfg4_attribute_24f_latentblend": dict(kind="tiny40", F=24, L=64, T=10, model_config=_MID, prompt_case="attribute_rabbit",
                                            is_replace=True, cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
-                                           blend_words=[["squirrel"], ["rabbit"]], blend_th=None, blend_latents=True, regime="split"),
+                                           blend_words=[["squirrel"], ["rabbit"]], blend_th=[0.2, 0.2], blend_latents=True, regime="split"),
     # config/shape/swan_duck_flamingo.yaml:7 -- 32 frames at 576^2 (72^2 latents: 5184 / 1296 / 324 / 81 tokens), default index
-    # [-1, 'first'], Replace + blend-masked self-attention with the teaser's th = 0.3 (procedural weights: ~all rows stay live)
+    # [-1, 'first'], Replace + blend-masked self-attention at the OTHER extreme the reference documents (swan_duck_flamingo.yaml:59:
+    # "blend_th : [0.0, 0.0], mask -> 1"): every row keeps the live attention -- the regime bench.py's job is in with its weights
     "cfg5_shape_32f_l72": dict(kind="tiny40", F=32, L=72, T=10, model_config={"lora": 16}, prompt_case="teaser_posche", is_replace=True,
                                cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
-                               blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[0.3, 0.3], blend_latents=False,
+                               blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[0.0, 0.0], blend_latents=False,
                                regime="all_live"),
     # config/teaser/jeep_posche_local_latent_blend.yaml at FULL SD-1.x width, the judged 8 frames, T = 4: cross window [0, 2), self window
     # [0, 2), latent blend live at steps 1-2 of 0-3; Replace + blend-masked self-attention + latent blend
@@ -648,10 +649,27 @@ def run_geometry_case(name, device, oracle_device=None, seed=21, fp32_leg=True):
             out = pipe(latents=z.to(device), edit_type="swap", output_type="latent", callback=cb, callback_steps=1, **kw)
             return out["sdimage_output"].images.float().cpu(), per_step, pipe.last_edit_controller
 
-        def oracle_edit(ost, z):
+        def oracle_edit(ost, z, forced_applied=None):
             c = O.make_edit_controller(tok, [src, tgt], ost, T, G["is_replace"], dict(G["cross_replace"]), G["self_replace"],
                                        blend_words=G["blend_words"], eq_params=G["eq_params"], blend_th=tuple(th),
                                        blend_self_attention=True, blend_latents=G["blend_latents"], save_self_attention=False)
+            if forced_applied is not None and c.latent_blend is not None:
+                # teacher forcing: the oracle computes (and records) its OWN masks, but blends the edited latents with the mask the
+                # native run applied at that step.  The target-prompt half of an applied mask is thresholded from the LIVE cross maps
+                # (fp16 natively, fp32 here): a pixel within that noise of the threshold flips, moves its latent by |x - inverted| and
+                # the following UNet steps spread the jump over the frame -- with the masks forced, what is compared is the arithmetic;
+                # the flips themselves are counted and bounded separately.
+                lb, queue = c.latent_blend, list(forced_applied)
+
+                def forced_call(attention_store, target_h=None, target_w=None, x_t=None, _orig=lb.__call__):
+                    n_before = len(lb.applied_mask_list)
+                    x_own = _orig(attention_store, target_h, target_w, x_t=x_t)
+                    if len(lb.applied_mask_list) == n_before:  # outside the window: nothing was blended
+                        return x_own
+                    m = queue.pop(0).to(x_t).reshape(1, 1, *x_t.shape[2:])
+                    return torch.cat([x_t[:1], x_t[:1] + m * (x_t[1:] - x_t[:1])], dim=0)
+                c.latent_blend = type("ForcedBlender", (), {"__call__": staticmethod(forced_call), "mask_list": lb.mask_list,
+                                                            "applied_mask_list": lb.applied_mask_list})()
             per_step = {}
             inner_cb = c.step_callback
 
@@ -680,7 +698,8 @@ def run_geometry_case(name, device, oracle_device=None, seed=21, fp32_leg=True):
         ost = O.StoreController()
         ost.attention_store_all_step = [{k: [t.float().to(odev) for t in v] for k, v in d.items()} for d in store.attention_store_all_step]
         ost.latents_store = [t.float().to(odev) for t in store.latents_store]
-        o_edit, osteps, octrl = oracle_edit(ost, zT)
+        forced = list(nctrl.latent_blend.applied_mask_list) if G["blend_latents"] else None
+        o_edit, osteps, octrl = oracle_edit(ost, zT, forced_applied=forced)
         res["edit_scale"] = float(o_edit.abs().max())
         near = masks_report(nctrl, octrl, "same_maps")
         per_step = [float((nsteps[i] - osteps[i]).abs().max()) for i in range(T)]
@@ -688,8 +707,6 @@ def run_geometry_case(name, device, oracle_device=None, seed=21, fp32_leg=True):
         em = (edited - o_edit).abs().amax(dim=(0, 1))
         res["edit_err_same_maps"] = float(em.max())
         res["edit_err_same_maps_q99"] = float(torch.quantile((edited - o_edit).abs().flatten()[:: max(1, edited.numel() // 1000000)], 0.99))
-        if near is not None:
-            res["edit_err_same_maps_off_applied_flips"] = float(em[~near].max())
         ml = nctrl.attention_blend.mask_list
         res["attn_mask_calls"] = len(ml)
         res["mask_ones_frac"] = float(sum(float(m.float().sum()) for m in ml) / max(1, sum(m.numel() for m in ml)))
@@ -720,12 +737,20 @@ def run_geometry_case(name, device, oracle_device=None, seed=21, fp32_leg=True):
         O.FAST_LARGE_ATTENTION = fast_before
 
 
-# Bounds of the geometry cases: <= 2x the worst measured on MI355X (profiles/r05_parity_numbers.txt)
-GEO_LATENT_TOL = 6e-3        # inversion, worst step, / max |latent|
-GEO_MAP_TOL = 1.5e-2         # captured cross maps (first and last step), absolute
-GEO_SELF_MAP_TOL = 4e-3
-GEO_EDIT_TOL_SAME_MAPS = 2e-2
-GEO_EDIT_Q99_TOL = 1e-2
+# Bounds of the geometry cases: <= 2x the worst measured on MI355X (profiles/r05_parity_numbers.txt; the native path is bit-deterministic).
+# Measured worst over the four cases -> bound:
+GEO_LATENT_TOL = 4e-3             # inversion, worst of the T steps, / max |latent|                         0.21 %
+GEO_MAP_TOL = 1.8e-2              # captured cross maps (first and last step), absolute                     1.00e-2
+GEO_SELF_MAP_TOL = 2.8e-3         # captured self maps                                                      1.42e-3
+GEO_EDIT_TOL_SAME_MAPS = 2.6e-2   # edit vs the oracle on the native maps (+ native applied masks), max      1.39 %  (grows ~0.14 % per step)
+GEO_EDIT_Q99_TOL = 1.1e-2         # the same, 99th percentile                                               0.58 %
+GEO_EDIT_TOL_VS_FP32 = 2.4e-2     # edit vs the all-fp32 run, max, when no mask pixel can flip               1.17 %
+GEO_EDIT_Q99_VS_FP32 = 2e-2       # edit vs the all-fp32 run, 99th percentile (away from applied-mask flips)  1.04 %
+GEO_ATTN_FLIP_TOL = 4.4e-3        # attention-blend mask elements that differ from the all-fp32 run          0.22 %
+GEO_SRC_MASK_FLIP_TOL = 3e-3      # latent blender's source-prompt masks vs the all-fp32 run                 0.15 %
+GEO_APPLIED_FLIP_TOL = 1.2e-2     # applied latent masks (source OR live target mask) vs the all-fp32 run    0.63 %
+GEO_APPLIED_FLIP_SAME_TOL = 7e-3  # the same on identical stored maps (only the live target half differs)    0.34 %
+GEO_BEYOND_BAND_TOL = 1.8e-2      # latent positions whose error leaves the 6 % band (flips + what they spread) 0.92 %
 
 
 def check_geometry(res):
@@ -737,24 +762,28 @@ def check_geometry(res):
     assert res["attn_mask_flips_same_maps"] == 0, res
     assert res["edit_err_same_maps_q99"] <= GEO_EDIT_Q99_TOL * res["edit_scale"], res
     if G["blend_latents"]:
-        # the target-prompt half of the applied latent mask is thresholded from the LIVE cross maps (fp16 here, fp32 in the oracle)
+        # the source-prompt half of a latent mask comes from the stored maps (identical): exact; the target-prompt half of the APPLIED
+        # mask is thresholded from the LIVE cross maps (fp16 here, fp32 in the oracle)
         assert res["latent_mask_flips_same_maps"] == 0, res
-        assert res["applied_mask_flips_same_maps"] <= MASK_FLIP_TOL * res["applied_mask_total"], res
-        assert res["edit_err_same_maps_off_applied_flips"] <= GEO_EDIT_TOL_SAME_MAPS * res["edit_scale"], res
-    else:
-        assert res["edit_err_same_maps"] <= GEO_EDIT_TOL_SAME_MAPS * res["edit_scale"], res
+        assert res["applied_mask_flips_same_maps"] <= GEO_APPLIED_FLIP_SAME_TOL * res["applied_mask_total"], res
+    # (latent blend: the oracle blends with the natively applied masks in this leg -- the arithmetic is compared, the flips are counted above)
+    assert res["edit_err_same_maps"] <= GEO_EDIT_TOL_SAME_MAPS * res["edit_scale"], res
     _check_regime(G, res)
     if "edit_err_vs_fp32" not in res:
         return
     if G["blend_latents"]:
-        assert res["applied_mask_flips_vs_fp32"] <= MASK_FLIP_TOL * res["applied_mask_total"], res
-        assert res["latent_mask_flips_vs_fp32"] <= MASK_FLIP_TOL * res["latent_mask_total"], res
-        assert res["edit_positions_beyond_band"] <= MASK_FLIP_TOL * res["edit_positions"], res
-        assert res["edit_err_vs_fp32_off_applied_flips"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
+        assert res["applied_mask_flips_vs_fp32"] <= GEO_APPLIED_FLIP_TOL * res["applied_mask_total"], res
+        assert res["latent_mask_flips_vs_fp32"] <= GEO_SRC_MASK_FLIP_TOL * res["latent_mask_total"], res
+        # a flipped pixel moves its latent by |x - inverted| and the UNet steps that follow spread the jump over the frame (global
+        # attention): over several blend steps the max is not boundable, away from the flips either -- the COUNT of positions that leave
+        # the band is, and so is the bulk (q99 below, taken away from the flips)
+        assert res["edit_positions_beyond_band"] <= GEO_BEYOND_BAND_TOL * res["edit_positions"], res
+    elif res["attn_mask_flips_vs_fp32"] == 0:
+        assert res["edit_err_vs_fp32"] <= GEO_EDIT_TOL_VS_FP32 * res["edit_scale"], res
     else:
         assert res["edit_err_vs_fp32"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
-    assert res["attn_mask_flips_vs_fp32"] <= MASK_FLIP_TOL * res["attn_mask_total"], res
-    assert res["edit_err_vs_fp32_q99"] <= EDIT_Q99_TOL * res["edit_scale"], res
+    assert res["attn_mask_flips_vs_fp32"] <= GEO_ATTN_FLIP_TOL * res["attn_mask_total"], res
+    assert res["edit_err_vs_fp32_q99"] <= GEO_EDIT_Q99_VS_FP32 * res["edit_scale"], res
 
 
 def _check_regime(G, res):
