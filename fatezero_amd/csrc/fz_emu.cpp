@@ -238,6 +238,35 @@ f32x16 mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_f16 for the calling wave:  A[i][k]: lane = i + 16*(k/8), element k%8;  B[k][n]: lane = n + 16*(k/8), element k%8;
+// C/D[row][col]: col = lane&15, row = 4*(lane>>4) + reg.  k ascending per output element.  Two wave barriers per call, like the
+// 32x32x16 routine: the scratch half alternates per MFMA with the barrier generation.
+f32x4 mfma_16x16x32_f16(half8_t a, half8_t b, f32x4 c) {
+    Worker* w = t_w;
+    const int tid = linear_tid();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lanes = (w->n - wave * 64) < 64 ? (w->n - wave * 64) : 64;
+    if (lanes != 64) __builtin_trap();
+    float* base = w->mm_buf + ((size_t)wave * 2 + ((w->wv_gen[wave] >> 1) & 1)) * kMmFloats;
+    float* A = base;
+    float* B = base + 64 * 8;
+    for (int e = 0; e < 8; ++e) {
+        A[lane * 8 + e] = (float)a[e];
+        B[lane * 8 + e] = (float)b[e];
+    }
+    wave_barrier(wave, 64);
+    wave_barrier(wave, 64);
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k)
+            acc = __builtin_fmaf(A[(row + 16 * (k >> 3)) * 8 + (k & 7)], B[(col + 16 * (k >> 3)) * 8 + (k & 7)], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 static Worker* get_worker() {
     static thread_local Worker w;
     if (!w.stacks) {

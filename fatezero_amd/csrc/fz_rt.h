@@ -48,6 +48,17 @@ static inline int fz_last_launch_status() { return hipGetLastError() == hipSucce
 FZ_DEVICE f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_f16:  A[i][k]: lane = i + 16*(k/8), element k%8;  B[k][n]: lane = n + 16*(k/8), element k%8;
+// C/D[row][col]: col = lane&15, row = 4*(lane>>4) + reg
+FZ_DEVICE f32x4 fz_mfma_16x16x32_f16(half8_t a, half8_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// sum over each aligned group of 4 lanes, result in all 4 (DPP quad_perm [1,0,3,2] then [2,3,0,1]; a fixed association order)
+FZ_DEVICE float fz_sum4(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
 // a value the program knows to be wave-uniform (e.g. threadIdx.x / 64): tell the compiler, so that what depends on it stays in SGPRs
 FZ_DEVICE int fz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // keeps a rarely taken branch a branch (hipcc otherwise if-converts it into per-use v_cndmask on the common path)
@@ -151,6 +162,7 @@ void dma_wait(int max_outstanding);                 // s_waitcnt vmcnt(N) for th
 void wave_exchange(const void* mine, void* all, size_t bytes);  // gather `bytes` from each of the wave's 64 lanes
 int lane_id();
 f32x16 mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c);        // one wave-wide MFMA (all 64 lane fibers call it)
+f32x4 mfma_16x16x32_f16(half8_t a, half8_t b, f32x4 c);
 }  // namespace fz_emu
 
 #define threadIdx (fz_emu::t_threadIdx)
@@ -176,6 +188,7 @@ static inline void __syncthreads() { fz_emu::sync_block(); }
 //   A[i][k]: lane = i + 32*(k/8), element k%8;  B[k][n]: lane = n + 32*(k/8), element k%8
 //   C/D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 static inline f32x16 fz_mfma_32x32x16_f16(half8_t a, half8_t b, f32x16 c) { return fz_emu::mfma_32x32x16_f16(a, b, c); }
+static inline f32x4 fz_mfma_16x16x32_f16(half8_t a, half8_t b, f32x4 c) { return fz_emu::mfma_16x16x32_f16(a, b, c); }
 static inline int fz_uniform(int v) { return v; }
 #define FZ_COLD_PATH() ((void)0)
 #define FZ_SCHED_FENCE() ((void)0)
@@ -205,6 +218,11 @@ static inline unsigned long long fz_ballot(int pred) {
     return m;
 }
 static inline float fz_pair_max32(float v) { return fmaxf(v, fz_shfl_xor(v, 32)); }
+static inline float fz_sum4(float v) {  // same association order as the DPP form: xor 1, xor 2
+    v += fz_shfl_xor(v, 1);
+    v += fz_shfl_xor(v, 2);
+    return v;
+}
 static inline float fz_sum8(float v) {  // same association order as the DPP form: xor 1, xor 2, mirror within 8
     v += fz_shfl_xor(v, 1);
     v += fz_shfl_xor(v, 2);

@@ -592,6 +592,90 @@ def gemm_vt(x: torch.Tensor, w: torch.Tensor, lp: int, out: Optional[torch.Tenso
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------
+# LayerNorm + projection in one launch (csrc/rowgemm.hip): the 320-channel rows of the 64x64 level
+# ------------------------------------------------------------------------------------------------------------
+def ln_gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Shapes fz_ln_gemm carries: K = 320 (whole rows in a workgroup), output columns a multiple of 320, unit channel stride, one row stride."""
+    k = x.shape[-1]
+    return (x.dtype == torch.float16 and w.dtype == torch.float16 and x.stride(-1) == 1 and w.stride(-1) == 1 and w.shape[-1] == k and
+            bool(N.lib().fz_ln_gemm_ok(x.numel() // k, k, w.shape[0])))
+
+
+def ln_gemm_preferred(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """... and where that launch is also the faster form on MI355X (the rows fill the chip with 128-row workgroups)."""
+    k = x.shape[-1]
+    return ln_gemm_ok(x, w) and bool(N.lib().fz_ln_gemm_preferred(x.numel() // k, k, w.shape[0]))
+
+
+def _row_stride(t):
+    for d in range(t.dim() - 2):
+        assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "one row stride"
+    return t.stride(-2) if t.dim() > 1 else t.shape[-1]
+
+
+def ln_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ln=None, res: Optional[torch.Tensor] = None,
+            res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """y = LN(x) @ w^T + bias (+ res) (+ res2) in ONE launch (fz_ln_gemm); ln = (gamma, beta, eps) fp16 vectors, or None for a plain
+    projection through the same row-streaming kernel.  x [..., 320], w [O, 320] with O % 320 == 0."""
+    k, o = x.shape[-1], w.shape[0]
+    rows = x.numel() // k
+    _chk16(x, w, bias, res, res2, out)
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (o,), dtype=torch.float16, device=x.device)
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = rows, k, o
+    d.ldx, d.ldw, d.ldy = _row_stride(x), w.stride(0), _row_stride(out)
+    d.batch, d.epilogue = 1, N.FZ_GEMM_PLAIN
+    for r in (res, res2):
+        if r is not None:
+            assert r.dtype == torch.float16 and r.shape[-1] == o and r.stride(-1) == 1 and r.numel() // o == rows
+            d.ldres = _row_stride(r)
+    if res is not None and res2 is not None:
+        assert _row_stride(res) == _row_stride(res2)
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+        assert g.dtype == b.dtype == torch.float16 and g.numel() == b.numel() == k and g.is_contiguous() and b.is_contiguous()
+    rc = N.lib().fz_ln_gemm(C.byref(d), x.data_ptr(), _ptr(g), _ptr(b), float(eps), w.data_ptr(), _ptr(bias), _ptr(res), _ptr(res2),
+                            out.data_ptr(), _stream(x))
+    if rc:
+        N.check(rc, "fz_ln_gemm")
+    return out
+
+
+def ln_gemm_qkvt_ok(x: torch.Tensor, w: torch.Tensor, split: int) -> bool:
+    return x.dim() == 3 and ln_gemm_ok(x, w) and split % 320 == 0 and 0 < split < w.shape[0] and x.shape[1] % 32 == 0
+
+
+def ln_gemm_qkvt(x: torch.Tensor, w: torch.Tensor, split: int, *, ln=None):
+    """LayerNorm + the q | k | V^T projection of a self-attention in ONE launch (fz_ln_gemm_qkvt): x [N, L, 320] raw rows, w [split + Cv, 320]
+    -> (y [N, L, split] = LN(x) @ w[:split]^T,  vt [N, Cv, L] = w[split:] @ LN(x[n])^T)."""
+    n, l, k = x.shape
+    o = w.shape[0]
+    cv = o - split
+    if not ln_gemm_qkvt_ok(x, w, split) or x.stride(0) != l * x.stride(1):
+        raise ValueError("fz_ln_gemm_qkvt: x [N, L, 320] with L % 32 == 0 and a single row stride, w [split + Cv, 320], split % 320 == 0")
+    _chk16(x, w)
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = n * l, k, o
+    d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(0), split
+    d.batch, d.epilogue = 1, N.FZ_GEMM_PLAIN
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+        assert g.dtype == b.dtype == torch.float16 and g.numel() == b.numel() == k
+    y = torch.empty(n, l, split, dtype=torch.float16, device=x.device)
+    vt = torch.empty(n, cv, l, dtype=torch.float16, device=x.device)
+    rc = N.lib().fz_ln_gemm_qkvt(C.byref(d), x.data_ptr(), _ptr(g), _ptr(b), float(eps), w.data_ptr(), y.data_ptr(), vt.data_ptr(), split, l,
+                                 cv * l, l, _stream(x))
+    if rc:
+        N.check(rc, "fz_ln_gemm_qkvt")
+    return y, vt
+
+
 _qkvt_plans = {}
 
 

@@ -566,6 +566,69 @@ def case_gemm_qkvt(device, *, n, l, k, c, tile_cfg=0, seed=0, ldx_extra=0):
             "vt_max_diff_vs_two_launches": float((vt.float() - vt2.float()).abs().max())}
 
 
+def case_ln_gemm(device, *, rows, o, ln=True, bias=True, n_res=0, seed=0, ldx_extra=0, lead=None, mean_shift=0.0):
+    """fz_ln_gemm (csrc/rowgemm.hip): LayerNorm + Linear (+ bias, residuals) in one launch, K = 320, vs fp32 torch with LN(x) rounded to
+    fp16 (what fz_layernorm stores and the GEMM then reads), and vs the two launches it replaces (fz_layernorm + fz_gemm) to a few fp16 ulp."""
+    g = torch.Generator().manual_seed(seed)
+    k = 320
+    xfull = (torch.randn(rows, k + ldx_extra, generator=g) * 1.5 + mean_shift).half().to(device)
+    x = xfull[:, ldx_extra:] if ldx_extra else xfull
+    w = (torch.randn(o, k, generator=g) * k ** -0.5).half()
+    b = (torch.randn(o, generator=g) * 0.3).half() if bias else None
+    gamma = (1.0 + 0.2 * torch.randn(k, generator=g)).half()
+    beta = (0.1 * torch.randn(k, generator=g)).half()
+    res = [torch.randn(rows, o, generator=g).half().to(device) for _ in range(n_res)]
+    eps = 1e-5
+    xin = x if lead is None else x.reshape(*lead, k)
+    assert K.ln_gemm_ok(xin, w.to(device))
+    y = K.ln_gemm(xin, w.to(device), None if b is None else b.to(device), ln=(gamma.to(device), beta.to(device), eps) if ln else None,
+                  res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None).reshape(rows, o)
+    xc = x.float().cpu()
+    xn = F.layer_norm(xc, (k,), gamma.float(), beta.float(), eps).half().float() if ln else xc
+    ref = xn @ w.float().t()
+    if bias:
+        ref = ref + b.float()
+    for r in res:
+        ref = ref + r.float().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((y.float().cpu() - ref).abs().max())
+    assert torch.isfinite(y.float()).all() and err < 4e-3 * scale, (err, scale)
+    # the two launches it replaces
+    xn_dev = K.layernorm(x.contiguous(), gamma.to(device), beta.to(device), eps=eps) if ln else x
+    y2 = K.gemm(xn_dev, w.to(device), None if b is None else b.to(device), res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None)
+    e2 = float((y.float() - y2.float()).abs().max())
+    assert e2 <= 4 * 2.0 ** -10 * scale, (e2, scale)
+    return {"max_err": err, "vs_two_launches": e2}
+
+
+def case_ln_gemm_qkvt(device, *, n, l, c=320, ln=True, seed=0):
+    """fz_ln_gemm_qkvt: LayerNorm + q | k | V^T in one launch vs fp32 torch and vs fz_layernorm + fz_gemm_qkvt."""
+    g = torch.Generator().manual_seed(seed)
+    k = 320
+    x = (torch.randn(n, l, k, generator=g) * 1.2 + 0.3).half().to(device)
+    w = (torch.randn(3 * c, k, generator=g) * k ** -0.5).half().to(device)
+    gamma = (1.0 + 0.2 * torch.randn(k, generator=g)).half().to(device)
+    beta = (0.1 * torch.randn(k, generator=g)).half().to(device)
+    eps = 1e-5
+    assert K.ln_gemm_qkvt_ok(x, w, 2 * c)
+    qk, vt = K.ln_gemm_qkvt(x, w, 2 * c, ln=(gamma, beta, eps) if ln else None)
+    assert qk.shape == (n, l, 2 * c) and vt.shape == (n, c, l)
+    xc = x.float().cpu()
+    xn = F.layer_norm(xc, (k,), gamma.float().cpu(), beta.float().cpu(), eps).half().float() if ln else xc
+    ref = xn @ w.float().cpu().t()
+    scale = max(1.0, float(ref.abs().max()))
+    e_qk = float((qk.float().cpu() - ref[..., : 2 * c]).abs().max())
+    e_vt = float((vt.float().cpu() - ref[..., 2 * c:].transpose(1, 2)).abs().max())
+    assert e_qk < 4e-3 * scale and e_vt < 4e-3 * scale, (e_qk, e_vt, scale)
+    res = {"qk_err": e_qk, "vt_err": e_vt}
+    if K.gemm_qkvt_ok(x, w, 2 * c):
+        xn_dev = K.layernorm(x, gamma, beta, eps=eps) if ln else x
+        qk2, vt2 = K.gemm_qkvt(xn_dev, w, 2 * c)
+        res["vs_two_launches"] = max(float((qk.float() - qk2.float()).abs().max()), float((vt.float() - vt2.float()).abs().max()))
+        assert res["vs_two_launches"] <= 4 * 2.0 ** -10 * scale, res
+    return res
+
+
 def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, producer="tconv", seed=0):
     """GroupNorm statistics out of the PRODUCING launch's epilogue (fz_temporal_conv3_gn / fz_gemm_gn -> fz_groupnorm_from_partials): the
     producer's output must be bit-identical to the plain launch, and GroupNorm(+SiLU) from the epilogue's partials must match both the

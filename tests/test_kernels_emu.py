@@ -312,6 +312,22 @@ def test_gemm_qkvt_rejects_a_pinned_tile_across_the_kv_boundary():
         K.gemm_qkvt(x, w, 128, tile_cfg=123456)  # not a qkvt tile at all
 
 
+def test_layernorm_plus_projection_in_one_launch():
+    """csrc/rowgemm.hip on the emulator: 128-row workgroups (whole and ragged last one), one and several 320-column passes, LayerNorm on /
+    off, bias, one / two residuals, a strided x view, rows with a large mean (two-sweep statistics)."""
+    KC.case_ln_gemm(DEV, rows=256, o=320, n_res=1)
+    KC.case_ln_gemm(DEV, rows=200, o=640, n_res=2, ldx_extra=8, seed=1)
+    KC.case_ln_gemm(DEV, rows=128, o=320, ln=False, bias=True, n_res=1, seed=2)
+    KC.case_ln_gemm(DEV, rows=40, o=960, bias=False, lead=(5, 8), mean_shift=6.0, seed=3)
+
+
+def test_layernorm_plus_qkvt_in_one_launch():
+    r = KC.case_ln_gemm_qkvt(DEV, n=3, l=64)
+    assert "vs_two_launches" in r
+    KC.case_ln_gemm_qkvt(DEV, n=2, l=96, ln=False, seed=1)   # 96 tokens per frame: a 128-row workgroup spans two frames mid sub-tile? no: 32 | 96
+    KC.case_ln_gemm_qkvt(DEV, n=1, l=160, seed=2)             # ragged last workgroup
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)

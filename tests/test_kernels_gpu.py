@@ -303,6 +303,17 @@ def test_gemm_qkvt_rejects_a_pinned_tile_across_the_kv_boundary():
         K.gemm_qkvt(x, w, 128, tile_cfg=123456)  # not a qkvt tile at all
 
 
+def test_layernorm_plus_projection_in_one_launch():
+    """csrc/rowgemm.hip at the 64x64-level shapes (8 / 16 frames x 4096 tokens x 320): LayerNorm + Linear (+ bias, residuals), several
+    320-column passes, a ragged last workgroup, LayerNorm + q | k | V^T -- vs fp32 torch and vs the launches it would replace."""
+    print(KC.case_ln_gemm(DEV, rows=32768, o=320, n_res=1))
+    print(KC.case_ln_gemm(DEV, rows=4096 * 3 + 200, o=640, n_res=2, seed=1))
+    print(KC.case_ln_gemm(DEV, rows=65536, o=320, ln=False, bias=True, n_res=1, seed=2))
+    print(KC.case_ln_gemm(DEV, rows=32768, o=960, bias=False, mean_shift=6.0, seed=3))
+    print(KC.case_ln_gemm_qkvt(DEV, n=8, l=4096))
+    print(KC.case_ln_gemm_qkvt(DEV, n=16, l=4096, ln=False, seed=1))
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=8, l=4096, k=320, c=320, lp=4096)
     KC.case_gemm_vt(DEV, n=4, l=1024, k=640, c=640, lp=1024)
