@@ -36,6 +36,13 @@
 __attribute__((weak)) int fz_igemm_trial_no_pp = 0;
 __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute under split-K as well when a K slice has at least this many K-64 steps
 #endif
+// The shipped library reads NO environment variable: the A/B switches of rounds 3-4 (tile order, K slices on XCDs, split-K launch cost)
+// exist only in builds with -DFZ_IGEMM_TUNING (scripts/build_variant.sh), where they are read once per process.
+#ifdef FZ_IGEMM_TUNING
+#define FZ_TUNING_FLAG(name) (getenv(name) != nullptr)
+#else
+#define FZ_TUNING_FLAG(name) false
+#endif
 #define FZ_PP_ON 1
 #define FZ_PP_NOPRIO 2
 #define FZ_PP_NOSTAGGER 4
@@ -1189,7 +1196,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     g.tiles_b = (int)tiles_b;
     g.group_b = 1;
     {
-        static const bool order_off = getenv("FZ_IGEMM_NO_TILE_ORDER") != nullptr;  // A/B switch (tuning only)
+        static const bool order_off = FZ_TUNING_FLAG("FZ_IGEMM_NO_TILE_ORDER");  // A/B switch (tuning builds only)
         const double kbytes = 2.0 * g.taps * g.Cin / (g.ksplit > 0 ? g.ksplit : 1);
         const double apanel = C::BA * kbytes, bpanel = C::BB * kbytes * (g.taps == 9 ? 1.5 : 1.0);
         const double conc = 32.0 * C::WAVES_PER_SIMD * 4 / C::NW;  // workgroups an XCD runs at a time (32 CUs x workgroups per CU)
@@ -1219,12 +1226,12 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
         // launches, LOSES 4.8 ms with a grouped order: it keeps the a-fastest one)
         if (!order_off && batch == 1 && g.ksplit == 1 && C::NW == 8 && best < 0.8 * cost(1.0)) g.group_b = best_g;
     }
-    static const bool xcd_ks_off = getenv("FZ_IGEMM_NO_XCD_KS") != nullptr;  // A/B switch of the K-slice -> XCD mapping (tuning only)
+    static const bool xcd_ks_off = FZ_TUNING_FLAG("FZ_IGEMM_NO_XCD_KS");  // A/B switch of the K-slice -> XCD mapping (tuning builds only)
     // Which launches: the kernel-level A/B (profiles/r04_xcd_ks_ab.txt: one launch repeated, its weights resident in Infinity Cache) has the
     // convolutions with Cin >= 1280 gain 3-6 % and the 10-25 us split-K projections / temporal convolutions LOSE up to 15 %; IN SITU (two
     // kernel-stats profiles per setting, profiles/r04_xcd_ks_in_situ.txt), where the weights come from HBM, the split-K projections gain
     // 1.9 ms per job and only the temporal convolutions lose (0.6 ms): every mode but the temporal one takes the flat grid.
-    static const bool xcd_ks_all = getenv("FZ_IGEMM_XCD_KS_ALL") != nullptr;  // trial switch: the temporal convolutions as well
+    static const bool xcd_ks_all = FZ_TUNING_FLAG("FZ_IGEMM_XCD_KS_ALL");  // trial switch: the temporal convolutions as well
     const bool flat = (MODE != 2 || xcd_ks_all) && g.ksplit > 1 && !xcd_ks_off && (nt * g.ksplit) % 8 == 0 && nt * g.ksplit < (1ll << 31);
     g.nt_flat = flat ? (int)nt : 0;
     dim3 grid(flat ? (unsigned)(nt * g.ksplit) : (unsigned)nt, flat ? 1u : (unsigned)g.ksplit, (unsigned)batch), block(C::T);
@@ -1390,7 +1397,11 @@ static const IgTile kTiles[] = {
 #define FZ_SPLITK_LAUNCH_US 3.0  /* fitted; 9.0 (reduce run time + inter-kernel gap at face value) chose too few splits: 32^2 conv 728 -> 561 TF/s */
 #endif
 static void ig_choose(const IgArgs& g, int batch, bool geglu, int64_t ws_floats, int* cfg_out, int* ksplit_out) {
-    static const double splitk_us = getenv("FZ_IGEMM_SPLITK_US") ? atof(getenv("FZ_IGEMM_SPLITK_US")) : FZ_SPLITK_LAUNCH_US;  // (env: in-situ tuning runs)
+#ifdef FZ_IGEMM_TUNING
+    static const double splitk_us = getenv("FZ_IGEMM_SPLITK_US") ? atof(getenv("FZ_IGEMM_SPLITK_US")) : FZ_SPLITK_LAUNCH_US;  // (in-situ tuning runs)
+#else
+    constexpr double splitk_us = FZ_SPLITK_LAUNCH_US;
+#endif
     double best = 1e300;
     *cfg_out = 212222;
     *ksplit_out = 1;
