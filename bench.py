@@ -781,6 +781,9 @@ def main():
                          "its self-test round trip succeeds on EVERY rank, else rccl (the line says which).  Default rccl: the peer transport "
                          "has met HIP IPC between two processes on one GPU but never xGMI -- opt in with --transport auto / peer")
     ap.add_argument("--peer-heap-gb", type=float, default=2.0, help="symmetric heap per GPU for --transport peer")
+    ap.add_argument("--blend-th", type=float, default=None,
+                    help="blend_th of the Porsche edit in the TIMED jobs instead of the config's 0.3 (the in-situ PMC pass of scripts/pmc_job.sh "
+                         "runs the split-mask job with it, so that the inject class it attributes really reads stored rows); the line says so")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration (fixed flash launch, 1 GiB copy) and the clock / power sampler")
     ap.add_argument("--no-split-mask", action="store_true",
                     help="skip the threshold sweep + the extra job whose blend mask splits the rows (the kernel breakdown then runs with th = 0.3)")
@@ -859,7 +862,7 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # job boundaries on the launch stream: no sync inside
     marks[0].record()
     for i in range(args.steps):
-        edited = run_job(pipe, z0, args.ddim_steps, device, args.n_edit)  # only the judged flash launches carry event brackets here
+        edited = run_job(pipe, z0, args.ddim_steps, device, args.n_edit, blend_th=args.blend_th)  # only the judged flash launches carry event brackets here
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -941,6 +944,7 @@ def main():
                                           "CFG edit (Replace, blend-masked self-attention), ") + "SD-1.x pseudo-3D UNet lora=160, "
                                        "random-init weights",
                            "frames": args.frames, "ddim_steps": args.ddim_steps, "n_edit": args.n_edit,
+                           **({"blend_th_override": args.blend_th} if args.blend_th is not None else {}),
                            "parallelism": ("single GPU" if world == 1 else
                                            f"{world}-way frame-sharded clip" if by_frames else f"dp{world} over clips"),
                            "arena_GB": pipe.store_controller.arena_bytes / 1e9, "outputs_finite": finite,

@@ -315,6 +315,9 @@ FZ_DEVICE void fz_st_h8_nt(half_t* p, half8_t v) {
 // error <= 1.7e-4 wherever |gelu| > 1e-3, i.e. below half an fp16 ulp of the stored value).  libm's erff is a two-branch
 // ~45-instruction sequence per call, which made the GEGLU epilogue of the K = 320 projection longer than its K loop.
 FZ_DEVICE float fz_gelu_erf(float x) {
+#ifdef FZ_GELU_TRIAL_IDENTITY  // (trial builds only, scripts/build_variant.sh: an upper bound on what a cheaper GELU could buy)
+    return x;
+#endif
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = fz_rcp(fmaf(0.3275911f, z, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
