@@ -54,18 +54,24 @@ while i < len(lines):
                 out += wrap(text.replace("\\|", "|"), "* ", "  ")
         i = j
         continue
-    if len(ln) <= W:
+    if ln.strip() == "" or ln.startswith("#") or ln.startswith(">") or ln.lstrip().startswith("|"):
         out.append(ln)
-    else:
-        m = re.match(r"^(\s*)([*+-]|\d+\.)\s+", ln)
-        if m:
-            first = m.group(0)
-            out += wrap(ln[len(first):], first, " " * len(first))
-        elif ln.startswith("#"):
-            out.append(ln)
-        else:
-            ind = re.match(r"^\s*", ln).group(0)
-            out += wrap(ln.strip(), ind, ind)
-    i += 1
+        i += 1
+        continue
+    # a paragraph or list item: gather its continuation lines (same block: non-empty, not a new item / heading / table / fence), re-flow
+    item = re.compile(r"^(\s*)([*+-]|\d+\.)\s+")
+    m = item.match(ln)
+    first = m.group(0) if m else re.match(r"^\s*", ln).group(0)
+    rest_ind = " " * len(first) if m else first
+    text = [ln[len(first):].strip()]
+    j = i + 1
+    while j < len(lines):
+        nx = lines[j]
+        if nx.strip() == "" or nx.startswith("#") or nx.lstrip().startswith("|") or nx.lstrip().startswith("```") or item.match(nx) or nx.startswith(">"):
+            break
+        text.append(nx.strip())
+        j += 1
+    out += wrap(" ".join(t for t in text if t), first, rest_ind)
+    i = j
 open(dst, "w").write("\n".join(out))
 print(dst, "max line", max(len(l) for l in out), "lines", len(out))
