@@ -531,6 +531,13 @@ def install_timers(K, timer):
         return gemm_class(x, w, kw)
     timer.wrap(K, "gemm_gn", sel_gemm_gn)
 
+    def sel_gemm_lnout(x, w, bias, ln, **kw):  # a projection whose epilogue also writes the next LayerNorm's output (one more rows x N write)
+        if not timer.extra:
+            return None
+        return gemm_class(x, w, dict(kw, ln_out=True))
+    if hasattr(K, "gemm_lnout"):
+        timer.wrap(K, "gemm_lnout", sel_gemm_lnout)
+
 
 def gemm_class(x, w, kw):
     """Roofline class of one projection GEMM (>= 1024 rows).  The launches fall into two regimes: plain projections with
@@ -546,7 +553,7 @@ def gemm_class(x, w, kw):
     geglu = bool(kw.get("geglu"))
     n_out = o // 2 if geglu else o
     n_res = (kw.get("res") is not None) + (kw.get("res2") is not None)
-    alg = 2.0 * (rows * k + rows * n_out * (1 + n_res) + k * o)
+    alg = 2.0 * (rows * k + rows * n_out * (1 + n_res + (1 if kw.get("ln_out") else 0)) + k * o)
     flops = 2.0 * rows * k * o
     if geglu or k > 640:
         return ("gemm_mfma", flops, alg)
@@ -559,11 +566,11 @@ def install_launch_log(K, path):
     counter rows rocprofv3 writes per dispatch can be attributed to the classes the line reports.  Written at exit."""
     import atexit
     log = []
-    for fn_name in ("gemm", "gemm_vt", "gemm_batched", "gemm_qkvt", "gemm_gn"):
+    for fn_name in ("gemm", "gemm_vt", "gemm_batched", "gemm_qkvt", "gemm_gn", "gemm_lnout"):
         orig = getattr(K, fn_name)
 
         def wrapped(x, w, *a, _orig=orig, _name=fn_name, **k):
-            if _name in ("gemm", "gemm_qkvt", "gemm_gn"):
+            if _name in ("gemm", "gemm_qkvt", "gemm_gn", "gemm_lnout"):
                 tag = gemm_class(x, w, k if _name != "gemm_qkvt" else {})
                 log.append("gemm_small" if tag is None else tag[0])
             else:

@@ -74,6 +74,7 @@ _SIGS = {
     "fz_ln_gemm_preferred": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "fz_ln_gemm": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
     "fz_ln_gemm_qkvt": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
+    "fz_gemm_lnout": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int64, _P, _P]),
     "fz_gemm_ln": (C.c_int, [C.POINTER(FzGemmDesc), C.POINTER(FzGemmLn), _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_gemm_qkvt": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
     "fz_gn_epilogue_chunks": (C.c_int, [C.c_int64]),

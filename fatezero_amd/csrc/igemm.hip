@@ -107,6 +107,13 @@ struct IgArgs {
     // (frame, group, 128-row chunk) in the layout gn_finalize reads, gs_out[frame][gs_groups][gs_chunks][3]
     float* gs_out;
     int gs_cpg, gs_groups, gs_chunks, gs_rpf;  // channels per group, groups of the whole tensor, chunks per frame, B rows per frame
+    // LayerNorm of the STORED rows out of the epilogue (the GS == -1 instantiation, fz_gemm_lnout): the tile spans the whole row (Ma == 320 ==
+    // the tile width), so the row statistics are exact two-sweep sums over the staging tile; lno_y[row][0..Ma) = LN(y[row]) * gamma + beta
+    half_t* lno_y;
+    const half_t* lno_gamma;
+    const half_t* lno_beta;
+    int64_t lno_ld;
+    float lno_eps;
 };
 
 template <int WA, int TA, int WB, int TB, int BK, int NS, bool GEGLU, int PP = 0>
@@ -997,11 +1004,61 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
                 fz_st_h8(dst, o);
-                if constexpr (GS > 0) fz_st_h8(Cs + pl * C::CSTR + ch * 8, o);  // the staging tile now holds what was STORED
+                if constexpr (GS != 0) fz_st_h8(Cs + pl * C::CSTR + ch * 8, o);  // the staging tile now holds what was STORED
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (co + e < Mo_store) dst[e] = (half_t)f[e];
+            }
+        }
+        if constexpr (GS == -1) {
+            // LayerNorm of the RP rows this pass stored (attention.py:295-337: every `x = f(norm(x)) + x` step ends in a Linear + residual
+            // whose output is the NEXT LayerNorm's input).  The tile is the whole row (launcher: Ma == CW == 320, a0 == 0, vector path), and
+            // the staging tile holds the fp16 values that were stored -- what a stand-alone fz_layernorm would read back from HBM.  8 lanes per
+            // row, 5 chunks of 8 channels per lane, exact two-sweep statistics (DPP sums over the 8 lanes, fixed order), one more row-major
+            // store.  The LayerNorm launch, its read of x and its launch latency are gone; the GEMM pays ~1 us of epilogue.
+            static_assert(C::CW == 320, "the tile must hold whole 320-channel rows");
+            __syncthreads();
+            const int l8 = tid & 7;
+            half8_t gmv[5], btv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                gmv[i] = fz_ld_h8(g.lno_gamma + (l8 + 8 * i) * 8);
+                btv[i] = fz_ld_h8(g.lno_beta + (l8 + 8 * i) * 8);
+            }
+            for (int rb = tid >> 3; rb < C::RP; rb += C::T >> 3) {
+                const int64_t px = b0 + ps * C::RP + rb;
+                half8_t v[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) v[i] = fz_ld_h8(Cs + rb * C::CSTR + (l8 + 8 * i) * 8);
+                float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        s0 += (float)v[i][e];
+                        s1 += (float)v[i][e + 1];
+                    }
+                const float mean = fz_sum8(s0 + s1) * (1.0f / 320.0f);
+                float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float d0 = (float)v[i][e] - mean, d1 = (float)v[i][e + 1] - mean;
+                        q0 += d0 * d0;
+                        q1 += d1 * d1;
+                    }
+                const float rstd = 1.0f / sqrtf(fz_sum8(q0 + q1) * (1.0f / 320.0f) + g.lno_eps);
+                if (px < g.Nb) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        half8_t o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mean) * rstd * (float)gmv[i][e] + (float)btv[i][e]);
+                        fz_st_h8(g.lno_y + ((int64_t)z * g.Nb + px) * g.lno_ld + (l8 + 8 * i) * 8, o);
+                    }
+                }
             }
         }
         if constexpr (GS > 0) {
@@ -1361,6 +1418,17 @@ static int ig_dispatch_gs_w(int cfg, const IgArgs& g, int batch, void* stream) {
         default: return FZ_ERR_BAD_ARG;
     }
 }
+// The LayerNorm-out instantiations (GS == -1): the three 320-wide tiles a 64x64-level projection onto 320 channels takes (MODE 0).
+static int ig_dispatch_lno(int cfg, const IgArgs& g, int batch, void* stream) {
+    constexpr int P = FZ_PP_ON | FZ_PP_PREP_IN_R;
+    switch (cfg) {
+        case 254222: return ig_launch<2, 5, 4, 2, 64, 2, 0, false, false, 0, false, -1>(g, batch, stream);
+        case 254122: return ig_launch<2, 5, 4, 1, 64, 2, 0, false, false, 0, false, -1>(g, batch, stream);
+        case 254218: return ig_launch<2, 5, 4, 2, 32, 4, 0, false, false, P, false, -1>(g, batch, stream);
+        default: return FZ_ERR_BAD_ARG;
+    }
+}
+
 template <int MODE>
 static int ig_dispatch_gs(int cfg, const IgArgs& g, int batch, void* stream) {
     if constexpr (MODE == 0 || MODE == 2) {
@@ -1472,6 +1540,19 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
     if (ksplit == 0) ksplit = 1;
     if (g.ln_in != nullptr) ksplit = 1;  // the LayerNorm correction lives in the GEMM's own epilogue
     bool gs_dropped = false;
+    if (g.lno_y != nullptr) {
+        // the LayerNorm leaves the epilogue only where the launch the library would pick ANYWAY is a 320-wide tile that IS the whole row
+        const bool ok = MODE == 0 && !GEGLU && ksplit == 1 && (cfg == 254222 || cfg == 254122 || cfg == 254218) && g.Ma == 320 &&
+                        g.ln_in == nullptr && g.st_out == nullptr && g.yt == nullptr && g.gs_out == nullptr && batch == 1 &&
+                        (g.ldy % 8) == 0 && (g.ldres % 8) == 0 && (g.lno_ld % 8) == 0;
+        if (ok) {
+            g.ksplit = 1;
+            g.part = nullptr;
+            return ig_dispatch_lno(cfg, g, batch, stream);
+        }
+        g.lno_y = nullptr;
+        gs_dropped = true;  // reported like a dropped statistics request: FZ_GEMM_NO_STATS, y complete
+    }
     if (g.gs_out != nullptr) {
         // Statistics leave the epilogue only where the launch the library would pick ANYWAY is a 320-wide ring tile without split-K
         // (forcing such a tile onto a launch that wants another one costs more than the statistics kernel it saves): otherwise the
@@ -1752,6 +1833,37 @@ extern "C" int fz_gemm_gn(const FzGemmDesc* d, const void* x, const void* w, con
     const bool want = ig_gs_setup(g, gn_partial, gn_groups, rows_per_frame);
     const int rc = ig_run<0, false>(g, 1, d->tile_cfg, 1, nullptr, 0, stream);
     return rc != FZ_OK ? rc : (want ? FZ_OK : FZ_GEMM_NO_STATS);
+}
+
+extern "C" int fz_gemm_lnout(const FzGemmDesc* d, const void* x, const void* w, const void* bias, const void* res, const void* res2, void* y,
+                             const void* gamma, const void* beta, float eps, void* y_ln, int64_t ld_ln, void* workspace, void* stream) {
+    if (!d || !x || !w || !y || !gamma || !beta || !y_ln || d->rows <= 0 || d->in_features <= 0 || d->out_features <= 0) return FZ_ERR_BAD_ARG;
+    if (d->epilogue != FZ_GEMM_PLAIN || d->transpose_out || d->batch > 1 || d->w_batch_stride) return FZ_ERR_UNSUPPORTED;
+    if (d->ldx < d->in_features || d->ldw < d->in_features || (d->ldx % 8) || (d->ldw % 8) || d->ldy < d->out_features || ld_ln < d->out_features)
+        return FZ_ERR_BAD_ARG;
+    IgArgs g = {};
+    g.taps = 1;
+    g.fpb = 1;
+    g.Cin = d->in_features;
+    g.temb_group = 1;
+    g.a = (const half_t*)w;
+    g.lda = d->ldw;
+    g.Ma = g.Ma_store = d->out_features;
+    g.b = (const half_t*)x;
+    g.ldb = d->ldx;
+    g.Nb = d->rows;
+    g.bias = (const half_t*)bias;
+    g.res = (const half_t*)res;
+    g.res2 = (const half_t*)res2;
+    g.y = (half_t*)y;
+    g.ldy = d->ldy;
+    g.ldres = d->ldres ? d->ldres : d->ldy;
+    g.lno_y = (half_t*)y_ln;
+    g.lno_gamma = (const half_t*)gamma;
+    g.lno_beta = (const half_t*)beta;
+    g.lno_ld = ld_ln;
+    g.lno_eps = eps;
+    return ig_run<0, false>(g, 1, d->tile_cfg, d->split_k, (float*)workspace, d->workspace_floats, stream);
 }
 
 static int temporal_conv3_impl(const void* x, const void* wt, const void* res, const void* res2, const void* temb, int64_t temb_stride,

@@ -502,6 +502,36 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return (out, stats) if want_stats else out
 
 
+def gemm_lnout(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ln, *, res: Optional[torch.Tensor] = None,
+               res2: Optional[torch.Tensor] = None, tile_cfg: int = 0):
+    """y = x @ w^T + bias (+ res) (+ res2) as K.gemm, plus LN(y) out of the same launch where the library's launch for the shape holds whole rows
+    (fz_gemm_lnout: 320 output channels on a 320-wide tile, no split-K); ln = (gamma, beta, eps) fp16.  Returns (y, y_ln) -- y_ln is None where
+    the epilogue form does not apply (y is complete: run K.layernorm)."""
+    k, o = x.shape[-1], w.shape[0]
+    rows = x.numel() // k
+    gam, bet, eps = ln
+    if (o != 320 or x.dtype != torch.float16 or not x.is_contiguous() or (res is not None and (not res.is_contiguous() or res.shape[-1] != o))
+            or (res2 is not None and (not res2.is_contiguous() or res2.shape[-1] != o)) or gam.dtype != torch.float16):
+        return _gemm_unwrapped(x, w, bias, res=res, res2=res2), None
+    _chk16(x, w, bias, res, res2, gam, bet)
+    y = torch.empty(tuple(x.shape[:-1]) + (o,), dtype=torch.float16, device=x.device)
+    yln = torch.empty_like(y)
+    d = N.FzGemmDesc()
+    d.rows, d.in_features, d.out_features = rows, k, o
+    d.ldx, d.ldw, d.ldy, d.ldres = k, w.stride(0), o, o
+    d.batch, d.epilogue, d.tile_cfg = 1, N.FZ_GEMM_PLAIN, tile_cfg
+    want_ws = o % 4 == 0 and k >= 1024 and 2 * rows * o <= _WS_FLOATS
+    if want_ws:
+        d.workspace_floats = _WS_FLOATS
+    rc = N.lib().fz_gemm_lnout(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(res), _ptr(res2), y.data_ptr(), gam.data_ptr(),
+                               bet.data_ptr(), float(eps), yln.data_ptr(), o, _ws_ptr(x.device) if want_ws else None, _stream(x))
+    if rc == N.FZ_GEMM_NO_STATS:
+        return y, None
+    if rc:
+        N.check(rc, "fz_gemm_lnout")
+    return y, yln
+
+
 _gemm_unwrapped = gemm  # (gemm_gn's fallback: a harness that wraps K.gemm -- bench.py's timers / launch log -- must see ONE call, gemm_gn's)
 
 

@@ -64,6 +64,30 @@ LN_FUSION = False
 # of a 512^2 clip.  Bit-identical to the two launches (tests/kernel_cases.py: case_gemm_qkvt).  Switch kept for same-box A/B runs.
 QKV_FUSION = os.environ.get("FZ_NO_QKV_FUSION") is None  # (the env switch: same-box A/B runs of bench.py)
 LN_FUSION_MAX_C = 640  # wider rows (K = 1280) want split-K in the consuming GEMM, which the fused epilogue excludes
+# LayerNorm out of the PRODUCING projection's epilogue (fz_gemm_lnout, round 5): every `x = f(norm(x)) + x` step ends in a Linear + residual
+# whose output is the next LayerNorm's input, and at the 320-channel level the 320-wide GEMM tile holds whole rows -- the epilogue computes
+# exact row statistics on the values it stores and writes LN(y) beside y: proj_in -> norm1, attn1.to_out -> norm2, attn2.to_out -> norm3,
+# ff.net[2] -> norm_temporal.  Four LayerNorm launches per 64x64-level block gone.  (env switch: same-box A/B runs of bench.py)
+LN_FROM_PRODUCER = os.environ.get("FZ_NO_LN_FROM_PRODUCER") is None
+LN_FROM_PRODUCER_C = 320
+
+
+class Prenormed:
+    """LN(y) that came out of the projection which produced y (fz_gemm_lnout): travels where the row statistics of fz_gemm_ln would."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def _out_proj(lin, out, residual, want_stats, ln_next):
+    """to_out / ff.net[2]: Linear + residual; with `ln_next` (the LayerNorm that consumes the result) also LN(result) from the same launch."""
+    if ln_next is not None and out.is_contiguous():
+        g, b = ln_next.packed(out.device)
+        w, bias = lin.packed(out.dtype, out.device)
+        y, yln = K.gemm_lnout(out, w, bias, (g, b, ln_next.eps), res=residual)
+        return y, (None if yln is None else Prenormed(yln))
+    return lin.apply(out, res=residual, want_stats=want_stats)
 
 
 def _ln_ready(norm, stats, x):
@@ -128,13 +152,15 @@ class CrossAttention(nn.Module):
         run_inject(p)
 
     # -- cross attention (attention_register.py:71-128) ------------------------------------------------------
-    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None, norm=None, stats=None, want_stats=False):
+    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None, norm=None, stats=None, want_stats=False, ln_next=None):
         """x.data: hidden states [N, L, C] -- LayerNorm'ed, or RAW together with (`norm`, `stats` = the row sums their producer
         wrote): the LayerNorm then rides in the to_q GEMM (fz_gemm_ln); ctx: [B, 77, Dctx] fp16.  Returns residual +
         to_out(attention) (the block's `hidden_states = attn2(...) + hidden_states`, attention.py:303-311, fused into the GEMM
         epilogue), plus that result's row statistics when want_stats."""
         n, lq, c = x.data.shape
-        if norm is not None:
+        if isinstance(stats, Prenormed):  # LN(x) came out of the producing projection's epilogue
+            q = self.to_q.apply(stats.t)
+        elif norm is not None:
             if _ln_ready(norm, stats, x.data):
                 if self._ln_fold is None or self._ln_fold[0] is not norm or self._ln_fold[1].w.device != x.data.device:
                     self._ln_fold = (norm, K.LnFold(self.to_q.weight, self.to_q.bias, norm.weight, norm.bias, norm.eps,
@@ -177,13 +203,15 @@ class CrossAttention(nn.Module):
             if plan.n_plain < n:
                 K.attn_cross(q, kk, vt, out, mode=plan.mode, frame0=plan.n_plain, n_frames=n - plan.n_plain, p=plan.p,
                              mapper_t=plan.mapper_t, coef=plan.coef, cur_out=plan.cur_out, **kw)
-        return self.to_out[0].apply(out, res=residual, want_stats=want_stats)
+        return _out_proj(self.to_out[0], out, residual, want_stats, ln_next)
 
     # -- temporal attention (attention.py:327-337; never controlled, attention_register.py:242) ---------------
     def forward_temporal(self, x_norm, batch: int, clip: int, residual=None, norm=None, stats=None):
         """x_norm: [B*F, L, C] LayerNorm'ed -- or RAW with (`norm`, `stats`): the LayerNorm then rides in the fused q/k/v GEMM;
         attention over the F frames of every (b, token); + residual in the epilogue."""
         n, l, c = x_norm.shape
+        if isinstance(stats, Prenormed):
+            x_norm, norm, stats = stats.t, None, None
         if norm is not None and not _ln_ready(norm, stats, x_norm):
             x_norm, norm = layer_norm_tokens(norm, x_norm), None
         if norm is not None:
@@ -273,7 +301,7 @@ class _ShardedKV:
 class SparseCausalAttention(CrossAttention):
     """attention.py:340-422 / attention_register.py:131-218: frame f attends the K/V of frames idx_j(f)."""
 
-    def forward_self(self, x: Tokens, clip: int, index_list, residual=None, want_stats=False):
+    def forward_self(self, x: Tokens, clip: int, index_list, residual=None, want_stats=False, ln_next=None):
         n, lq, c = x.data.shape
         xn = x.data
         # head dims with a free MFMA contraction slot (SD-1.x: 40): the softmax scale and log2(e) go into Wq, q comes out of
@@ -333,7 +361,7 @@ class SparseCausalAttention(CrossAttention):
                                 row_mask=plan.row_mask, **rest, **kw)
                 elif not (plan.mode == K.FZ_ATTN_FLASH and plan.capture_first is not None):
                     K.attn_self(q, kk, vt, out, mode=plan.mode, p=plan.p, **rest, **kw)
-        return self.to_out[0].apply(out, res=residual, want_stats=want_stats)
+        return _out_proj(self.to_out[0], out, residual, want_stats, ln_next)
 
 
 class _GEGLU(nn.Module):
@@ -359,12 +387,14 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([_GEGLU(dim, dim * mult), nn.Identity(), _LinearParams(dim * mult, dim)])
         self._ln_fold = None
 
-    def apply(self, x, res=None, norm=None, stats=None, want_stats=False):
+    def apply(self, x, res=None, norm=None, stats=None, want_stats=False, ln_next=None):
         """res + Linear(h * gelu(gate)): the 8C-wide GEGLU intermediate is never written (gate applied in the epilogue of the
         projection GEMM), the residual add rides in the epilogue of the output GEMM.  x: LayerNorm'ed, or RAW with
         (`norm`, `stats`) -- the LayerNorm then rides in the projection GEMM as well (fz_gemm_ln)."""
         g = self.net[0]
         fused = g.proj.weight.shape[0] % 64 == 0
+        if isinstance(stats, Prenormed):
+            x, norm, stats = stats.t, None, None
         if norm is not None and not (fused and _ln_ready(norm, stats, x)):
             x, norm = layer_norm_tokens(norm, x), None
         if norm is not None:
@@ -377,7 +407,7 @@ class FeedForward(nn.Module):
             h = K.gemm(x, w, b, geglu=True)
         else:
             h = K.geglu(g.proj.apply(x))
-        return self.net[2].apply(h, res=res, want_stats=want_stats)
+        return _out_proj(self.net[2], h, res, want_stats, ln_next)
 
 
 class SpatioTemporalTransformerBlock(nn.Module):
@@ -404,18 +434,21 @@ class SpatioTemporalTransformerBlock(nn.Module):
     def sc_index(self):
         return self.model_config.get("SparseCausalAttention_index", [-1, "first"])  # attention.py:347 default
 
-    def forward_tokens(self, x: Tokens, ctx):
+    def forward_tokens(self, x: Tokens, ctx, prenorm1=None):
         hs = x.data
         clip = x.f
+        lnp = LN_FROM_PRODUCER and hs.shape[-1] == LN_FROM_PRODUCER_C and hs.dtype == torch.float16 and D.active_shard() is None
         # every `x = f(norm(x)) + x` of attention.py:295-337 ends in a GEMM: the residual add is that GEMM's epilogue -- and
         # so are the row statistics of the result, which let norm2 / norm3 / norm_temporal ride inside the GEMM that consumes
         # them (fz_gemm_ln; `st` is None where that form does not apply and the LayerNorm kernel runs instead).  norm1 stays a
         # kernel: its output also feeds the transposed V projection.
-        hs, st = self.attn1.forward_self(x.like(layer_norm_tokens(self.norm1, hs)), clip, self.sc_index, residual=hs,
-                                         want_stats=LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C)
+        n1 = prenorm1 if prenorm1 is not None else layer_norm_tokens(self.norm1, hs)
+        hs, st = self.attn1.forward_self(x.like(n1), clip, self.sc_index, residual=hs,
+                                         want_stats=LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C, ln_next=self.norm2 if lnp else None)
         want = LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C
-        hs, st = self.attn2.forward_cross(x.like(hs), ctx, clip, residual=hs, norm=self.norm2, stats=st, want_stats=want)
-        hs, st = self.ff.apply(hs, res=hs, norm=self.norm3, stats=st, want_stats=want)
+        hs, st = self.attn2.forward_cross(x.like(hs), ctx, clip, residual=hs, norm=self.norm2, stats=st, want_stats=want,
+                                          ln_next=self.norm3 if lnp else None)
+        hs, st = self.ff.apply(hs, res=hs, norm=self.norm3, stats=st, want_stats=want, ln_next=self.norm_temporal if lnp else None)
         hs = self.attn_temporal.forward_temporal(hs, x.b, clip, residual=hs, norm=self.norm_temporal, stats=st)
         return x.like(hs)
 
@@ -437,8 +470,15 @@ class SpatioTemporalTransformerModel(nn.Module):
 
     def forward_tokens(self, x: Tokens, ctx) -> Tokens:
         h = group_norm_tokens(self.norm, x, span_frames=False, silu=False)
-        h = h.like(self.proj_in.apply(h.data))
-        h = self.transformer_blocks[0].forward_tokens(h, ctx)
+        blk = self.transformer_blocks[0]
+        pre1 = None
+        if (LN_FROM_PRODUCER and self.proj_in.weight.shape[0] == LN_FROM_PRODUCER_C and h.data.dtype == torch.float16 and h.data.is_contiguous()
+                and D.active_shard() is None):
+            y, pre1 = self.proj_in.apply_lnout(h.data, blk.norm1)  # proj_in + norm1 of the block in one launch
+            h = h.like(y)
+        else:
+            h = h.like(self.proj_in.apply(h.data))
+        h = blk.forward_tokens(h, ctx, prenorm1=pre1)
         from .resnet import GN_FROM_EPILOGUE
         if GN_FROM_EPILOGUE and D.active_shard() is None:
             # the next consumer is a GroupNorm (the following resnet's norm1 / conv_norm_out) with the UNet's group count: where the
@@ -469,6 +509,12 @@ class _Conv1x1Params(nn.Module):
     def apply(self, x, res=None):
         w, b = self._pack(x)
         return K.gemm(x, w, b, res=res)
+
+    def apply_lnout(self, x, norm):
+        """apply() + LayerNorm `norm` of the result out of the same launch: (y, LN(y) or None)."""
+        w, b = self._pack(x)
+        g, be = norm.packed(x.device)
+        return K.gemm_lnout(x, w, b, (g, be, norm.eps))
 
     def apply_gn(self, x, res, groups, rows_per_frame):
         """apply() + the GroupNorm(groups) statistics partials of the result out of the same launch: (y, partial or None)."""

@@ -315,6 +315,16 @@ int fz_groupnorm_from_partials(const void* x, void* y, const void* gamma, const 
                                int channels, int groups, float eps, int silu, const float* partial, int partial_chunks, float* stats,
                                void* stream);
 
+/* fz_gemm that ALSO writes the LayerNorm of the rows it stores: every `x = f(norm(x)) + x` step of SpatioTemporalTransformerBlock.forward
+ * (attention.py:295-337) ends in a Linear + residual whose output is the NEXT LayerNorm's input (attn1.to_out -> norm2, attn2.to_out -> norm3,
+ * ff.net[2] -> norm_temporal; proj_in -> norm1).  Where the launch the library picks for the shape is a 320-wide tile that holds WHOLE rows
+ * (out_features == 320: the 64x64 level), the epilogue computes exact two-sweep row statistics on the fp16 values it stored and writes
+ *   y_ln[row][o] = (y[row][o] - mean_row) * rstd_row * gamma[o] + beta[o]        (row stride ld_ln)
+ * beside y: the LayerNorm launch and its read of y are gone.  Returns 0 when y_ln was written, FZ_GEMM_NO_STATS (> 0) when the launch cannot
+ * produce it (other widths, split-K, narrower tiles): y is complete, y_ln untouched -- run fz_layernorm.  workspace as for fz_gemm. */
+int fz_gemm_lnout(const FzGemmDesc* desc, const void* x, const void* w, const void* bias, const void* res, const void* res2, void* y,
+                  const void* gamma, const void* beta, float eps, void* y_ln, int64_t ld_ln, void* workspace, void* stream);
+
 /* LayerNorm over channels, rows = tokens (attention.py:193-233). gamma/beta fp16. */
 int fz_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int channels,
                  float eps, void* stream);

@@ -566,6 +566,32 @@ def case_gemm_qkvt(device, *, n, l, k, c, tile_cfg=0, seed=0, ldx_extra=0):
             "vt_max_diff_vs_two_launches": float((vt.float() - vt2.float()).abs().max())}
 
 
+def case_gemm_lnout(device, *, rows, k, n_res=1, bias=True, seed=0, mean_shift=0.0, expect=True, tile_cfg=0):
+    """fz_gemm_lnout: fz_gemm whose epilogue also writes LayerNorm(y) for whole-row (320-wide) tiles.  y must be BIT-IDENTICAL to fz_gemm's;
+    y_ln vs fp32 torch LayerNorm of the stored fp16 y, and vs fz_layernorm on it (a few fp16 ulp: other summation order)."""
+    g = torch.Generator().manual_seed(seed)
+    o = 320
+    x = torch.randn(rows, k, generator=g).half().to(device)
+    w = (torch.randn(o, k, generator=g) * k ** -0.5).half().to(device)
+    b = ((torch.randn(o, generator=g) * 0.3) + mean_shift).half().to(device) if bias else None
+    res = [(torch.randn(rows, o, generator=g) * 1.5).half().to(device) for _ in range(n_res)]
+    gamma = (1.0 + 0.2 * torch.randn(o, generator=g)).half().to(device)
+    beta = (0.1 * torch.randn(o, generator=g)).half().to(device)
+    kw = dict(res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None)
+    y0 = K.gemm(x, w, b, tile_cfg=tile_cfg, **kw)
+    y, yln = K.gemm_lnout(x, w, b, (gamma, beta, 1e-5), tile_cfg=tile_cfg, **kw)
+    assert torch.equal(y, y0), "the LayerNorm epilogue must not change what is stored"
+    if yln is None:
+        assert not expect, "this shape runs on a whole-row tile: the LayerNorm must come from the epilogue"
+        return None
+    ref = F.layer_norm(y.float().cpu(), (o,), gamma.float().cpu(), beta.float().cpu(), 1e-5)
+    e_t = float((yln.float().cpu() - ref).abs().max())
+    e_k = float((yln.float() - K.layernorm(y, gamma, beta, eps=1e-5).float()).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert e_t < 2e-3 * scale and e_k <= 3 * 2.0 ** -10 * scale, (e_t, e_k, scale)
+    return {"vs_torch": e_t, "vs_layernorm_kernel": e_k}
+
+
 def case_ln_gemm(device, *, rows, o, ln=True, bias=True, n_res=0, seed=0, ldx_extra=0, lead=None, mean_shift=0.0):
     """fz_ln_gemm (csrc/rowgemm.hip): LayerNorm + Linear (+ bias, residuals) in one launch, K = 320, vs fp32 torch with LN(x) rounded to
     fp16 (what fz_layernorm stores and the GEMM then reads), and vs the two launches it replaces (fz_layernorm + fz_gemm) to a few fp16 ulp."""

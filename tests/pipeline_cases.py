@@ -562,6 +562,12 @@ GEOMETRY_CASES = {
                                           is_replace=True, cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
                                           blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=None, blend_latents=True,
                                           regime="split"),
+    # the reference's DEFAULT blend (th [2, 2]: every row takes the stored map -- the inject launches run without a row mask) at FULL width and
+    # the judged 8 / 16-frame launch shapes; T = 2: the cross and self windows are live at step 0 and closed at step 1
+    "cfg2_fullwidth_8f_all_stored": dict(kind="sd15", F=8, L=64, T=2, model_config={"lora": 160}, prompt_case="teaser_posche", is_replace=True,
+                                         cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
+                                         blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[2, 2], blend_latents=False,
+                                         regime="all_stored"),
     # miniature of the same harness for the GPU-less suite (emulator): all three windows toggle inside T = 6
     "mini_emu": dict(kind="tiny16", F=2, L=64, T=6, model_config={"lora": 16}, prompt_case="teaser_posche", is_replace=True,
                      cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,

@@ -312,6 +312,16 @@ def test_gemm_qkvt_rejects_a_pinned_tile_across_the_kv_boundary():
         K.gemm_qkvt(x, w, 128, tile_cfg=123456)  # not a qkvt tile at all
 
 
+def test_layernorm_out_of_the_producing_gemm_epilogue():
+    """fz_gemm_lnout on the emulator: the 320 x 128 tile (rows <= 32768), the 320 x 256 ring tile, the ping-pong tile (K >= 640), ragged rows,
+    rows with a large mean; shapes whose launch is not a whole-row tile report it and y is still right."""
+    assert KC.case_gemm_lnout(DEV, rows=300, k=64, n_res=1, tile_cfg=254122) is not None
+    assert KC.case_gemm_lnout(DEV, rows=600, k=64, n_res=2, bias=False, seed=1, tile_cfg=254222) is not None
+    assert KC.case_gemm_lnout(DEV, rows=384, k=640, n_res=1, mean_shift=5.0, seed=2, tile_cfg=254218) is not None   # the ping-pong loop's tile
+    assert KC.case_gemm_lnout(DEV, rows=100, k=64, n_res=1, seed=3, expect=False) is None     # the library picks a 64-wide tile: no LayerNorm from it
+    assert KC.case_gemm_lnout(DEV, rows=256, k=64, n_res=1, seed=4, expect=False, tile_cfg=212222) is None
+
+
 def test_layernorm_plus_projection_in_one_launch():
     """csrc/rowgemm.hip on the emulator: 128-row workgroups (whole and ragged last one), one and several 320-column passes, LayerNorm on /
     off, bias, one / two residuals, a strided x view, rows with a large mean (two-sweep statistics)."""

@@ -303,6 +303,17 @@ def test_gemm_qkvt_rejects_a_pinned_tile_across_the_kv_boundary():
         K.gemm_qkvt(x, w, 128, tile_cfg=123456)  # not a qkvt tile at all
 
 
+def test_layernorm_out_of_the_producing_gemm_epilogue():
+    """fz_gemm_lnout at the 64x64-level shapes of the bench job (8 / 16 frames x 4096 tokens -> 320 channels, K = 320 and K = 1280: the 320 x 128
+    ring tile, the 320 x 256 ring tile and the ping-pong tile), ragged rows: y bit-identical to fz_gemm, LN(y) vs fp32 torch and fz_layernorm."""
+    for kw in (dict(rows=32768, k=320, n_res=1), dict(rows=65536, k=320, n_res=1, seed=1), dict(rows=32768, k=1280, n_res=1, seed=2),
+               dict(rows=65536, k=1280, n_res=1, mean_shift=4.0, seed=3), dict(rows=32768, k=320, n_res=0, seed=4), dict(rows=32768 + 72, k=320, n_res=2, seed=5, tile_cfg=254122)):  # (ragged last tile: pinned)
+        r = KC.case_gemm_lnout(DEV, **kw)
+        print("gemm_lnout", kw, r)
+        assert r is not None
+    assert KC.case_gemm_lnout(DEV, rows=512, k=1280, n_res=1, expect=False) is None   # 8x8 level rows, 320 outputs: small tiles / split-K
+
+
 def test_layernorm_plus_projection_in_one_launch():
     """csrc/rowgemm.hip at the 64x64-level shapes (8 / 16 frames x 4096 tokens x 320): LayerNorm + Linear (+ bias, residuals), several
     320-column passes, a ragged last workgroup, LayerNorm + q | k | V^T -- vs fp32 torch and vs the launches it would replace."""

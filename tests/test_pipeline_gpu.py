@@ -113,7 +113,7 @@ def test_oracle_executed_on_the_gpu_matches_the_cpu_oracle():
     assert e_edit <= 1e-3 * scale or aflips > 0, (e_edit, scale)
 
 
-GEOMETRY = ["cfg3_style_16f", "cfg4_attribute_24f_latentblend", "cfg5_shape_32f_l72", "cfg2_fullwidth_8f_latentblend"]
+GEOMETRY = ["cfg3_style_16f", "cfg4_attribute_24f_latentblend", "cfg5_shape_32f_l72", "cfg2_fullwidth_8f_latentblend", "cfg2_fullwidth_8f_all_stored"]
 
 
 @pytest.mark.parametrize("name", GEOMETRY)
