@@ -1550,6 +1550,8 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
             g.part = nullptr;
             return ig_dispatch_lno(cfg, g, batch, stream);
         }
+        // (a split-K launch could hand the LayerNorm to its tail kernel -- one wave per row summing the slabs -- and that form was built and
+        //  measured: it costs the job +0.5 % where the whole-row epilogue alone gains 0.9 %, profiles/r05_ln_from_producer_ab.txt)
         g.lno_y = nullptr;
         gs_dropped = true;  // reported like a dropped statistics request: FZ_GEMM_NO_STATS, y complete
     }

@@ -503,7 +503,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 
 def gemm_lnout(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ln, *, res: Optional[torch.Tensor] = None,
-               res2: Optional[torch.Tensor] = None, tile_cfg: int = 0):
+               res2: Optional[torch.Tensor] = None, tile_cfg: int = 0, split_k: int = 0):
     """y = x @ w^T + bias (+ res) (+ res2) as K.gemm, plus LN(y) out of the same launch where the library's launch for the shape holds whole rows
     (fz_gemm_lnout: 320 output channels on a 320-wide tile, no split-K); ln = (gamma, beta, eps) fp16.  Returns (y, y_ln) -- y_ln is None where
     the epilogue form does not apply (y is complete: run K.layernorm)."""
@@ -519,8 +519,8 @@ def gemm_lnout(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], l
     d = N.FzGemmDesc()
     d.rows, d.in_features, d.out_features = rows, k, o
     d.ldx, d.ldw, d.ldy, d.ldres = k, w.stride(0), o, o
-    d.batch, d.epilogue, d.tile_cfg = 1, N.FZ_GEMM_PLAIN, tile_cfg
-    want_ws = o % 4 == 0 and k >= 1024 and 2 * rows * o <= _WS_FLOATS
+    d.batch, d.epilogue, d.tile_cfg, d.split_k = 1, N.FZ_GEMM_PLAIN, tile_cfg, split_k
+    want_ws = o % 4 == 0 and (k >= 1024 or split_k > 1) and 2 * rows * o <= _WS_FLOATS
     if want_ws:
         d.workspace_floats = _WS_FLOATS
     rc = N.lib().fz_gemm_lnout(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(res), _ptr(res2), y.data_ptr(), gam.data_ptr(),

@@ -68,6 +68,8 @@ LN_FUSION_MAX_C = 640  # wider rows (K = 1280) want split-K in the consuming GEM
 # whose output is the next LayerNorm's input, and at the 320-channel level the 320-wide GEMM tile holds whole rows -- the epilogue computes
 # exact row statistics on the values it stores and writes LN(y) beside y: proj_in -> norm1, attn1.to_out -> norm2, attn2.to_out -> norm3,
 # ff.net[2] -> norm_temporal.  Four LayerNorm launches per 64x64-level block gone.  (env switch: same-box A/B runs of bench.py)
+# Only there: at 640 channels a row spans two column tiles, and handing the LayerNorm to the split-K tail kernel of the 1280-wide projections
+# (one wave per row) was built and measured a LOSS for the job (profiles/r05_ln_from_producer_ab.txt).
 LN_FROM_PRODUCER = os.environ.get("FZ_NO_LN_FROM_PRODUCER") is None
 LN_FROM_PRODUCER_C = 320
 

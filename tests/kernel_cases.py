@@ -566,11 +566,10 @@ def case_gemm_qkvt(device, *, n, l, k, c, tile_cfg=0, seed=0, ldx_extra=0):
             "vt_max_diff_vs_two_launches": float((vt.float() - vt2.float()).abs().max())}
 
 
-def case_gemm_lnout(device, *, rows, k, n_res=1, bias=True, seed=0, mean_shift=0.0, expect=True, tile_cfg=0):
+def case_gemm_lnout(device, *, rows, k, n_res=1, bias=True, seed=0, mean_shift=0.0, expect=True, tile_cfg=0, o=320, split_k=0):
     """fz_gemm_lnout: fz_gemm whose epilogue also writes LayerNorm(y) for whole-row (320-wide) tiles.  y must be BIT-IDENTICAL to fz_gemm's;
     y_ln vs fp32 torch LayerNorm of the stored fp16 y, and vs fz_layernorm on it (a few fp16 ulp: other summation order)."""
     g = torch.Generator().manual_seed(seed)
-    o = 320
     x = torch.randn(rows, k, generator=g).half().to(device)
     w = (torch.randn(o, k, generator=g) * k ** -0.5).half().to(device)
     b = ((torch.randn(o, generator=g) * 0.3) + mean_shift).half().to(device) if bias else None
@@ -578,8 +577,8 @@ def case_gemm_lnout(device, *, rows, k, n_res=1, bias=True, seed=0, mean_shift=0
     gamma = (1.0 + 0.2 * torch.randn(o, generator=g)).half().to(device)
     beta = (0.1 * torch.randn(o, generator=g)).half().to(device)
     kw = dict(res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None)
-    y0 = K.gemm(x, w, b, tile_cfg=tile_cfg, **kw)
-    y, yln = K.gemm_lnout(x, w, b, (gamma, beta, 1e-5), tile_cfg=tile_cfg, **kw)
+    y0 = K.gemm(x, w, b, tile_cfg=tile_cfg, split_k=split_k, **kw)
+    y, yln = K.gemm_lnout(x, w, b, (gamma, beta, 1e-5), tile_cfg=tile_cfg, split_k=split_k, **kw)
     assert torch.equal(y, y0), "the LayerNorm epilogue must not change what is stored"
     if yln is None:
         assert not expect, "this shape runs on a whole-row tile: the LayerNorm must come from the epilogue"

@@ -320,6 +320,7 @@ def test_layernorm_out_of_the_producing_gemm_epilogue():
     assert KC.case_gemm_lnout(DEV, rows=384, k=640, n_res=1, mean_shift=5.0, seed=2, tile_cfg=254218) is not None   # the ping-pong loop's tile
     assert KC.case_gemm_lnout(DEV, rows=100, k=64, n_res=1, seed=3, expect=False) is None     # the library picks a 64-wide tile: no LayerNorm from it
     assert KC.case_gemm_lnout(DEV, rows=256, k=64, n_res=1, seed=4, expect=False, tile_cfg=212222) is None
+    assert KC.case_gemm_lnout(DEV, rows=100, k=512, n_res=1, seed=5, tile_cfg=212222, split_k=4, expect=False) is None   # split-K: reports it
 
 
 def test_layernorm_plus_projection_in_one_launch():
