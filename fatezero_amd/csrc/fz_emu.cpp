@@ -374,7 +374,12 @@ static Pool* get_pool(int nthreads) {
     return p;
 }
 
+static std::atomic<int> g_null_launch{0};   // host-issue-time measurements: every launch returns at once (fz_emu_set_null_launch)
+static std::atomic<long> g_launch_count{0};
+
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+    g_launch_count.fetch_add(1);
+    if (g_null_launch.load()) return;
     const long total = (long)grid.x * grid.y * grid.z;
     unsigned hw = std::thread::hardware_concurrency();
     int nthreads = (int)(hw ? hw : 4);
@@ -406,4 +411,9 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 }
 
 }  // namespace fz_emu
+
+// Emulator-only switches (not part of include/fatezero_hip.h): with null launches on, every fz_* call does its host work and returns without
+// running the kernel -- what is left is the host's issue time; the counter counts kernel launches either way.
+extern "C" void fz_emu_set_null_launch(int on) { fz_emu::g_null_launch.store(on); }
+extern "C" long fz_emu_launch_count() { return fz_emu::g_launch_count.load(); }
 #endif  // FZ_EMU

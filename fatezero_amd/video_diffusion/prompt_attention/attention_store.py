@@ -13,9 +13,11 @@ Two entry points:
   * `__call__(attn, ...)`   -- the reference's tensor protocol, kept for drop-in use with foreign attention code.
 Differences, by design: the running sum `attention_store` (attention_store.py:95-101) is kept in fp32 and only for
 cross maps unless `accumulate_self=True` (its self-attention entries have no live consumer in the reference);
-`latents_store` stays on the device; `disk_store=True` is accepted and ignored (288 GB of HBM replace the disk).
+`latents_store` stays on the device; `disk_store=True` spills the steps that do not fit the HBM budget to pinned host memory (MapArena)
+instead of writing .pt files.
 """
 import abc
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -78,14 +80,38 @@ class AttentionControl(abc.ABC):
         return AttnPlan(0)
 
 
+SPILL_RING = 3  # HBM staging slabs of the spill tier: the step in use, the step being copied, one spare (a latent blend reads a neighbour)
+
+
+def _is_gpu(device):
+    return torch.device(device).type == "cuda"
+
+
+class SpilledStep:
+    """One step's maps in the host tier: `host` is the step's slab (pinned on a GPU box), `layout` = [(key, byte offset, storage shape, lk)]
+    in capture order; `slot` is the staging slab of the HBM ring that currently holds a copy (None: host only)."""
+    __slots__ = ("host", "layout", "slot")
+
+    def __init__(self, host, layout):
+        self.host, self.layout, self.slot = host, layout, None
+
+
 class MapArena:
     """HBM slabs for captured maps. The first step sizes the slab; later steps take one allocation each (or a
     single pre-reserved block when the number of steps is known).  Reserved blocks (tens of GB) are recycled
-    through a process-wide pool when their store dies, so a second job never pays hipMalloc/hipFree for them."""
+    through a process-wide pool when their store dies, so a second job never pays hipMalloc/hipFree for them.
+
+    Spill tier (`spill=True`: the store was built with the reference's `disk_store=True`, attention_store.py:103-108 / attention_util.py:115-116
+    -- there each step's maps go to a .pt file and come back with torch.load).  Here steps stay in HBM while they fit `hbm_budget`; the steps
+    beyond it are captured into a ring of SPILL_RING staging slabs and copied to (pinned) host memory on a copy stream behind the step that
+    wrote them, so the capture pass never waits for PCIe unless the ring wraps onto a copy still in flight.  `fetch(step)` brings a spilled
+    step back into a ring slab (copy stream, the compute stream waits on its event) and starts the copy of the step the consumer will ask
+    for next, so that an edit pass walks the spilled steps with one step of H2D always under the previous step's UNet forward."""
     _pool = []  # released reserved blocks (uint8 tensors), largest reuse wins
+    _host_pool = []  # released host slabs of the spill tier (pinning tens of GB is seconds: recycle)
 
     @classmethod
-    def _take(cls, nbytes, device):
+    def _take(cls, nbytes, device, hint="disk_store=True (spills the steps that do not fit to pinned host memory), "):
         best = None
         for i, t in enumerate(cls._pool):
             if t.device == torch.device(device) and t.numel() >= nbytes and (best is None or t.numel() < cls._pool[best].numel()):
@@ -98,16 +124,26 @@ class MapArena:
         except torch.OutOfMemoryError as e:  # e.g. 32 frames x 512^2 x 50 steps with index [-1, 'first']: 299 GB
             raise RuntimeError(
                 f"the attention-map arena of this job needs {nbytes / 1e9:.1f} GB of HBM in one block and does not fit on {device}: "
-                "the maps are kept on the device by design (the reference's host / disk store is not reproduced) -- use fewer frames or "
-                "DDIM steps, a one-frame SparseCausalAttention_index (e.g. ['mid'] halves the self-attention maps), "
-                "save_self_attention=False, or split the clip's frames over GPUs (fatezero_amd.dist.FrameShard)") from e
+                f"use {hint}fewer frames or DDIM steps, a one-frame SparseCausalAttention_index (e.g. ['mid'] halves the self-attention "
+                "maps), save_self_attention=False, or split the clip's frames over GPUs (fatezero_amd.dist.FrameShard)") from e
+
+    @classmethod
+    def _take_host(cls, nbytes, pinned):
+        for i, t in enumerate(cls._host_pool):
+            if t.numel() == nbytes and t.is_pinned() == pinned:
+                return cls._host_pool.pop(i)
+        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
 
     def release(self):
         if self.reserved is not None:
             MapArena._pool.append(self.reserved)
             self.reserved = None
+        if self.spilled:
+            self._drain_copies()
+            MapArena._host_pool = [sp.host for sp in self.spilled.values()]  # (only the latest job's: a pool, not a second arena)
+        self.spilled, self.ring, self.ring_step = {}, [], []
 
-    def __init__(self):
+    def __init__(self, spill=False, hbm_budget=None):
         self.step_bytes = 0
         self.cur = None
         self.cur_off = 0
@@ -115,12 +151,62 @@ class MapArena:
         self.reserved_off = 0
         self.first_step_done = False
         self.total_bytes = 0
+        # spill tier
+        self.spill = spill
+        self.hbm_budget = hbm_budget      # bytes of HBM this arena may hold (None: what the device has free when the block is reserved)
+        self.step = 0                     # index of the step being captured
+        self.spilled = {}                 # step -> SpilledStep
+        self.spilled_bytes = 0
+        self.ring = []                    # SPILL_RING staging slabs (uint8 [step_bytes]), allocated with the first spilled step
+        self.ring_step = []               # the step whose maps each slab holds (None: free)
+        self.ring_event = []              # copy-stream event after which the slab's content / the host copy of it is complete
+        self.ring_clock = []              # last use, for the least-recently-used choice
+        self._clock = 0
+        self._cur_slot = None             # ring slot the step being captured writes to (None: resident)
+        self._copy_stream = None
+        self._last_fetch = None
+        self.fetch_stats = {"h2d": 0, "hits": 0}
+
+    # -- residency --------------------------------------------------------------------------------------
+    def _budget(self, device):
+        if self.hbm_budget is not None:
+            return int(self.hbm_budget)
+        env = os.environ.get("FZ_ARENA_HBM_GB")
+        if env:
+            return int(float(env) * 1e9)
+        if not _is_gpu(device):
+            return None
+        free, _ = torch.cuda.mem_get_info(device)
+        recyclable = sum(t.numel() for t in MapArena._pool if t.device == torch.device(device))
+        return self.total_bytes + int(0.9 * (free + recyclable))
 
     def reserve(self, n_steps, device):
         if self.first_step_done and self.step_bytes and n_steps > 0 and self.reserved is None:
-            self.reserved = MapArena._take(self.step_bytes * n_steps, device)
+            if self.spill:
+                budget = self._budget(device)
+                if budget is not None:
+                    n_steps = max(0, min(n_steps, (budget - self.total_bytes - SPILL_RING * self.step_bytes) // self.step_bytes))
+                    if n_steps == 0:
+                        return
+            self.reserved = MapArena._take(self.step_bytes * n_steps, device, hint="" if self.spill else
+                                           "disk_store=True (spills the steps that do not fit to pinned host memory), ")
             self.reserved_off = 0
             self.total_bytes += self.step_bytes * n_steps
+
+    def _resident_slab(self, nbytes, device):
+        """The HBM slab of the next step, or None when the step goes to the spill tier."""
+        if self.reserved is not None and self.reserved_off + self.step_bytes <= self.reserved.numel():
+            slab = self.reserved[self.reserved_off: self.reserved_off + self.step_bytes]
+            self.reserved_off += self.step_bytes
+            return slab
+        want = max(self.step_bytes, nbytes)
+        if self.spill:  # (a block reserved for the known number of steps was sized to the budget: what comes after it lands here as well)
+            budget = self._budget(device)
+            if budget is not None and self.total_bytes + want + (0 if self.ring else SPILL_RING * self.step_bytes) > budget:
+                return None
+        slab = torch.empty(want, dtype=torch.uint8, device=device)
+        self.total_bytes += want
+        return slab
 
     def alloc(self, shape, device):
         nbytes = 2
@@ -132,21 +218,117 @@ class MapArena:
             self.total_bytes += nbytes
             return torch.empty(shape, dtype=torch.float16, device=device)
         if self.cur is None or self.cur_off + nbytes > self.cur.numel():
-            if self.reserved is not None and self.reserved_off + self.step_bytes <= self.reserved.numel():
-                self.cur = self.reserved[self.reserved_off: self.reserved_off + self.step_bytes]
-                self.reserved_off += self.step_bytes
-            else:
-                self.cur = torch.empty(max(self.step_bytes, nbytes), dtype=torch.uint8, device=device)
-                self.total_bytes += self.cur.numel()
+            self.cur = self._resident_slab(nbytes, device)
+            self._cur_slot = None
+            if self.cur is None:
+                if nbytes > self.step_bytes:
+                    raise RuntimeError("spill tier: a step larger than the first one cannot be staged (the capture layout changed between steps)")
+                self._cur_slot = self._claim_slot(device, for_step=self.step)
+                self.cur = self.ring[self._cur_slot]
             self.cur_off = 0
         out = self.cur[self.cur_off: self.cur_off + 2 * _numel(shape)].view(torch.float16).view(shape)
         self.cur_off += nbytes
         return out
 
     def end_step(self):
+        """Close the step being captured.  Returns the ring slab of a step that goes to the host tier (the caller describes its layout with
+        `spill_step`) or None for a resident step."""
+        slab = self.ring[self._cur_slot] if self._cur_slot is not None else None
         self.first_step_done = True
         self.cur = None
         self.cur_off = 0
+        if slab is None:
+            self.step += 1
+        return slab
+
+    # -- spill tier -------------------------------------------------------------------------------------
+    def _streams(self, device):
+        if not _is_gpu(device):
+            return None, None
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=device)
+        return torch.cuda.current_stream(device), self._copy_stream
+
+    def _drain_copies(self):
+        if self._copy_stream is not None:
+            self._copy_stream.synchronize()
+
+    def _claim_slot(self, device, for_step, keep=()):
+        """A ring slab for `for_step`: the least recently used one outside `keep`.  The compute stream is made to wait for the copy that last
+        touched it (the D2H of the step captured into it, or an H2D prefetch), and whatever the compute stream has queued on it so far is
+        ordered in front of the next copy into it by an event the caller records (`_copy_in`)."""
+        if not self.ring:
+            self.ring = [torch.empty(self.step_bytes, dtype=torch.uint8, device=device) for _ in range(SPILL_RING)]
+            self.total_bytes += SPILL_RING * self.step_bytes
+            self.ring_step, self.ring_event, self.ring_clock = [None] * SPILL_RING, [None] * SPILL_RING, [0] * SPILL_RING
+        slot = min((j for j in range(SPILL_RING) if j not in keep), key=lambda j: self.ring_clock[j])
+        old = self.ring_step[slot]
+        if old is not None and old in self.spilled:
+            self.spilled[old].slot = None
+        compute, _ = self._streams(device)
+        if compute is not None and self.ring_event[slot] is not None:
+            compute.wait_event(self.ring_event[slot])
+        self.ring_step[slot] = for_step
+        self._clock += 1
+        self.ring_clock[slot] = self._clock
+        return slot
+
+    def spill_step(self, layout, device):
+        """The step just closed was captured into a ring slab: queue its copy to the host tier behind the kernels that wrote it."""
+        slot, step = self._cur_slot, self.step
+        pinned = _is_gpu(device)
+        sp = SpilledStep(MapArena._take_host(self.step_bytes, pinned), layout)
+        compute, copy = self._streams(device)
+        if copy is None:
+            sp.host.copy_(self.ring[slot])
+        else:
+            copy.wait_event(compute.record_event())
+            with torch.cuda.stream(copy):
+                sp.host.copy_(self.ring[slot], non_blocking=True)
+                self.ring_event[slot] = copy.record_event()
+        sp.slot = slot  # the slab still holds the step until it is claimed again
+        self.spilled[step] = sp
+        self.spilled_bytes += self.step_bytes
+        self._cur_slot = None
+        self.step += 1
+        return sp
+
+    def _copy_in(self, step, slot, device):
+        sp = self.spilled[step]
+        compute, copy = self._streams(device)
+        if copy is None:
+            self.ring[slot].copy_(sp.host)
+        else:
+            copy.wait_event(compute.record_event())  # the slab's previous readers are queued in front of this point
+            with torch.cuda.stream(copy):
+                self.ring[slot].copy_(sp.host, non_blocking=True)
+                self.ring_event[slot] = copy.record_event()
+        sp.slot = slot
+        self.fetch_stats["h2d"] += 1
+
+    def fetch(self, step, device):
+        """The ring slab that holds spilled `step`, valid for everything queued on the compute stream from here on; starts the copy of the
+        step the caller is walking towards."""
+        sp = self.spilled[step]
+        if sp.slot is None:
+            self._copy_in(step, self._claim_slot(device, for_step=step), device)
+            compute, _ = self._streams(device)
+            if compute is not None:
+                compute.wait_event(self.ring_event[sp.slot])
+        elif self._last_fetch != step:
+            self.fetch_stats["hits"] += 1
+            compute, _ = self._streams(device)
+            if compute is not None and self.ring_event[sp.slot] is not None:
+                compute.wait_event(self.ring_event[sp.slot])
+        self._clock += 1
+        self.ring_clock[sp.slot] = self._clock
+        if self._last_fetch != step:
+            direction = -1 if self._last_fetch is None or step < self._last_fetch else 1
+            nxt = step + direction
+            if nxt in self.spilled and self.spilled[nxt].slot is None:
+                self._copy_in(nxt, self._claim_slot(device, for_step=nxt, keep=(sp.slot,)), device)
+            self._last_fetch = step
+        return self.ring[sp.slot]
 
 
 def _numel(shape):
@@ -167,13 +349,14 @@ class CapturedMap:
 
 
 class AttentionStore(AttentionControl):
-    def __init__(self, save_self_attention: bool = True, disk_store=False, accumulate_self: bool = False):
+    def __init__(self, save_self_attention: bool = True, disk_store=False, accumulate_self: bool = False, hbm_budget_bytes=None):
         super().__init__()
-        self.disk_store = disk_store  # accepted for API compatibility; maps stay in HBM
-        if disk_store:
-            import warnings
-            warnings.warn("disk_store=True: this build keeps the attention maps in the HBM arena (74.7 GB for 8 frames x 50 steps "
-                          "of the 288 GB); nothing is written to `store_dir`", stacklevel=2)
+        # The reference's disk_store=True writes every step's maps to ./trash/attention_cache_*/NNN.pt and loads them back in the edit
+        # (attention_store.py:103-108, attention_util.py:115-116).  Here it switches the arena's spill tier on: steps stay in HBM while they
+        # fit (`hbm_budget_bytes`, or FZ_ARENA_HBM_GB, or 90 % of what the device has free), the rest goes to pinned host memory behind the
+        # capture and comes back one step ahead of the edit (MapArena).  Nothing is written to disk; `store_dir` stays None.
+        self.disk_store = disk_store
+        self.hbm_budget_bytes = hbm_budget_bytes
         self.store_dir = None
         self.save_self_attention = save_self_attention
         self.accumulate_self = accumulate_self
@@ -188,7 +371,8 @@ class AttentionStore(AttentionControl):
         self._step_maps = {k: [] for k in KEYS}       # CapturedMap objects of the current step
         self._all_step_maps: List[Dict[str, List[CapturedMap]]] = []
         self._sum_storage: Dict[str, List[torch.Tensor]] = {}
-        self.arena = MapArena()
+        self.arena = MapArena(spill=bool(self.disk_store), hbm_budget=self.hbm_budget_bytes)
+        self._fetched = (None, None)  # (step, its maps in the ring slab) of the latest spilled step handed out
 
     @staticmethod
     def get_empty_store():
@@ -204,6 +388,7 @@ class AttentionStore(AttentionControl):
 
     def new_slot(self, key, frames, heads, lq, lk, is_cross, device) -> CapturedMap:
         width = K.CROSS_P_STRIDE if is_cross else lk
+        self._device = device
         cm = CapturedMap(self.arena.alloc((frames, heads, lq, width), device), lk)
         self._step_maps[key].append(cm)
         self.step_store[key].append(cm.view)
@@ -247,7 +432,9 @@ class AttentionStore(AttentionControl):
         self.step_store = self.get_empty_store()
         self._step_maps = {k: [] for k in KEYS}
         first = not self.arena.first_step_done
-        self.arena.end_step()
+        slab = self.arena.end_step()
+        if slab is not None:
+            self._spill_last_step(slab)
         if first and self.expected_steps and self.latents_store is not None:
             dev = None
             for k in KEYS:
@@ -262,8 +449,37 @@ class AttentionStore(AttentionControl):
         self.latents_store.append(x_t.detach().clone())
         return x_t
 
+    def _spill_last_step(self, slab):
+        """The step just appended was captured into a staging slab of the spill tier: describe its layout, queue the copy to the host
+        tier, and hand the reference-shaped views of `attention_store_all_step` over to the host copy (the reference keeps a file path
+        there; its 32 x 32 maps are host tensors even without disk_store, attention_store.py:86-87)."""
+        step = len(self._all_step_maps) - 1
+        maps, layout, base = self._all_step_maps[step], [], slab.data_ptr()
+        for k in KEYS:
+            for cm in maps[k]:
+                layout.append((k, cm.storage.data_ptr() - base, tuple(cm.storage.shape), cm.view.shape[-1]))
+        sp = self.arena.spill_step(layout, slab.device)
+        self.attention_store_all_step[step] = {k: [cm.view for cm in v] for k, v in self._maps_over(sp.host, layout).items()}
+        self._all_step_maps[step] = None  # resolved through the arena from here on (maps_of_step)
+
+    @staticmethod
+    def _maps_over(slab, layout):
+        out = {k: [] for k in KEYS}
+        for k, off, shape, lk in layout:
+            out[k].append(CapturedMap(slab[off: off + 2 * _numel(shape)].view(torch.float16).view(shape), lk))
+        return out
+
     def maps_of_step(self, step_in_store) -> Dict[str, List[CapturedMap]]:
-        return self._all_step_maps[step_in_store]
+        if step_in_store < 0:
+            step_in_store += len(self._all_step_maps)
+        maps = self._all_step_maps[step_in_store]
+        if maps is not None:
+            return maps
+        if self._fetched[0] != step_in_store:  # a spilled step: into a staging slab of the ring, the next one behind it
+            sp = self.arena.spilled[step_in_store]
+            slab = self.arena.fetch(step_in_store, self._device)
+            self._fetched = (step_in_store, self._maps_over(slab, sp.layout))
+        return self._fetched[1]
 
     def get_average_attention(self):
         return {key: [item / self.cur_step for item in self.attention_store[key]] for key in self.attention_store}
@@ -289,7 +505,8 @@ class AttentionStore(AttentionControl):
             arena.release()
             # tensors handed out earlier (attention_store_all_step views, CapturedMap.storage) alias the released block and are
             # invalid from here on; a store that is used again reserves a fresh arena instead of allocating per step
-            self.arena = type(arena)()
+            self.arena = type(arena)(spill=arena.spill, hbm_budget=arena.hbm_budget)
+            self._fetched = (None, None)
 
     def __del__(self):
         try:

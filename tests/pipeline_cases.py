@@ -105,14 +105,16 @@ def check_mask_dumps(save_path, ctrl):
     return n_checked
 
 
-def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_path=None):
+def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_path=None, disk_store=False):
+    """`disk_store=True`: the reference's switch of the same name (attention_store.py:103-108) -- here the arena's spill tier; the budget
+    comes from FZ_ARENA_HBM_GB (the tests set 0: every step behind the first goes through the staging ring to the host tier and back)."""
     meta = load_json("pipeline_meta.json")[name]
     consts = load_json("host_constants.json")[meta["prompt_case"]]
     gz = load_npz(name + ".npz")
     unet = build_unet("tiny16", meta["model_config"], device)
     T = meta["T"]
     pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=ReplayTokenizer(), unet=unet,
-                                         scheduler=DDIMScheduler())
+                                         scheduler=DDIMScheduler(), disk_store=disk_store)
     pipe.set_progress_bar_config(disable=True)
     pipe.scheduler.set_timesteps(T)
     assert [int(t) for t in pipe.scheduler.timesteps] == meta["timesteps"]
@@ -139,6 +141,8 @@ def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_
     kw.pop("save_path", None)
     if save_path is not None:
         kw["save_path"] = save_path
+    if disk_store:
+        kw["disk_store"] = True
     pipe._encode_prompt = lambda *a, **k: emb_tgt
     # start the edit from the reference's own inverted latent so that the two halves are checked independently
     out = pipe(latents=zT_ref.to(device), output_type="latent", **kw)
@@ -146,6 +150,8 @@ def run_pipeline_case(name, device, return_pipe=False, mixed_oracle=False, save_
     ref = torch.from_numpy(gz["edited"])
     res["edit_err"] = float((edited - ref).abs().max())
     res["edit_scale"] = float(ref.abs().max())
+    if return_pipe:
+        pipe.last_edited_latents = edited
     # robust view of the same comparison: a blend mask is a hard threshold, so ONE pixel whose normalised score sits within
     # fp16 noise of the threshold flips and moves that latent pixel by |x - inverted| (order of the latent scale itself)
     res["edit_err_q99"] = float(torch.quantile((edited - ref).abs().flatten(), 0.99))
@@ -510,6 +516,32 @@ def run_drift_case(device, T=50, F=2, L=32, marks=(10, 25, 50), seed=5):
          is_replace_controller=True, save_self_attention=False, guidance_scale=7.5, callback=cb, callback_steps=1)
     res["edit"] = {m: float((got[m] - trace[m]).abs().max()) / float(trace[m].abs().max()) for m in marks}
     return res
+
+
+def run_spill_case(device, disk_store, T=20, F=4, L=64, seed=9):
+    """A T-step capture inversion + Replace edit with attention blend at tiny16 width, native pipeline only: what a run with the arena's spill
+    tier on (disk_store=True) must reproduce bit for bit.  Returns (inverted latent, edited latent, per-step sums of the captured maps,
+    the store's arena)."""
+    unet = build_unet("tiny16", {"lora": 16}, device)
+    tok = ReplayTokenizer()
+    pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=tok, unet=unet, scheduler=DDIMScheduler(),
+                                         disk_store=disk_store)
+    pipe.set_progress_bar_config(disable=True)
+    pipe.scheduler.set_timesteps(T)
+    g = torch.Generator().manual_seed(seed)
+    z0 = torch.randn(1, 4, F, L, L, generator=g)
+    emb_src = torch.randn(2, 77, 64, generator=g) * 0.5
+    emb_tgt = emb_src + 0.25 * torch.randn(2, 77, 64, generator=g)
+    lat = pipe.prepare_latents_ddim_inverted(image=None, batch_size=1, num_images_per_prompt=1, text_embeddings=emb_src.to(device),
+                                             store_attention=True, LOW_RESOURCE=True, latents=z0.to(device))
+    pipe._encode_prompt = lambda *a, **k: emb_tgt.to(device)
+    out = pipe(latents=lat[-1], edit_type="swap", output_type="latent", prompt=FULL_TGT, source_prompt=FULL_SRC, num_inference_steps=T,
+               cross_replace_steps={"default_": 0.6}, self_replace_steps=0.7, use_inversion_attention=True, is_replace_controller=True,
+               blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[0.55, 0.55], blend_self_attention=True, save_self_attention=True, guidance_scale=7.5,
+               disk_store=disk_store)
+    store = pipe.store_controller
+    sums = [[float(m.float().sum()) for k in sorted(st) for m in st[k]] for st in store.attention_store_all_step]
+    return lat[-1].float().cpu(), out["sdimage_output"].images.float().cpu(), sums, store.arena
 
 
 DRIFT_TOL = {"inv": 4e-3, "edit": 1.5e-2}   # measured at steps 10 / 25 / 50: inversion 0.03 / 0.06 / 0.15 %, edit 0.67 / 0.89 / 0.82 %

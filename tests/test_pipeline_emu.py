@@ -2,6 +2,7 @@
 emulation backend against the unmodified reference's outputs -- small-latent scenarios only (the 64x64-latent blend
 scenarios run on the MI355X, tests/test_pipeline_gpu.py)."""
 import pytest
+import torch
 
 from fatezero_amd import _native, build
 
@@ -20,6 +21,32 @@ def emu_backend():
 def test_pipeline_small(name):
     res = PC.run_pipeline_case(name, "cpu")
     print(name, res)
+    PC.check(res)
+
+
+@pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_f3_mid_next"])
+def test_disk_store_spill_tier_is_bit_identical(name, monkeypatch):
+    """disk_store=True (attention_store.py:103-108: a .pt file per step in the reference) with an HBM budget of 0: every step behind the first
+    is captured into the 2-slab staging ring, copied to the host tier, and comes back for the edit -- one still in its slab, the others by
+    the H2D path with the next step prefetched.  Same kernels on the same bytes: the whole job must reproduce the resident run bit for bit."""
+    from fatezero_amd.video_diffusion.prompt_attention import attention_store as AS
+    base, pipe0 = PC.run_pipeline_case(name, "cpu", return_pipe=True)
+    maps0 = [{k: [m.clone() for m in v] for k, v in st.items()} for st in pipe0.store_controller.attention_store_all_step]
+    edited0 = pipe0.last_edited_latents
+    monkeypatch.setenv("FZ_ARENA_HBM_GB", "0")
+    monkeypatch.setattr(AS, "SPILL_RING", 2)
+    res, pipe = PC.run_pipeline_case(name, "cpu", return_pipe=True, disk_store=True)
+    store = pipe.store_controller
+    T = len(store.attention_store_all_step)
+    assert sorted(store.arena.spilled) == list(range(1, T)), (sorted(store.arena.spilled), T)   # the first step sizes the slab: resident
+    assert store.arena.fetch_stats["h2d"] >= T - 3 and store.arena.fetch_stats["hits"] >= 1, store.arena.fetch_stats
+    assert torch.equal(pipe.last_edited_latents, edited0)
+    assert res == base, (res, base)
+    for s, (st, st0) in enumerate(zip(store.attention_store_all_step, maps0)):   # the reference-shaped views: host copies of the spilled steps
+        for k in st0:
+            assert len(st[k]) == len(st0[k])
+            for a, b in zip(st[k], st0[k]):
+                assert torch.equal(a.cpu(), b.cpu()), (s, k)
     PC.check(res)
 
 

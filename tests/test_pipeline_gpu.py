@@ -1,5 +1,6 @@
 """MI355X end-to-end parity: native pipeline (HIP kernels through the C ABI) vs vectors from the unmodified reference."""
 import pytest
+import torch
 
 from fatezero_amd import _native
 
@@ -134,6 +135,22 @@ def test_unet_vs_reference_golden(name):
     r = PC.run_unet_golden(name, "cuda")
     print(name, r)
     assert r["err"] <= 1.5e-2 * r["scale"], r
+
+
+def test_disk_store_spill_tier_is_bit_identical_gpu(monkeypatch):
+    """disk_store=True (attention_store.py:103-108) with an HBM budget of 0 on the real device: 19 of 20 steps go through the staging ring to
+    pinned host memory on the copy stream and come back one step ahead of the edit -- against the resident run, bit for bit (a missing
+    stream dependency between the copies and the kernels would show here, not on the emulator)."""
+    inv0, ed0, sums0, arena0 = PC.run_spill_case("cuda", disk_store=False)
+    assert not arena0.spilled
+    monkeypatch.setenv("FZ_ARENA_HBM_GB", "0")
+    inv, ed, sums, arena = PC.run_spill_case("cuda", disk_store=True)
+    print("spill tier:", len(arena.spilled), "of", len(sums), "steps in the host tier,", arena.spilled_bytes, "bytes;", arena.fetch_stats)
+    assert sorted(arena.spilled) == list(range(1, len(sums)))
+    assert arena.fetch_stats["h2d"] >= len(sums) - 4
+    assert all(sp.host.is_pinned() for sp in arena.spilled.values())
+    assert torch.equal(inv, inv0) and torch.equal(ed, ed0)
+    assert sums == sums0
 
 
 def test_drift_50_steps():
