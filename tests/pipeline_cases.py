@@ -521,7 +521,7 @@ def run_drift_case(device, T=50, F=2, L=32, marks=(10, 25, 50), seed=5):
 def run_spill_case(device, disk_store, T=20, F=4, L=64, seed=9):
     """A T-step capture inversion + Replace edit with attention blend at tiny16 width, native pipeline only: what a run with the arena's spill
     tier on (disk_store=True) must reproduce bit for bit.  Returns (inverted latent, edited latent, per-step sums of the captured maps,
-    the store's arena)."""
+    a summary of the store's arena)."""
     unet = build_unet("tiny16", {"lora": 16}, device)
     tok = ReplayTokenizer()
     pipe = P2pDDIMSpatioTemporalPipeline(vae=None, text_encoder=None, tokenizer=tok, unet=unet, scheduler=DDIMScheduler(),
@@ -540,8 +540,11 @@ def run_spill_case(device, disk_store, T=20, F=4, L=64, seed=9):
                blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[0.55, 0.55], blend_self_attention=True, save_self_attention=True, guidance_scale=7.5,
                disk_store=disk_store)
     store = pipe.store_controller
-    sums = [[float(m.float().sum()) for k in sorted(st) for m in st[k]] for st in store.attention_store_all_step]
-    return lat[-1].float().cpu(), out["sdimage_output"].images.float().cpu(), sums, store.arena
+    sums = [[float(m.cpu().double().sum()) for k in sorted(st) for m in st[k]] for st in store.attention_store_all_step]   # (on one device: same order)
+    arena = store.arena   # (a snapshot: the store releases its arena when it is collected)
+    info = {"spilled": sorted(arena.spilled), "spilled_bytes": arena.spilled_bytes, "fetch_stats": dict(arena.fetch_stats),
+            "pinned": [sp.host.is_pinned() for sp in arena.spilled.values()], "hbm_bytes": arena.total_bytes}
+    return lat[-1].float().cpu(), out["sdimage_output"].images.float().cpu(), sums, info
 
 
 DRIFT_TOL = {"inv": 4e-3, "edit": 1.5e-2}   # measured at steps 10 / 25 / 50: inversion 0.03 / 0.06 / 0.15 %, edit 0.67 / 0.89 / 0.82 %
