@@ -117,6 +117,13 @@ _SIGS = {
     "fz_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "fz_peer_put": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int, C.c_uint32, _P, _P]),
     "fz_peer_wait": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_int64, _P]),
+    "fz_plan_begin": (C.c_int, [C.POINTER(_P)]),
+    "fz_plan_pause": (C.c_int, [_P, C.c_int]),
+    "fz_plan_end": (C.c_int, [_P]),
+    "fz_plan_launches": (C.c_int64, [_P]),
+    "fz_plan_relocate": (C.c_int64, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
+    "fz_plan_replay": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
+    "fz_plan_destroy": (None, [_P]),
     "fz_version": (C.c_char_p, []),
 }
 

@@ -38,10 +38,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef hipStream_t fz_stream_t;
 
-#define FZ_LAUNCH(kernel, grid, block, smem, stream, ...)                                    \
-    do {                                                                                     \
-        hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__);   \
-    } while (0)
+// every kernel of the library is launched through fz_plan::launch (bottom of this file): the launch itself, or -- while a native issue
+// plan is being recorded (fz_plan_begin, csrc/plan.hip) -- the launch AND a record of it that fz_plan_replay re-issues later
+#define FZ_RAW_LAUNCH(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#define FZ_LAUNCH(kernel, grid, block, smem, stream, ...) fz_plan::launch(kernel, grid, block, smem, (void*)(stream), __VA_ARGS__)
 
 static inline int fz_last_launch_status() { return hipGetLastError() == hipSuccess ? FZ_OK : FZ_ERR_LAUNCH; }
 
@@ -178,8 +178,8 @@ f32x4 mfma_16x16x32_f16(half8_t a, half8_t b, f32x4 c);
 #define __launch_bounds__(...)
 #define __restrict__
 
-#define FZ_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    fz_emu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+#define FZ_RAW_LAUNCH(kernel, grid, block, smem, stream, ...) fz_emu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+#define FZ_LAUNCH(kernel, grid, block, smem, stream, ...) fz_plan::launch(kernel, grid, block, smem, (void*)(stream), __VA_ARGS__)
 
 static inline int fz_last_launch_status() { return FZ_OK; }
 static inline void __syncthreads() { fz_emu::sync_block(); }
@@ -358,3 +358,84 @@ FZ_DEVICE f32x2 fz_exp2_poly2(f32x2 x) {
 
 static inline int fz_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int fz_round_up(int a, int b) { return fz_ceil_div(a, b) * b; }
+
+// ============================================================================================
+//                     native issue plans: record a launch list once, re-issue it later
+// ============================================================================================
+// One UNet forward is ~520-700 launches whose grid, arguments and order are a pure function of (clip geometry, controller plan); Python
+// decides them again at every DDIM step.  A plan is that decision taken once: while fz_plan_begin ... fz_plan_end brackets a forward, every
+// launch of the library is issued as usual AND appended to the plan -- kernel, grid, block, LDS bytes and a byte copy of the kernel
+// arguments -- and fz_plan_replay re-issues a range of the records with one call.  What changes from step to step is data behind pointers
+// (latents, the timestep embedding, the step's map slabs, masks): fz_plan_relocate rewrites every pointer-sized argument word of a record
+// range that points into [old, old + bytes) to the same offset from `new_base`.  (csrc/plan.hip; host side: fatezero_amd/issue.py)
+#include <string.h>
+#include <vector>
+
+namespace fz_plan {
+
+struct Record {
+    void (*run)(const Record&, const unsigned char* args, void* stream);
+    const void* kernel;
+    dim3 grid, block;
+    size_t smem;
+    uint32_t arg_off, arg_len;   // this record's argument bytes in Plan::args (arg_off is a multiple of 16)
+};
+
+struct Plan {
+    std::vector<Record> recs;
+    std::vector<uint64_t> args;   // (uint64_t: the relocation pass walks pointer-sized, pointer-aligned words)
+};
+
+extern Plan* g_recording;   // the plan being recorded by this process (nullptr: none) -- ONE issuing thread, as the host layer has
+
+// the arguments of one launch as an aggregate of the kernel's own parameter types: trivially copyable, pointers at their natural alignment
+template <typename... P> struct Args;
+template <> struct Args<> {};
+template <typename H, typename... T> struct Args<H, T...> {
+    H head;
+    Args<T...> tail;
+};
+template <typename... T> struct Packer;
+template <> struct Packer<> {
+    static Args<> make() { return Args<>{}; }
+};
+template <typename H, typename... T> struct Packer<H, T...> {
+    template <typename A0, typename... AR> static Args<H, T...> make(A0&& a0, AR&&... ar) {
+        return Args<H, T...>{(H)a0, Packer<T...>::make(ar...)};
+    }
+};
+template <typename F, typename... Done> inline void unpack(F&& f, const Args<>&, const Done&... d) { f(d...); }
+template <typename F, typename H, typename... T, typename... Done> inline void unpack(F&& f, const Args<H, T...>& a, const Done&... d) {
+    unpack(f, a.tail, d..., a.head);
+}
+
+template <typename... P> struct Thunk {
+    static void run(const Record& r, const unsigned char* args, void* stream) {
+        Args<P...> a;
+        memcpy(&a, args + r.arg_off, sizeof(a));
+        void (*k)(P...) = (void (*)(P...))r.kernel;
+        const dim3 grid = r.grid, block = r.block;
+        const size_t smem = r.smem;
+        unpack([&](const P&... p) { FZ_RAW_LAUNCH(k, grid, block, smem, stream, p...); }, a);
+    }
+};
+
+template <typename... P, typename... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t smem, void* stream, A&&... a) {
+    if (g_recording != nullptr) {
+        Plan& pl = *g_recording;
+        const Args<P...> packed = Packer<P...>::make(a...);
+        Record r;
+        r.run = &Thunk<P...>::run;
+        r.kernel = (const void*)kernel;
+        r.grid = grid; r.block = block; r.smem = smem;
+        r.arg_off = (uint32_t)(pl.args.size() * 8);
+        r.arg_len = (uint32_t)sizeof(packed);
+        pl.args.resize(pl.args.size() + (sizeof(packed) + 15) / 16 * 2, 0);
+        memcpy((unsigned char*)pl.args.data() + r.arg_off, &packed, sizeof(packed));
+        pl.recs.push_back(r);
+    }
+    FZ_RAW_LAUNCH(kernel, grid, block, smem, stream, a...);
+}
+
+}  // namespace fz_plan

@@ -1,0 +1,298 @@
+"""Native issue path for the UNet forward: the launch list recorded once, replayed from native code at the following DDIM steps.
+
+The reference issues `self.unet(latent_model_input, t, encoder_hidden_states=...)` (p2p_ddim_spatial_temporal.py:286,
+stable_diffusion.py:360-372) by walking the module tree in Python at every one of the 50 + 50 steps of a job.  The walk decides ~520-700
+kernel launches (descriptors, grids, pointers) that are a pure function of (clip geometry, text context, controller kind): only data behind
+pointers differs between steps.  `IssuePlans.run` therefore
+
+  1. lets the FIRST forward of a kind run through Python untouched (weight packs, the text context's K / V^T, scratch buffers get cached);
+  2. RECORDS the second one (`fz_plan_begin` ... `fz_plan_end`, csrc/plan.hip): the forward runs as usual and every launch the library
+     makes is appended to a native plan.  What the attention CONTROLLER does stays live: each `controller.attention_plan(...)` call of the
+     walk becomes an *event* -- recording is paused around it (its own launches, e.g. the blend-mask kernels, are issued by the controller at
+     every replay) and the tensors of the `AttnPlan` it returns are remembered with the index of the first launch that may use them;
+  3. REPLAYS from the third forward on: the records between two events are re-issued by ONE native call each (`fz_plan_replay`), the
+     controller is asked for the step's plan at each event exactly as the walk would (its counters, arena slots and masks advance as in the
+     reference protocol), and where the step's tensors live elsewhere than the recorded ones -- the step's slab of the map arena, the
+     per-step cross-attention coefficients, a fresh mask -- the pointers of that layer's records are rewritten (`fz_plan_relocate`).
+     The forward's inputs (latent tokens, timestep embedding) are relocated the same way.
+
+Every buffer the records point into was allocated by the recorded forward.  On the GPU those allocations come from a private
+`torch.cuda.MemPool` shared by all plans of a process (blocks freed during the forward are reused inside it exactly as the recording saw,
+and never handed to anyone else); without one (the CPU emulation backend of the tests) the plan keeps every allocation of its forward alive.
+A torch *compute* op inside the recorded part of the forward would not be re-issued by a replay: a dispatch mode watches the recording and
+such a forward is never replayed (`IssuePlans.stats["unrecordable"]` says which op).
+
+Scope: one process, one GPU, the built-in controllers (`issue_signature()`); a frame-sharded forward (fatezero_amd.dist) and foreign
+controllers run the Python walk as before.  Off by default: `UNetPseudo3DConditionModel.enable_issue_plans()` / FZ_ISSUE_PLANS=1.
+"""
+import ctypes as C
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from . import _native as N
+from . import kernels as K
+
+_TENSOR_FIELDS = ("p", "row_mask", "mapper_t", "coef", "cur_out", "capture_first")
+
+# aten ops a recorded forward may run between its launches: allocation and metadata only
+_ALLOC_OPS = {"aten.empty.memory_format", "aten.empty_like.default", "aten.empty_strided.default", "aten.new_empty.default",
+              "aten.new_empty_strided.default"}
+_VIEW_OPS = {"aten.view.default", "aten._unsafe_view.default", "aten.reshape.default", "aten._reshape_alias.default", "aten.as_strided.default",
+             "aten.slice.Tensor", "aten.select.int", "aten.permute.default", "aten.transpose.int", "aten.t.default", "aten.expand.default",
+             "aten.unsqueeze.default", "aten.squeeze.dim", "aten.squeeze.default", "aten.detach.default", "aten.alias.default",
+             "aten.split.Tensor", "aten.split_with_sizes.default", "aten.unbind.int", "aten.narrow.default", "aten.unflatten.int",
+             "aten.flatten.using_ints", "aten.chunk.default", "aten.view_as.default", "aten.lift_fresh.default", "aten.unfold.default",
+             "aten.movedim.int"}
+
+
+class _Watch(TorchDispatchMode):
+    """Sees every aten op of the recorded forward: keeps allocations alive where no private pool does, names compute ops."""
+
+    def __init__(self, rec):
+        super().__init__()
+        self.rec = rec
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        rec = self.rec
+        if rec.live == 0:
+            name = str(func)
+            if name in _ALLOC_OPS:
+                if rec.keep is not None:
+                    rec.keep.append(out)
+            elif name not in _VIEW_OPS:
+                rec.foreign.append(name)  # a compute op (or a host read) of torch's own: a replay would not repeat it
+        return out
+
+
+class _Event:
+    """One `controller.attention_plan(...)` call of the walk: its arguments, what it returned at recording time, and the records
+    [first, first + count) issued between it and the next event (the only ones that can use the tensors it returned)."""
+    __slots__ = ("args", "first", "count", "n_plain", "mode", "fields")
+
+    def __init__(self, args, first, plan):
+        self.args, self.first, self.count = args, first, 0
+        self.n_plain, self.mode = plan.n_plain, plan.mode
+        # field -> [pointer the records currently hold, bytes]
+        self.fields = {f: [getattr(plan, f).data_ptr(), getattr(plan, f).numel() * getattr(plan, f).element_size()]
+                       for f in _TENSOR_FIELDS if getattr(plan, f) is not None}
+
+
+class _Recording:
+    """State of the one forward being recorded (attention._plan_for reports the controller calls to it)."""
+
+    def __init__(self, handle, keep):
+        self.handle, self.keep = handle, keep
+        self.events, self.foreign = [], []
+        self.live = 0          # > 0: inside a controller call -- launches and torch ops are the controller's, not the plan's
+        self.pool_ctx = None   # re-entered around the recorded stretches (GPU only)
+        self.enter_pool = None
+
+    def controller_call(self, planner, args):
+        L = N.lib()
+        N.check(L.fz_plan_pause(self.handle, 1), "fz_plan_pause")
+        if self.pool_ctx is not None:
+            self.pool_ctx.__exit__(None, None, None)
+            self.pool_ctx = None
+        self.live += 1
+        try:
+            plan = planner(*args)
+        finally:
+            self.live -= 1
+            if self.enter_pool is not None:
+                self.pool_ctx = self.enter_pool()
+                self.pool_ctx.__enter__()
+            N.check(L.fz_plan_pause(self.handle, 0), "fz_plan_pause")
+        self.events.append(_Event(args, int(L.fz_plan_launches(self.handle)), plan))
+        return plan
+
+
+_recording = None  # the forward being recorded (attention._plan_for looks here)
+
+
+def recording():
+    return _recording
+
+
+class ForwardPlan:
+    """A recorded forward: the native plan, its events, the tensors it must keep alive and its output."""
+
+    def __init__(self, handle, events, keep, out, inputs, n_launches, ctx, controller):
+        self.handle, self.events, self.keep, self.out = handle, events, keep, out
+        self.inputs = inputs  # name -> [pointer the records hold, bytes]
+        self.n = n_launches
+        self.ctx, self.controller = ctx, controller  # (references: the key holds their ids)
+        self.replays = 0
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                N.lib().fz_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+    def _relocate(self, first, count, slot, tensor, what):
+        ptr = tensor.data_ptr()
+        if ptr == slot[0]:
+            return
+        nbytes = tensor.numel() * tensor.element_size()
+        if nbytes != slot[1]:
+            raise RuntimeError(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
+        if N.lib().fz_plan_relocate(self.handle, first, count, C.c_void_p(slot[0]), nbytes, C.c_void_p(ptr)) < 0:
+            raise RuntimeError("fz_plan_relocate failed")
+        slot[0] = ptr
+
+    def replay(self, x, temb_act):
+        L = N.lib()
+        h, stream = self.handle, K._stream(x.data)
+        head = self.events[0].first if self.events else self.n  # conv_in and the time-embedding projections: in front of the first attention
+        self._relocate(0, head, self.inputs["x"], x.data, "the latent tokens")
+        self._relocate(0, head, self.inputs["temb"], temb_act, "the timestep embedding")
+        planner = None if self.controller is None else self.controller.attention_plan
+        at = 0
+        for ev in self.events:
+            if ev.first > at:
+                rc = L.fz_plan_replay(h, at, ev.first - at, stream)
+                if rc:
+                    N.check(rc, "fz_plan_replay")
+            at = ev.first
+            plan = planner(*ev.args)
+            if plan.n_plain != ev.n_plain or plan.mode != ev.mode:
+                raise RuntimeError("issue plan: the controller answered a different attention plan than the recorded forward "
+                                   f"(mode {ev.mode} -> {plan.mode}, plain frames {ev.n_plain} -> {plan.n_plain}): issue_signature() "
+                                   "does not separate the two kinds of step")
+            for f in _TENSOR_FIELDS:
+                t = getattr(plan, f)
+                slot = ev.fields.get(f)
+                if (t is None) != (slot is None):
+                    raise RuntimeError(f"issue plan: AttnPlan.{f} is {'absent' if t is None else 'present'} where the recorded forward "
+                                       "had the opposite: issue_signature() does not separate the two kinds of step")
+                if t is not None:
+                    self._relocate(ev.first, ev.count, slot, t, f"AttnPlan.{f}")
+        if self.n > at:
+            rc = L.fz_plan_replay(h, at, self.n - at, stream)
+            if rc:
+                N.check(rc, "fz_plan_replay")
+        K._launches[0] += self.n
+        self.replays += 1
+        return self.out.like(self.out.data.clone())  # (the caller may keep a forward's result across the next forward, as after the walk)
+
+
+class IssuePlans:
+    """Per-UNet cache of recorded forwards.  `run` returns the forward's output tokens, or None: take the Python walk."""
+    MAX_PLANS = 8
+    _pool = None  # torch.cuda.MemPool shared by every plan of the process
+
+    def __init__(self, unet):
+        self.unet = unet
+        self.seen = {}
+        self.plans = {}
+        self._probe = None
+        self.stats = {"walked": 0, "recorded": 0, "replayed": 0, "unsupported": 0, "unrecordable": []}
+
+    # -- what kind of forward is this ----------------------------------------------------------------------
+    def _controller(self):
+        if self._probe is None:
+            from .video_diffusion.models.attention import CrossAttention
+            self._probe = next(m for m in self.unet.modules() if isinstance(m, CrossAttention))
+        return self._probe.controller
+
+    def clear(self):
+        self.seen.clear()
+        self.plans.clear()
+
+    def _key(self, x, temb_act, ctx, controller):
+        from . import dist as D
+        if D.active_shard() is not None or x.data.dtype != torch.float16 or not x.data.is_contiguous():
+            return None
+        if controller is None:
+            sig = ("none",)
+        else:
+            sig_fn = getattr(controller, "issue_signature", None)
+            sig = None if sig_fn is None or getattr(controller, "attention_plan", None) is None else sig_fn()
+            if sig is None:
+                return None
+        return (tuple(x.data.shape), x.b, x.f, x.h, x.w, str(x.data.device), tuple(temb_act.shape), id(ctx), ctx._version, tuple(ctx.shape),
+                id(controller), sig)
+
+    # -- record --------------------------------------------------------------------------------------------
+    @classmethod
+    def _pool_entry(cls, device):
+        if torch.device(device).type != "cuda":
+            return None
+        if cls._pool is None:
+            cls._pool = torch.cuda.MemPool()
+        pool = cls._pool
+        return lambda: torch.cuda.use_mem_pool(pool, device=device)
+
+    def _record(self, key, x, temb_act, ctx, controller):
+        global _recording
+        L = N.lib()
+        handle = C.c_void_p()
+        N.check(L.fz_plan_begin(C.byref(handle)), "fz_plan_begin")
+        enter_pool = self._pool_entry(x.data.device)
+        rec = _Recording(handle, None if enter_pool is not None else [])
+        rec.enter_pool = enter_pool
+        _recording = rec
+        try:
+            with _Watch(rec):
+                if enter_pool is not None:
+                    rec.pool_ctx = enter_pool()
+                    rec.pool_ctx.__enter__()
+                try:
+                    out = self.unet._forward_body(x, temb_act, ctx)
+                finally:
+                    if rec.pool_ctx is not None:
+                        rec.pool_ctx.__exit__(None, None, None)
+                        rec.pool_ctx = None
+        except BaseException:
+            _recording = None
+            L.fz_plan_end(handle)
+            L.fz_plan_destroy(handle)
+            raise
+        _recording = None
+        N.check(L.fz_plan_end(handle), "fz_plan_end")
+        n = int(L.fz_plan_launches(handle))
+        for i, ev in enumerate(rec.events):
+            ev.count = (rec.events[i + 1].first if i + 1 < len(rec.events) else n) - ev.first
+        if rec.foreign:
+            self.stats["unrecordable"].append(sorted(set(rec.foreign)))
+            self.plans[key] = None  # this kind of forward is walked from now on
+            L.fz_plan_destroy(handle)
+            return out
+        result = out.like(out.data.clone())  # the plan keeps `out`: every replay writes it
+        inputs = {"x": [x.data.data_ptr(), x.data.numel() * x.data.element_size()],
+                  "temb": [temb_act.data_ptr(), temb_act.numel() * temb_act.element_size()]}
+        if len(self.plans) >= self.MAX_PLANS:
+            self.plans.pop(next(iter(self.plans)))
+        keep = rec.keep
+        if keep is not None:
+            keep.append(x.data)
+            keep.append(temb_act)
+        self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx, controller)
+        self.stats["recorded"] += 1
+        return result
+
+    # -- entry ---------------------------------------------------------------------------------------------
+    def run(self, x, temb_act, ctx):
+        controller = self._controller()
+        key = self._key(x, temb_act, ctx, controller)
+        if key is None:
+            self.stats["unsupported"] += 1
+            return None
+        if key in self.plans:
+            plan = self.plans[key]
+            if plan is None:
+                self.stats["walked"] += 1
+                return None
+            self.stats["replayed"] += 1
+            return plan.replay(x, temb_act)
+        n = self.seen.get(key, 0)
+        self.seen[key] = n + 1
+        if len(self.seen) > 64:
+            self.seen.pop(next(iter(self.seen)))
+        if n == 0:
+            self.stats["walked"] += 1
+            return None  # the first forward of a kind warms the caches the walk fills lazily
+        return self._record(key, x, temb_act, ctx, controller)

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from ... import dist as D
+from ... import issue as _issue
 from ... import kernels as K
 from .resnet import Tokens, _LinearParams, _NormParams, group_norm_tokens
 
@@ -49,6 +50,9 @@ def _plan_for(controller, is_cross, place, n, clip, heads, lq, lk, device):
         return AttnPlan(n)
     planner = getattr(controller, "attention_plan", None)
     if planner is not None:
+        rec = _issue.recording()
+        if rec is not None:  # a forward being recorded into a native issue plan: the controller call is an event, not part of the plan
+            return rec.controller_call(planner, (is_cross, place, n, clip, heads, lq, lk, device))
         return planner(is_cross, place, n, clip, heads, lq, lk, device)
     return None  # foreign controller: generic path
 

@@ -102,6 +102,7 @@ class UNetPseudo3DConditionModel(nn.Module):
                 cross_attention_dim=cross_attention_dim, attn_num_head_channels=rev_h[i], model_config=model_config))
         self.conv_norm_out = _NormParams(block_out_channels[0], norm_num_groups, norm_eps)
         self.conv_out = PseudoConv3d(block_out_channels[0], out_channels, kernel_size=3, padding=1, model_config=model_config)
+        self._issuer = None  # fatezero_amd.issue.IssuePlans once enable_issue_plans() was called
 
     # ------------------------------------------------------------------------------------------------------
     @property
@@ -114,6 +115,8 @@ class UNetPseudo3DConditionModel(nn.Module):
 
     def invalidate_packed(self):
         self._temb_pack = None
+        if getattr(self, "_issuer", None) is not None:
+            self._issuer.clear()  # recorded plans point at the packed weights
         for m in self.modules():
             for a in ("_packed", "_qk", "_qkv", "_ctx_kv", "_ln_fold"):
                 if hasattr(m, a):
@@ -164,8 +167,29 @@ class UNetPseudo3DConditionModel(nn.Module):
         from ... import kernels as K
         K.refresh_stream()
         temb_act = self.time_embed(timestep, x.b, x.data.device)
-        self._project_time_embeddings(temb_act)
         ctx = ctx.to(torch.float16)
+        issuer = self._issuer
+        if issuer is None and os.environ.get("FZ_ISSUE_PLANS") == "1":
+            issuer = self.enable_issue_plans()
+        if issuer is not None:  # the launch list of this kind of forward, recorded earlier, re-issued from native code (fatezero_amd/issue.py)
+            y = issuer.run(x, temb_act, ctx)
+            if y is not None:
+                return y
+        return self._forward_body(x, temb_act, ctx)
+
+    def enable_issue_plans(self, on=True):
+        """Native issue path: from its third occurrence on, a forward of a given kind (clip geometry, text context, controller kind) is
+        replayed from a recorded launch plan instead of being walked in Python.  Off by default (FZ_ISSUE_PLANS=1 switches it on)."""
+        if on and self._issuer is None:
+            from ...issue import IssuePlans
+            self._issuer = IssuePlans(self)
+        elif not on:
+            self._issuer = None
+        return self._issuer
+
+    def _forward_body(self, x: Tokens, temb_act, ctx) -> Tokens:
+        """Everything of the forward that is the library's own launches: time-embedding projections, conv_in ... conv_out."""
+        self._project_time_embeddings(temb_act)
         from .resnet import GN_FROM_EPILOGUE
         x = self.conv_in.forward_tokens(x, gn_groups=self.conv_norm_out.num_groups if GN_FROM_EPILOGUE else 0)
         skips = [x]

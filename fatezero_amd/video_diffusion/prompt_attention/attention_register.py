@@ -20,6 +20,9 @@ class DummyController:
         from ..models.attention import AttnPlan
         return AttnPlan(n_frames)
 
+    def issue_signature(self):
+        return ("dummy",)
+
 
 def register_attention_control(model, controller):
     "Connect a model with a controller"

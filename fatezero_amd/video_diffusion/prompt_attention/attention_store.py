@@ -79,6 +79,12 @@ class AttentionControl(abc.ABC):
     def plan_controlled(self, is_cross, place, n_ctrl, clip_len, heads, lq, lk, device) -> AttnPlan:
         return AttnPlan(0)
 
+    def issue_signature(self):
+        """What, beside the clip geometry, decides the LAUNCH LIST of a UNet forward under this controller (fatezero_amd/issue.py: forwards of
+        one signature share a recorded plan; pointers and data may differ between them, kernels and modes may not).  None: not known --
+        every forward is walked in Python."""
+        return None
+
 
 SPILL_RING = 3  # HBM staging slabs of the spill tier: the step in use, the step being copied, one spare (a latent blend reads a neighbour)
 
@@ -400,6 +406,11 @@ class AttentionStore(AttentionControl):
         key = f"{place}_{'cross' if is_cross else 'self'}"
         cm = self.new_slot(key, n_ctrl, heads, lq, lk, is_cross, device)
         return AttnPlan(0, K.FZ_ATTN_CAPTURE, p=cm.storage)
+
+    def issue_signature(self):
+        if type(self).plan_controlled is not AttentionStore.plan_controlled:
+            return None  # a subclass that plans differently says so itself
+        return ("store", bool(self.LOW_RESOURCE), bool(self.save_self_attention))
 
     def forward(self, attn, is_cross: bool, place_in_unet: str):
         """Reference tensor protocol (attention_store.py:81-93): keep a copy of the map."""

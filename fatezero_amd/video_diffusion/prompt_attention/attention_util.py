@@ -112,6 +112,13 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
     def update_attention_position_dict(self, current_attention_key):
         self.attention_position_counter_dict[current_attention_key] += 1
 
+    def issue_signature(self):
+        if type(self).plan_controlled is not AttentionControlEdit.plan_controlled:
+            return None
+        in_self_window = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
+        return ("edit", bool(self.LOW_RESOURCE), bool(self.save_self_attention), bool(in_self_window), self.attention_blend is not None,
+                bool(self.track_cross_attention), self.visualize_res)
+
     def plan_controlled(self, is_cross, place, n_ctrl, clip_len, heads, lq, lk, device) -> AttnPlan:
         if lq > MAX_CONTROLLED_TOKENS:
             return AttnPlan(0)

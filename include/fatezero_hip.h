@@ -367,6 +367,28 @@ int fz_peer_put(const void* src, int64_t bytes, void* const* dst, uint32_t* cons
                 uint32_t* done_counter, void* stream);
 int fz_peer_wait(const uint32_t* flags, uint64_t sender_mask, uint32_t epoch, uint32_t* err, int64_t timeout_us, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Native issue plans.  The reference issues a UNet forward by walking its module tree in Python at every DDIM step
+ * (`self.unet(latent_model_input, t, encoder_hidden_states=...)`, p2p_ddim_spatial_temporal.py:286 / stable_diffusion.py:360-372); the launch
+ * list that walk produces is a pure function of (clip geometry, controller plan).  A plan is that list recorded once: between
+ * fz_plan_begin and fz_plan_end every launch the library makes on behalf of ANY fz_* entry point is issued as usual and appended to the plan
+ * (kernel, grid, block, LDS bytes, a byte copy of the kernel arguments); fz_plan_replay re-issues records [first, first + count) on
+ * `stream` with one call.  What changes between steps is data behind pointers: fz_plan_relocate rewrites, inside the argument bytes of
+ * records [first, first + count), every pointer-sized, pointer-aligned word that points into [old_base, old_base + nbytes) to the same
+ * offset from new_base, and returns the number of words rewritten (< 0: bad arguments).  fz_plan_pause(p, 1) ... (p, 0) brackets host work
+ * whose launches must NOT enter the plan (what the host repeats live at every replay: the attention controller's own kernels).
+ * One recording at a time, from the one thread that issues launches; a plan never allocates device memory, never synchronises, and owns
+ * nothing but host memory (the buffers its records point into are the host layer's to keep alive: fatezero_amd/issue.py).
+ * Returns FZ_OK or a negative FZ_ERR_* code like every other entry point. */
+typedef struct FzPlan FzPlan;
+int fz_plan_begin(FzPlan** out);
+int fz_plan_pause(FzPlan* plan, int paused);
+int fz_plan_end(FzPlan* plan);
+int64_t fz_plan_launches(const FzPlan* plan);
+int64_t fz_plan_relocate(FzPlan* plan, int64_t first, int64_t count, const void* old_base, int64_t nbytes, const void* new_base);
+int fz_plan_replay(const FzPlan* plan, int64_t first, int64_t count, void* stream);
+void fz_plan_destroy(FzPlan* plan);
+
 const char* fz_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,141 @@
+"""Native issue plans (csrc/plan.hip, fatezero_amd/issue.py) on the CPU emulation backend: the record / relocate / replay machinery of the
+library, and the pipeline with the UNet forwards of the steady-state steps replayed from recorded plans against the same pipeline walked in
+Python -- same kernels, same arguments, so bit for bit.  (The GPU leg with the private memory pool: tests/test_pipeline_gpu.py.)"""
+import ctypes as C
+
+import pytest
+import torch
+
+from fatezero_amd import _native, build
+
+import pipeline_cases as PC
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_backend():
+    _native.use_test_backend(build.build_emu())
+    yield
+    _native.reset_backend()
+
+
+def test_record_relocate_replay():
+    from fatezero_amd import kernels as K
+    L = _native.lib()
+    g = torch.Generator().manual_seed(3)
+    x1, x2 = (torch.randn(96, 320, generator=g).half() for _ in range(2))
+    gam, bet = torch.randn(320, generator=g).half(), torch.randn(320, generator=g).half()
+    want1, want2 = K.layernorm(x1, gam, bet, eps=1e-5), K.layernorm(x2, gam, bet, eps=1e-5)
+    eye = torch.eye(320).half()   # (what a record points at must outlive the plan: the plan owns host memory only)
+    h = C.c_void_p()
+    assert L.fz_plan_begin(C.byref(h)) == 0
+    h2 = C.c_void_p()
+    assert L.fz_plan_begin(C.byref(h2)) < 0                      # one recording at a time
+    y = K.layernorm(x1, gam, bet, eps=1e-5)                      # recorded (and run)
+    assert L.fz_plan_pause(h, 1) == 0
+    K.layernorm(x2, gam, bet, eps=1e-5)                          # live only: not part of the plan
+    assert L.fz_plan_pause(h, 0) == 0
+    z = K.gemm(y, eye)                         # a second record that reads the first one's output
+    assert L.fz_plan_end(h) == 0
+    n = L.fz_plan_launches(h)
+    assert n == 2, n
+    assert torch.equal(y, want1)
+    zwant2 = K.gemm(want2, eye)
+    # replay as recorded: same buffers, same result
+    y.zero_(); z.zero_()
+    assert L.fz_plan_replay(h, 0, n, None) == 0
+    assert torch.equal(y, want1)
+    # the input lives elsewhere now: one pointer of record 0 moves, nothing of record 1
+    nbytes = x1.numel() * 2
+    assert L.fz_plan_relocate(h, 1, 1, C.c_void_p(x1.data_ptr()), nbytes, C.c_void_p(x2.data_ptr())) == 0
+    assert L.fz_plan_relocate(h, 0, n, C.c_void_p(x1.data_ptr()), nbytes, C.c_void_p(x2.data_ptr())) == 1
+    assert L.fz_plan_replay(h, 0, n, None) == 0
+    assert torch.equal(y, want2) and torch.equal(z, zwant2)
+    # a pointer INTO the old range keeps its offset: rows 32.. of x1 as the input of a one-record plan
+    h3 = C.c_void_p()
+    assert L.fz_plan_begin(C.byref(h3)) == 0
+    y3 = K.layernorm(x1[32:], gam, bet, eps=1e-5)
+    assert L.fz_plan_end(h3) == 0
+    assert L.fz_plan_relocate(h3, 0, 1, C.c_void_p(x1.data_ptr()), nbytes, C.c_void_p(x2.data_ptr())) == 1
+    assert L.fz_plan_replay(h3, 0, 1, None) == 0
+    assert torch.equal(y3, want2[32:])
+    assert L.fz_plan_replay(h, 0, n + 1, None) < 0 and L.fz_plan_relocate(h, 1, n, None, 8, None) < 0   # ranges are checked
+    L.fz_plan_destroy(h); L.fz_plan_destroy(h3)
+
+
+@pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_f3_mid_next"])
+def test_pipeline_replayed_from_plans_is_bit_identical(name, monkeypatch):
+    base, pipe0 = PC.run_pipeline_case(name, "cpu", return_pipe=True)
+    monkeypatch.setenv("FZ_ISSUE_PLANS", "1")
+    res, pipe = PC.run_pipeline_case(name, "cpu", return_pipe=True)
+    stats = pipe.unet._issuer.stats
+    print(name, stats)
+    assert stats["replayed"] >= 3 and stats["recorded"] >= 1 and not stats["unrecordable"] and not stats["unsupported"], stats
+    assert torch.equal(pipe.last_edited_latents, pipe0.last_edited_latents)
+    assert res == base
+    for st, st0 in zip(pipe.store_controller.attention_store_all_step, pipe0.store_controller.attention_store_all_step):
+        for k in st0:
+            for a, b in zip(st[k], st0[k]):
+                assert torch.equal(a, b), k
+
+
+def test_plans_over_the_spill_tier(monkeypatch):
+    """Replayed capture launches follow the step's slab into the staging ring of the arena's spill tier (disk_store=True): the pointers of
+    every capture layer are relocated at every step."""
+    from fatezero_amd.video_diffusion.prompt_attention import attention_store as AS
+    base, pipe0 = PC.run_pipeline_case("pipe_small_refine_reweight", "cpu", return_pipe=True)
+    monkeypatch.setenv("FZ_ISSUE_PLANS", "1")
+    monkeypatch.setenv("FZ_ARENA_HBM_GB", "0")
+    monkeypatch.setattr(AS, "SPILL_RING", 2)
+    res, pipe = PC.run_pipeline_case("pipe_small_refine_reweight", "cpu", return_pipe=True, disk_store=True)
+    assert pipe.unet._issuer.stats["replayed"] >= 3 and pipe.store_controller.arena.fetch_stats["h2d"] >= 1
+    assert torch.equal(pipe.last_edited_latents, pipe0.last_edited_latents) and res == base
+
+
+def test_a_forward_with_a_torch_compute_op_is_never_replayed(monkeypatch):
+    """A torch op of its own inside the recorded stretch would not be repeated by a replay: the recording notices and that kind of forward
+    stays on the Python walk."""
+    from fatezero_amd.video_diffusion.models import unet_3d_condition as U
+    unet = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+    unet.enable_issue_plans()
+    orig = U.UNetPseudo3DConditionModel._forward_body
+
+    def body(self, x, temb_act, ctx):
+        y = orig(self, x, temb_act, ctx)
+        return y.like(y.data * 1.0)   # aten.mul: not one of the library's launches
+    monkeypatch.setattr(U.UNetPseudo3DConditionModel, "_forward_body", body)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, 4, 2, 16, 16, generator=g).half()
+    ctx = torch.randn(1, 77, 64, generator=g).half()
+    outs = [unet(z, 10 * i + 1, ctx).sample for i in range(4)]
+    st = unet._issuer.stats
+    assert st["unrecordable"] == [["aten.mul.Tensor"]] and st["replayed"] == 0 and st["walked"] == 3, st
+    assert all(torch.isfinite(o).all() for o in outs)
+
+
+def test_replay_refuses_a_step_of_another_kind():
+    """Two kinds of step that a controller's issue_signature() fails to tell apart: the replay compares what the controller answers with
+    what the recording saw and stops instead of issuing the wrong launch list."""
+    from fatezero_amd.video_diffusion.prompt_attention.attention_register import register_attention_control, DummyController
+    from fatezero_amd.video_diffusion.models.attention import AttnPlan
+    from fatezero_amd import kernels as K
+    from types import SimpleNamespace
+
+    class Flip(DummyController):
+        capture = False
+
+        def attention_plan(self, is_cross, place, n_frames, clip_len, heads, lq, lk, device):
+            if self.capture and is_cross:
+                return AttnPlan(0, K.FZ_ATTN_CAPTURE, p=torch.empty(n_frames, heads, lq, K.CROSS_P_STRIDE, dtype=torch.float16))
+            return AttnPlan(n_frames)
+    unet = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+    unet.enable_issue_plans()
+    ctrl = Flip()
+    register_attention_control(SimpleNamespace(unet=unet), ctrl)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, 4, 2, 16, 16, generator=g).half()
+    ctx = torch.randn(1, 77, 64, generator=g).half()
+    ys = [unet(z, 5, ctx).sample for _ in range(3)]
+    assert unet._issuer.stats["replayed"] == 1 and torch.equal(ys[0], ys[2]) and torch.equal(ys[1], ys[2])
+    ctrl.capture = True
+    with pytest.raises(RuntimeError, match="issue_signature"):
+        unet(z, 5, ctx)

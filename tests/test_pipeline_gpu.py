@@ -153,6 +153,33 @@ def test_disk_store_spill_tier_is_bit_identical_gpu(monkeypatch):
     assert sums == sums0
 
 
+@pytest.mark.parametrize("name", ["pipe_refine_reweight_latentblend", "pipe_f3_mid_next"])
+def test_pipeline_replayed_from_issue_plans_is_bit_identical_gpu(name, monkeypatch):
+    """The UNet forwards of the steady-state steps re-issued from recorded native plans (csrc/plan.hip, fatezero_amd/issue.py; buffers from the
+    private torch.cuda.MemPool) against the same pipeline walked in Python: same kernels, same arguments -- bit for bit."""
+    base, pipe0 = PC.run_pipeline_case(name, "cuda", return_pipe=True)
+    monkeypatch.setenv("FZ_ISSUE_PLANS", "1")
+    res, pipe = PC.run_pipeline_case(name, "cuda", return_pipe=True)
+    stats = pipe.unet._issuer.stats
+    print(name, stats)
+    assert stats["replayed"] >= 3 and stats["recorded"] >= 1 and not stats["unrecordable"] and not stats["unsupported"], stats
+    assert torch.equal(pipe.last_edited_latents, pipe0.last_edited_latents)
+    assert res == base
+
+
+def test_spill_case_replayed_from_issue_plans_gpu(monkeypatch):
+    """20 + 20 steps with attention blend, plans on, and the arena's spill tier under them (every capture pointer relocated into the staging
+    ring at every step, every inject pointer into the slab a step was fetched to): bit-identical to the walked, resident run."""
+    inv0, ed0, sums0, _ = PC.run_spill_case("cuda", disk_store=False)
+    monkeypatch.setenv("FZ_ISSUE_PLANS", "1")
+    inv1, ed1, sums1, _ = PC.run_spill_case("cuda", disk_store=False)
+    assert torch.equal(inv1, inv0) and torch.equal(ed1, ed0) and sums1 == sums0
+    monkeypatch.setenv("FZ_ARENA_HBM_GB", "0")
+    inv2, ed2, sums2, arena = PC.run_spill_case("cuda", disk_store=True)
+    assert len(arena["spilled"]) == len(sums0) - 1
+    assert torch.equal(inv2, inv0) and torch.equal(ed2, ed0) and sums2 == sums0
+
+
 def test_drift_50_steps():
     res = PC.run_drift_case("cuda")
     print("drift (max latent error / max |latent| at steps 10, 25, 50):", res)
