@@ -123,6 +123,7 @@ _SIGS = {
     "fz_plan_launches": (C.c_int64, [_P]),
     "fz_plan_relocate": (C.c_int64, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "fz_plan_replay": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
+    "fz_plan_graph_launch": (C.c_int, [_P, _P]),
     "fz_plan_destroy": (None, [_P]),
     "fz_version": (C.c_char_p, []),
 }

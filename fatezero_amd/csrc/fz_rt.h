@@ -375,6 +375,7 @@ namespace fz_plan {
 
 struct Record {
     void (*run)(const Record&, const unsigned char* args, void* stream);
+    int (*argptrs)(unsigned char* packed, void** out);   // addresses of the packed arguments, in kernel-parameter order (graph nodes)
     const void* kernel;
     dim3 grid, block;
     size_t smem;
@@ -409,7 +410,14 @@ template <typename F, typename H, typename... T, typename... Done> inline void u
     unpack(f, a.tail, d..., a.head);
 }
 
+inline int collect(Args<>&, void**, int i) { return i; }
+template <typename H, typename... T> inline int collect(Args<H, T...>& a, void** out, int i) {
+    out[i] = (void*)&a.head;
+    return collect(a.tail, out, i + 1);
+}
+
 template <typename... P> struct Thunk {
+    static int argptrs(unsigned char* packed, void** out) { return collect(*(Args<P...>*)packed, out, 0); }
     static void run(const Record& r, const unsigned char* args, void* stream) {
         Args<P...> a;
         memcpy(&a, args + r.arg_off, sizeof(a));
@@ -427,6 +435,8 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t smem, voi
         const Args<P...> packed = Packer<P...>::make(a...);
         Record r;
         r.run = &Thunk<P...>::run;
+        r.argptrs = &Thunk<P...>::argptrs;
+        static_assert(sizeof...(P) <= 32 && alignof(Args<P...>) <= 16, "kernel argument list beyond what a plan record holds");
         r.kernel = (const void*)kernel;
         r.grid = grid; r.block = block; r.smem = smem;
         r.arg_off = (uint32_t)(pl.args.size() * 8);

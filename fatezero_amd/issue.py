@@ -6,6 +6,9 @@ kernel launches (descriptors, grids, pointers) that are a pure function of (clip
 pointers differs between steps.  `IssuePlans.run` therefore
 
   1. lets the FIRST forward of a kind run through Python untouched (weight packs, the text context's K / V^T, scratch buffers get cached);
+     a kind = (clip geometry, shape of the text context, controller class and `issue_signature()`), NOT the job: the plans of one job serve
+     the next one -- a new context of the same shape is projected into the K / V^T buffers the records already point at (`bind_context`),
+     a new controller object answers the same events;
   2. RECORDS the second one (`fz_plan_begin` ... `fz_plan_end`, csrc/plan.hip): the forward runs as usual and every launch the library
      makes is appended to a native plan.  What the attention CONTROLLER does stays live: each `controller.attention_plan(...)` call of the
      walk becomes an *event* -- recording is paused around it (its own launches, e.g. the blend-mask kernels, are issued by the controller at
@@ -14,7 +17,10 @@ pointers differs between steps.  `IssuePlans.run` therefore
      controller is asked for the step's plan at each event exactly as the walk would (its counters, arena slots and masks advance as in the
      reference protocol), and where the step's tensors live elsewhere than the recorded ones -- the step's slab of the map arena, the
      per-step cross-attention coefficients, a fresh mask -- the pointers of that layer's records are rewritten (`fz_plan_relocate`).
-     The forward's inputs (latent tokens, timestep embedding) are relocated the same way.
+     The forward's inputs (latent tokens, timestep embedding) are relocated the same way.  Where the controller's planning never reads the
+     forward's own activations (the built-in controllers: slots of the arena, constants, masks from the STORED maps -- `issue_events_first`)
+     all its calls are taken first and the whole launch list goes out as ONE hipGraph launch (`fz_plan_graph_launch`: kernel nodes in
+     record order, the relocated ones refreshed with hipGraphExecKernelNodeSetParams).
 
 Every buffer the records point into was allocated by the recorded forward.  On the GPU those allocations come from a private
 `torch.cuda.MemPool` shared by all plans of a process (blocks freed during the forward are reused inside it exactly as the recording saw,
@@ -26,6 +32,7 @@ Scope: one process, one GPU, the built-in controllers (`issue_signature()`); a f
 controllers run the Python walk as before.  Off by default: `UNetPseudo3DConditionModel.enable_issue_plans()` / FZ_ISSUE_PLANS=1.
 """
 import ctypes as C
+import os
 
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
@@ -118,17 +125,21 @@ def recording():
 class ForwardPlan:
     """A recorded forward: the native plan, its events, the tensors it must keep alive and its output."""
 
-    def __init__(self, handle, events, keep, out, inputs, n_launches, ctx, controller):
+    def __init__(self, handle, events, keep, out, inputs, n_launches, ctx_kv):
         self.handle, self.events, self.keep, self.out = handle, events, keep, out
         self.inputs = inputs  # name -> [pointer the records hold, bytes]
         self.n = n_launches
-        self.ctx, self.controller = ctx, controller  # (references: the key holds their ids)
+        # the text context the recorded forward attended to, and ITS K / V^T projections [(module, K, V^T)]: the records of the cross-attention
+        # layers point at these buffers (the walk projects a context once per pass and caches the result on the module, attention.py)
+        self.ctx_kv = ctx_kv
         self.replays = 0
+        self._lib = N.lib()  # the library that made the handle destroys it
 
     def __del__(self):
         try:
             if self.handle is not None:
-                N.lib().fz_plan_destroy(self.handle)
+                self._lib.fz_plan_destroy(self.handle)
+                self.handle = None
         except Exception:
             pass
 
@@ -143,21 +154,39 @@ class ForwardPlan:
             raise RuntimeError("fz_plan_relocate failed")
         slot[0] = ptr
 
-    def replay(self, x, temb_act):
+    def bind_context(self, ctx):
+        """A new text context of the recorded shape (the next job, the other pass): its K / V^T into the buffers the records point at."""
+        for m, kk, vt in self.ctx_kv:
+            m.project_context_into(ctx, kk, vt)
+
+    def context_is_bound(self, ctx):
+        """Do the buffers the records point at hold the projections of `ctx`?  The modules' caches say: whoever writes those buffers
+        (bind_context of any plan that shares them) or replaces them (a walked forward with another context) updates the cache."""
+        for m, kk, _ in (self.ctx_kv[0], self.ctx_kv[-1]) if self.ctx_kv else ():
+            c = m._ctx_kv
+            if c is None or c[0] is not ctx or c[1] != ctx._version or c[2] is not kk:
+                return False
+        return True
+
+    def replay(self, x, temb_act, controller, events_first=False, graph=False):
+        """events_first: every controller call is taken before the first launch (a controller whose planning never reads the forward's own
+        activations says so: `issue_events_first`) and the records go out in one piece -- as ONE hipGraph launch with `graph`."""
         L = N.lib()
         h, stream = self.handle, K._stream(x.data)
         head = self.events[0].first if self.events else self.n  # conv_in and the time-embedding projections: in front of the first attention
         self._relocate(0, head, self.inputs["x"], x.data, "the latent tokens")
         self._relocate(0, head, self.inputs["temb"], temb_act, "the timestep embedding")
-        planner = None if self.controller is None else self.controller.attention_plan
+        planner = None if controller is None else controller.attention_plan
         at = 0
+        alive = []  # what the controller handed out stays allocated until the launches that read it are queued
         for ev in self.events:
-            if ev.first > at:
+            if ev.first > at and not events_first:
                 rc = L.fz_plan_replay(h, at, ev.first - at, stream)
                 if rc:
                     N.check(rc, "fz_plan_replay")
-            at = ev.first
+                at = ev.first
             plan = planner(*ev.args)
+            alive.append(plan)
             if plan.n_plain != ev.n_plain or plan.mode != ev.mode:
                 raise RuntimeError("issue plan: the controller answered a different attention plan than the recorded forward "
                                    f"(mode {ev.mode} -> {plan.mode}, plain frames {ev.n_plain} -> {plan.n_plain}): issue_signature() "
@@ -170,10 +199,15 @@ class ForwardPlan:
                                        "had the opposite: issue_signature() does not separate the two kinds of step")
                 if t is not None:
                     self._relocate(ev.first, ev.count, slot, t, f"AttnPlan.{f}")
-        if self.n > at:
+        if graph and at == 0:
+            rc = L.fz_plan_graph_launch(h, stream)
+            if rc:
+                N.check(rc, "fz_plan_graph_launch")
+        elif self.n > at:
             rc = L.fz_plan_replay(h, at, self.n - at, stream)
             if rc:
                 N.check(rc, "fz_plan_replay")
+        del alive
         K._launches[0] += self.n
         self.replays += 1
         return self.out.like(self.out.data.clone())  # (the caller may keep a forward's result across the next forward, as after the walk)
@@ -184,12 +218,14 @@ class IssuePlans:
     MAX_PLANS = 8
     _pool = None  # torch.cuda.MemPool shared by every plan of the process
 
-    def __init__(self, unet):
+    def __init__(self, unet, graph=None):
         self.unet = unet
+        # one hipGraph launch per forward where the controller's calls can all be taken first (FZ_ISSUE_GRAPH=0: per-record launches)
+        self.graph = (os.environ.get("FZ_ISSUE_GRAPH", "1") != "0") if graph is None else bool(graph)
         self.seen = {}
         self.plans = {}
         self._probe = None
-        self.stats = {"walked": 0, "recorded": 0, "replayed": 0, "unsupported": 0, "unrecordable": []}
+        self.stats = {"walked": 0, "recorded": 0, "replayed": 0, "contexts_bound": 0, "unsupported": 0, "unrecordable": []}
 
     # -- what kind of forward is this ----------------------------------------------------------------------
     def _controller(self):
@@ -213,8 +249,8 @@ class IssuePlans:
             sig = None if sig_fn is None or getattr(controller, "attention_plan", None) is None else sig_fn()
             if sig is None:
                 return None
-        return (tuple(x.data.shape), x.b, x.f, x.h, x.w, str(x.data.device), tuple(temb_act.shape), id(ctx), ctx._version, tuple(ctx.shape),
-                id(controller), sig)
+        return (tuple(x.data.shape), x.b, x.f, x.h, x.w, str(x.data.device), tuple(temb_act.shape), tuple(ctx.shape), ctx.dtype,
+                type(controller), sig)
 
     # -- record --------------------------------------------------------------------------------------------
     @classmethod
@@ -264,13 +300,20 @@ class IssuePlans:
         result = out.like(out.data.clone())  # the plan keeps `out`: every replay writes it
         inputs = {"x": [x.data.data_ptr(), x.data.numel() * x.data.element_size()],
                   "temb": [temb_act.data_ptr(), temb_act.numel() * temb_act.element_size()]}
+        from .video_diffusion.models.attention import CrossAttention
+        ctx_kv = []
+        for m in self.unet.modules():
+            if isinstance(m, CrossAttention) and m._ctx_kv is not None:
+                if m._ctx_kv[0] is not ctx:  # (cannot happen: the recorded forward just attended to ctx)
+                    raise RuntimeError("issue plan: a cross-attention layer holds the projections of another context")
+                ctx_kv.append((m, m._ctx_kv[2], m._ctx_kv[3]))
         if len(self.plans) >= self.MAX_PLANS:
             self.plans.pop(next(iter(self.plans)))
         keep = rec.keep
         if keep is not None:
             keep.append(x.data)
             keep.append(temb_act)
-        self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx, controller)
+        self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx_kv)
         self.stats["recorded"] += 1
         return result
 
@@ -287,7 +330,11 @@ class IssuePlans:
                 self.stats["walked"] += 1
                 return None
             self.stats["replayed"] += 1
-            return plan.replay(x, temb_act)
+            if not plan.context_is_bound(ctx):
+                plan.bind_context(ctx)
+                self.stats["contexts_bound"] += 1
+            first = controller is None or bool(getattr(controller, "issue_events_first", False))
+            return plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
         if len(self.seen) > 64:

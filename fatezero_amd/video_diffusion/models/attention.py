@@ -143,6 +143,16 @@ class CrossAttention(nn.Module):
             self._qk_fold = q_fold
         return self._qk
 
+    def project_context_into(self, ctx, kk, vt):
+        """K / V^T of the text context `ctx` written into EXISTING buffers (those of an earlier context of the same shape) and made this
+        module's cached projections: the launch records of a native issue plan keep pointing at valid data (fatezero_amd/issue.py)."""
+        if kk.shape[:-1] != ctx.shape[:-1] or kk.device != ctx.device or ctx.dtype != kk.dtype:
+            raise RuntimeError(f"issue plan: text context {tuple(ctx.shape)} / {ctx.dtype} does not fit the recorded projections {tuple(kk.shape)}")
+        w, b = self.to_k.packed(ctx.dtype, ctx.device)
+        K.gemm(ctx, w, b, out=kk)
+        K.gemm_vt(ctx, self.to_v.packed(ctx.dtype, ctx.device)[0], K.CROSS_KEYS, out=vt)
+        self._ctx_kv = (ctx, ctx._version, kk, vt)
+
     def _generic_controller_call(self, controller, is_cross, q, k, vt, out, clip, lq, lk_total, run_capture, run_inject):
         """Reference protocol for a controller that only has __call__: materialise P, call it, apply the result.
         Like the reference with xformers enabled (attention_register.py:112-116,198-204) maps larger than 32x32

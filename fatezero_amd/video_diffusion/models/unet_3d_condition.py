@@ -177,12 +177,12 @@ class UNetPseudo3DConditionModel(nn.Module):
                 return y
         return self._forward_body(x, temb_act, ctx)
 
-    def enable_issue_plans(self, on=True):
+    def enable_issue_plans(self, on=True, graph=None):
         """Native issue path: from its third occurrence on, a forward of a given kind (clip geometry, text context, controller kind) is
         replayed from a recorded launch plan instead of being walked in Python.  Off by default (FZ_ISSUE_PLANS=1 switches it on)."""
         if on and self._issuer is None:
             from ...issue import IssuePlans
-            self._issuer = IssuePlans(self)
+            self._issuer = IssuePlans(self, graph=graph)
         elif not on:
             self._issuer = None
         return self._issuer

@@ -20,6 +20,8 @@ class DummyController:
         from ..models.attention import AttnPlan
         return AttnPlan(n_frames)
 
+    issue_events_first = True
+
     def issue_signature(self):
         return ("dummy",)
 

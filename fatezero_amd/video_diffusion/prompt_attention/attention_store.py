@@ -407,6 +407,11 @@ class AttentionStore(AttentionControl):
         cm = self.new_slot(key, n_ctrl, heads, lq, lk, is_cross, device)
         return AttnPlan(0, K.FZ_ATTN_CAPTURE, p=cm.storage)
 
+    @property
+    def issue_events_first(self):
+        """plan_controlled hands out a slot of the arena per captured layer: nothing of the forward is read."""
+        return type(self).plan_controlled is AttentionStore.plan_controlled
+
     def issue_signature(self):
         if type(self).plan_controlled is not AttentionStore.plan_controlled:
             return None  # a subclass that plans differently says so itself

@@ -112,6 +112,11 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
     def update_attention_position_dict(self, current_attention_key):
         self.attention_position_counter_dict[current_attention_key] += 1
 
+    @property
+    def issue_events_first(self):
+        """plan_controlled hands out the step's stored maps, per-step constants, blend masks thresholded from the STORED cross maps: nothing of the live forward is read."""
+        return type(self).plan_controlled is AttentionControlEdit.plan_controlled
+
     def issue_signature(self):
         if type(self).plan_controlled is not AttentionControlEdit.plan_controlled:
             return None

@@ -387,6 +387,10 @@ int fz_plan_end(FzPlan* plan);
 int64_t fz_plan_launches(const FzPlan* plan);
 int64_t fz_plan_relocate(FzPlan* plan, int64_t first, int64_t count, const void* old_base, int64_t nbytes, const void* new_base);
 int fz_plan_replay(const FzPlan* plan, int64_t first, int64_t count, void* stream);
+/* All records with ONE runtime call: the plan as an executable hipGraph (a chain of kernel nodes in record order, built and instantiated at the
+ * first call); records whose arguments fz_plan_relocate changed since the previous launch are refreshed first
+ * (hipGraphExecKernelNodeSetParams).  For a forward whose controller events can all be taken before the first launch. */
+int fz_plan_graph_launch(FzPlan* plan, void* stream);
 void fz_plan_destroy(FzPlan* plan);
 
 const char* fz_version(void);

@@ -69,6 +69,18 @@ def main():
                 ts.append(time.perf_counter() - t0)
                 if store is not None:
                     store.step_callback(x.data)   # closes the step: the next forward captures into the next slab of the arena
+        if dev == "cuda":  # the same forwards back to back, nothing synchronised in between: what the GPU needs for one
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                e0.record()
+                for i in range(10):
+                    unet.forward_tokens(x, 481 - 20 * i, ctx)
+                    if store is not None:
+                        store.step_callback(x.data)
+                e1.record()
+                torch.cuda.synchronize()
+            out[mode + "_gpu_ms_per_forward"] = round(e0.elapsed_time(e1) / 10, 3)
         steady = sorted(ts[4:])
         out[mode + "_ms"] = round(1e3 * steady[len(steady) // 2], 3)
         out[mode + "_ms_min"] = round(1e3 * steady[0], 3)

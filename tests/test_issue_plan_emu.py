@@ -139,3 +139,39 @@ def test_replay_refuses_a_step_of_another_kind():
     ctrl.capture = True
     with pytest.raises(RuntimeError, match="issue_signature"):
         unet(z, 5, ctx)
+
+
+def test_plans_serve_the_next_job():
+    """The plans of one job replay the next one: a new text context of the same shape is projected into the K / V^T buffers the records point
+    at, a new controller object answers the recorded events -- against a walked run of the same two jobs, bit for bit."""
+    from types import SimpleNamespace
+    from fatezero_amd.video_diffusion.prompt_attention.attention_register import register_attention_control
+    from fatezero_amd.video_diffusion.prompt_attention.attention_store import AttentionStore
+    g = torch.Generator().manual_seed(4)
+    z = [torch.randn(1, 4, 2, 16, 16, generator=g).half() for _ in range(2)]
+    ctxs = [torch.randn(1, 77, 64, generator=g).half() for _ in range(2)]
+
+    def jobs(plans):
+        unet = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+        if plans:
+            unet.enable_issue_plans()
+        outs, maps = [], []
+        for j in range(2):
+            store = AttentionStore()
+            store.LOW_RESOURCE = True
+            register_attention_control(SimpleNamespace(unet=unet), store)
+            x = z[j]
+            for i in range(4):
+                x = unet(x, 900 - 200 * i, ctxs[j]).sample
+                store.step_callback(x)
+                outs.append(x.clone())
+            maps.append([[m.clone() for k in sorted(st) for m in st[k]] for st in store.attention_store_all_step])
+        return unet, outs, maps
+    _, outs0, maps0 = jobs(False)
+    unet, outs1, maps1 = jobs(True)
+    st = unet._issuer.stats
+    assert st["walked"] == 1 and st["recorded"] == 1 and st["replayed"] == 6 and st["contexts_bound"] == 1, st
+    assert all(torch.equal(a, b) for a, b in zip(outs0, outs1))
+    for ja, jb in zip(maps0, maps1):
+        for sa, sb in zip(ja, jb):
+            assert len(sa) == len(sb) and all(torch.equal(a, b) for a, b in zip(sa, sb))
