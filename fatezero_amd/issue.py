@@ -98,6 +98,16 @@ class _Recording:
 
     def controller_call(self, planner, args):
         L = N.lib()
+        if self.handle is None:  # the warm-up walk under the private pool: nothing is recorded, the controller still allocates outside it
+            if self.pool_ctx is not None:
+                self.pool_ctx.__exit__(None, None, None)
+                self.pool_ctx = None
+            try:
+                return planner(*args)
+            finally:
+                if self.enter_pool is not None:
+                    self.pool_ctx = self.enter_pool()
+                    self.pool_ctx.__enter__()
         N.check(L.fz_plan_pause(self.handle, 1), "fz_plan_pause")
         if self.pool_ctx is not None:
             self.pool_ctx.__exit__(None, None, None)
@@ -116,6 +126,7 @@ class _Recording:
 
 
 _recording = None  # the forward being recorded (attention._plan_for looks here)
+ENABLED = True     # same-box A/B runs (scripts/ab_bench.py fatezero_amd.issue ENABLED): False -> every forward is walked
 
 
 def recording():
@@ -225,6 +236,8 @@ class IssuePlans:
         self.seen = {}
         self.plans = {}
         self._probe = None
+        self.runahead = int(os.environ.get("FZ_ISSUE_RUNAHEAD", "0"))
+        self._ring = []
         self.stats = {"walked": 0, "recorded": 0, "replayed": 0, "contexts_bound": 0, "unsupported": 0, "unrecordable": []}
 
     # -- what kind of forward is this ----------------------------------------------------------------------
@@ -319,6 +332,8 @@ class IssuePlans:
 
     # -- entry ---------------------------------------------------------------------------------------------
     def run(self, x, temb_act, ctx):
+        if not ENABLED:
+            return None
         controller = self._controller()
         key = self._key(x, temb_act, ctx, controller)
         if key is None:
@@ -334,12 +349,39 @@ class IssuePlans:
                 plan.bind_context(ctx)
                 self.stats["contexts_bound"] += 1
             first = controller is None or bool(getattr(controller, "issue_events_first", False))
-            return plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
+            y = plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
+            if self.runahead > 0 and y.data.is_cuda:  # (trial knob: the host may be at most `runahead` replayed forwards in front of the GPU)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._ring.append(ev)
+                if len(self._ring) > self.runahead:
+                    self._ring.pop(0).synchronize()
+            return y
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
         if len(self.seen) > 64:
             self.seen.pop(next(iter(self.seen)))
         if n == 0:
             self.stats["walked"] += 1
-            return None  # the first forward of a kind warms the caches the walk fills lazily
+            return self._walk_in_pool(x, temb_act, ctx)  # the first forward of a kind warms the caches the walk fills lazily
         return self._record(key, x, temb_act, ctx, controller)
+
+    def _walk_in_pool(self, x, temb_act, ctx):
+        """The warm-up walk allocates from the private pool as the recording will: the recorded forward then finds the pool in its steady
+        state (freed blocks of the right sizes to reuse) instead of growing it allocation by allocation -- a compact set of addresses."""
+        global _recording
+        enter_pool = self._pool_entry(x.data.device)
+        if enter_pool is None:
+            return None
+        rec = _Recording(None, None)
+        rec.enter_pool = enter_pool
+        _recording = rec
+        rec.pool_ctx = enter_pool()
+        rec.pool_ctx.__enter__()
+        try:
+            out = self.unet._forward_body(x, temb_act, ctx)
+        finally:
+            _recording = None
+            if rec.pool_ctx is not None:
+                rec.pool_ctx.__exit__(None, None, None)
+        return out.like(out.data.clone())  # (out of the general allocator: pool blocks stay with the plans)
