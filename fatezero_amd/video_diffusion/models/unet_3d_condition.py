@@ -35,6 +35,9 @@ class _TimestepEmbedding(nn.Module):
         self.linear_2 = _LinearParams(cout, cout)
 
 
+TIME_EMBED_CACHE = True  # (switch for same-box A/B runs: False = the timestep enters as a device tensor at every forward, as before)
+
+
 class UNetPseudo3DConditionModel(nn.Module):
     def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
                  center_input_sample: bool = False, flip_sin_to_cos: bool = True, freq_shift: int = 0,
@@ -103,6 +106,7 @@ class UNetPseudo3DConditionModel(nn.Module):
         self.conv_norm_out = _NormParams(block_out_channels[0], norm_num_groups, norm_eps)
         self.conv_out = PseudoConv3d(block_out_channels[0], out_channels, kernel_size=3, padding=1, model_config=model_config)
         self._issuer = None  # fatezero_amd.issue.IssuePlans once enable_issue_plans() was called
+        self._temb_cache, self._temb_freq = {}, {}
 
     # ------------------------------------------------------------------------------------------------------
     @property
@@ -115,6 +119,7 @@ class UNetPseudo3DConditionModel(nn.Module):
 
     def invalidate_packed(self):
         self._temb_pack = None
+        self._temb_cache, self._temb_freq = {}, {}
         if getattr(self, "_issuer", None) is not None:
             self._issuer.clear()  # recorded plans point at the packed weights
         for m in self.modules():
@@ -135,12 +140,33 @@ class UNetPseudo3DConditionModel(nn.Module):
         Returns silu(emb) in fp16: every consumer (ResnetBlock.time_emb_proj) applies the non-linearity first."""
         c0 = self.config.block_out_channels[0]
         half = c0 // 2
-        t = torch.as_tensor(timestep, dtype=torch.float32, device=device).reshape(-1).expand(batch)
-        freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=device) / half)
-        e = t[:, None] * freq[None]
+        # The DDIM loops pass host integers (schedulers.py keeps `timesteps` on the host): a scalar that enters the device as a TENSOR is a
+        # blocking host-to-device copy, i.e. a full stream synchronisation in front of every forward (the GPU drains, then idles until the
+        # first launches of the forward are issued).  It enters as a kernel ARGUMENT instead (freq * float), and the result -- a function of
+        # (timestep, weights) only -- is kept: the 50 timesteps of a job recur in every pass and every job.
+        host_scalar = TIME_EMBED_CACHE and not (isinstance(timestep, torch.Tensor) and (timestep.is_cuda or timestep.numel() != 1))
+        key = (float(timestep), batch, str(device)) if host_scalar else None
+        if key is not None:
+            hit = self._temb_cache.get(key)
+            if hit is not None:
+                return hit
+        freq = self._temb_freq.get(str(device))
+        if freq is None:
+            freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=device) / half)
+            self._temb_freq[str(device)] = freq
+        if key is not None:
+            e = (freq * key[0])[None].expand(batch, half)
+        else:
+            t = torch.as_tensor(timestep, dtype=torch.float32, device=device).reshape(-1).expand(batch)
+            e = t[:, None] * freq[None]
         e = torch.cat([torch.cos(e), torch.sin(e)], dim=-1).to(torch.float16)
         e = self.time_embedding.linear_2.apply(F.silu(self.time_embedding.linear_1.apply(e)))
-        return F.silu(e)
+        e = F.silu(e)
+        if key is not None:
+            if len(self._temb_cache) >= 4096:
+                self._temb_cache.clear()
+            self._temb_cache[key] = e
+        return e
 
     def _project_time_embeddings(self, temb_act):
         """All 22 `time_emb_proj` Linear layers of the ResNet blocks as ONE GEMM (they only depend on the timestep)."""

@@ -94,15 +94,18 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
             mt = torch.zeros(K.CROSS_KEYS, K.CROSS_KEYS)
             mt[:MAX_WORDS, :MAX_WORDS] = self.mapper_matrix().t()
             self._mapper_t_dev = mt.to(device=device, dtype=torch.float16).contiguous()
-        key = (step, str(device))
+        key = str(device)
         if key not in self._coef_cache:
+            # every step's (A, B) row pair in ONE device tensor, moved once: a host-to-device copy per step would be a stream
+            # synchronisation per step (the first cross-attention layer of every edit forward would drain the GPU)
             a0, b0 = self.inner_coef()
-            alpha = self.cross_replace_alpha[step].reshape(-1)[:MAX_WORDS].float()
-            coef = torch.zeros(2, K.CROSS_KEYS)
-            coef[0, :MAX_WORDS] = alpha * a0
-            coef[1, :MAX_WORDS] = alpha * b0 + (1 - alpha)
+            n = self.cross_replace_alpha.shape[0]
+            alpha = self.cross_replace_alpha.reshape(n, -1)[:, :MAX_WORDS].float()
+            coef = torch.zeros(n, 2, K.CROSS_KEYS)
+            coef[:, 0, :MAX_WORDS] = alpha * a0
+            coef[:, 1, :MAX_WORDS] = alpha * b0 + (1 - alpha)
             self._coef_cache[key] = coef.to(device)
-        return self._mapper_t_dev, self._coef_cache[key]
+        return self._mapper_t_dev, self._coef_cache[key][step]
 
     # ---------------------------------------------------------------------------------------------------
     def _step_in_store(self):

@@ -24,7 +24,7 @@ def test_pipeline_small(name):
     PC.check(res)
 
 
-@pytest.mark.parametrize("name", ["pipe_small_refine_reweight", "pipe_f3_mid_next"])
+@pytest.mark.parametrize("name", ["pipe_f3_mid_next"])   # (pipe_small_refine_reweight: under the issue plans, tests/test_issue_plan_emu.py)
 def test_disk_store_spill_tier_is_bit_identical(name, monkeypatch):
     """disk_store=True (attention_store.py:103-108: a .pt file per step in the reference) with an HBM budget of 0: every step behind the first
     is captured into the 2-slab staging ring, copied to the host tier, and comes back for the edit -- one still in its slab, the others by
