@@ -793,6 +793,8 @@ def main():
                     help="blend_th of the Porsche edit in the TIMED jobs instead of the config's 0.3 (the in-situ PMC pass of scripts/pmc_job.sh "
                          "runs the split-mask job with it, so that the inject class it attributes really reads stored rows); the line says so")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration (fixed flash launch, 1 GiB copy) and the clock / power sampler")
+    ap.add_argument("--split-steps", type=int, default=10, help="DDIM steps of the short jobs the split threshold is bisected on")
+    ap.add_argument("--split-iters", type=int, default=10, help="bisection steps of the split threshold")
     ap.add_argument("--no-split-mask", action="store_true",
                     help="skip the threshold sweep + the extra job whose blend mask splits the rows (the kernel breakdown then runs with th = 0.3)")
     ap.add_argument("--issue-plans", action="store_true",
@@ -902,7 +904,7 @@ def main():
         # a blend threshold under which the masked-inject launches really read stored rows (pick_split_threshold), and ONE job with it,
         # timed like the primary (no event brackets besides the flash ones), beside the config-faithful th = 0.3 of the timed region
         timer.enabled = False
-        th_split, seen = pick_split_threshold(pipe, z0, device)
+        th_split, seen = pick_split_threshold(pipe, z0, device, steps=args.split_steps, iters=args.split_iters)
         if th_split is not None:
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -41,6 +41,7 @@ from . import _native as N
 from . import kernels as K
 
 _TENSOR_FIELDS = ("p", "row_mask", "mapper_t", "coef", "cur_out", "capture_first")
+_PARK_BASE = 0x7000_0000_0000_0000  # (far outside any address space a device or host allocation can have; fields 2^44 bytes apart)
 
 # aten ops a recorded forward may run between its launches: allocation and metadata only
 _ALLOC_OPS = {"aten.empty.memory_format", "aten.empty_like.default", "aten.empty_strided.default", "aten.new_empty.default",
@@ -165,6 +166,26 @@ class ForwardPlan:
             raise RuntimeError("fz_plan_relocate failed")
         slot[0] = ptr
 
+    def _relocate_many(self, first, count, pairs, what):
+        """Several pointers of one record range at once.  Done one after the other, a tensor that landed where ANOTHER field's previous tensor
+        lived would be moved twice (a -> b, then every b -> c): the changed ones go through distinct addresses no allocation can have first."""
+        changed = [(slot, t) for slot, t in pairs if t.data_ptr() != slot[0]]
+        if len(changed) <= 1:
+            for slot, t in changed:
+                self._relocate(first, count, slot, t, what)
+            return
+        L = N.lib()
+        for i, (slot, t) in enumerate(changed):
+            nbytes = t.numel() * t.element_size()
+            if nbytes != slot[1]:
+                raise RuntimeError(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
+            parked = _PARK_BASE + (i << 44)
+            if L.fz_plan_relocate(self.handle, first, count, C.c_void_p(slot[0]), nbytes, C.c_void_p(parked)) < 0:
+                raise RuntimeError("fz_plan_relocate failed")
+            slot[0] = parked
+        for slot, t in changed:
+            self._relocate(first, count, slot, t, what)
+
     def bind_context(self, ctx):
         """A new text context of the recorded shape (the next job, the other pass): its K / V^T into the buffers the records point at."""
         for m, kk, vt in self.ctx_kv:
@@ -185,8 +206,7 @@ class ForwardPlan:
         L = N.lib()
         h, stream = self.handle, K._stream(x.data)
         head = self.events[0].first if self.events else self.n  # conv_in and the time-embedding projections: in front of the first attention
-        self._relocate(0, head, self.inputs["x"], x.data, "the latent tokens")
-        self._relocate(0, head, self.inputs["temb"], temb_act, "the timestep embedding")
+        self._relocate_many(0, head, [(self.inputs["x"], x.data), (self.inputs["temb"], temb_act)], "a forward input")
         planner = None if controller is None else controller.attention_plan
         at = 0
         alive = []  # what the controller handed out stays allocated until the launches that read it are queued
@@ -202,6 +222,7 @@ class ForwardPlan:
                 raise RuntimeError("issue plan: the controller answered a different attention plan than the recorded forward "
                                    f"(mode {ev.mode} -> {plan.mode}, plain frames {ev.n_plain} -> {plan.n_plain}): issue_signature() "
                                    "does not separate the two kinds of step")
+            pairs = []
             for f in _TENSOR_FIELDS:
                 t = getattr(plan, f)
                 slot = ev.fields.get(f)
@@ -209,7 +230,9 @@ class ForwardPlan:
                     raise RuntimeError(f"issue plan: AttnPlan.{f} is {'absent' if t is None else 'present'} where the recorded forward "
                                        "had the opposite: issue_signature() does not separate the two kinds of step")
                 if t is not None:
-                    self._relocate(ev.first, ev.count, slot, t, f"AttnPlan.{f}")
+                    pairs.append((slot, t))
+            if pairs:
+                self._relocate_many(ev.first, ev.count, pairs, "an AttnPlan tensor")
         if graph and at == 0:
             rc = L.fz_plan_graph_launch(h, stream)
             if rc:

@@ -212,7 +212,7 @@ def test_bench_main_single_rank_with_the_kernel_breakdown_job():
     import subprocess
     import sys
     cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_harness.py"), "--steps", "1", "--warmup", "0", "--ddim-steps", "2",
-           "--frames", "2", "--latent-size", "8", "--no-cpu-baseline"]
+           "--frames", "2", "--latent-size", "8", "--no-cpu-baseline", "--split-steps", "2", "--split-iters", "3"]   # (the bisection: 3 short jobs, not 10)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run(cmd, check=True, timeout=600, capture_output=True, text=True, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

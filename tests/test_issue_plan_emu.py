@@ -194,3 +194,27 @@ def test_timestep_as_kernel_argument_matches_the_tensor_path(monkeypatch):
     assert torch.equal(c[0], a[0]) and not torch.equal(c[1], a[1])
     unet.load_state_dict(unet.state_dict())                                       # new weights: nothing kept
     assert not unet._temb_cache
+
+
+def test_relocations_that_chain_are_not_applied_twice():
+    """Two pointers of one record range change at once and the first one's NEW address is the second one's OLD address (the allocator handed a
+    freed buffer of one field to another): moved one after the other the first would travel twice."""
+    from fatezero_amd import kernels as K
+    from fatezero_amd.issue import ForwardPlan
+    L = _native.lib()
+    g = torch.Generator().manual_seed(8)
+    pool = torch.randn(3, 64, 320, generator=g).half()      # three equally sized buffers at known addresses
+    xa, xb, xc = pool[0], pool[1], pool[2]
+    gam, bet = torch.ones(320).half(), torch.zeros(320).half()
+    h = C.c_void_p()
+    assert L.fz_plan_begin(C.byref(h)) == 0
+    ya = K.layernorm(xa, gam, bet, eps=1e-5)                 # record 0 reads xa
+    yb = K.layernorm(xb, gam, bet, eps=1e-5)                 # record 1 reads xb
+    assert L.fz_plan_end(h) == 0
+    plan = ForwardPlan(h, [], None, None, {}, 2, [])
+    nbytes = xa.numel() * 2
+    slots = ([xa.data_ptr(), nbytes], [xb.data_ptr(), nbytes])
+    plan._relocate_many(0, 2, [(slots[0], xb), (slots[1], xc)], "test")   # xa -> xb while xb -> xc
+    assert L.fz_plan_replay(h, 0, 2, None) == 0
+    assert torch.equal(ya, K.layernorm(xb, gam, bet, eps=1e-5)) and torch.equal(yb, K.layernorm(xc, gam, bet, eps=1e-5))
+    assert slots[0][0] == xb.data_ptr() and slots[1][0] == xc.data_ptr()
