@@ -387,7 +387,9 @@ struct Plan {
     std::vector<uint64_t> args;   // (uint64_t: the relocation pass walks pointer-sized, pointer-aligned words)
 };
 
-extern Plan* g_recording;   // the plan being recorded by this process (nullptr: none) -- ONE issuing thread, as the host layer has
+inline Plan* g_recording = nullptr;   // the plan being recorded by this process (nullptr: none) -- ONE issuing thread, as the host layer has
+                                      // (a C++17 inline variable: one object for all translation units of the library, and the stand-alone
+                                      //  trial programs under scripts/ that include a kernel file link without csrc/plan.hip)
 
 // the arguments of one launch as an aggregate of the kernel's own parameter types: trivially copyable, pointers at their natural alignment
 template <typename... P> struct Args;

@@ -4,10 +4,6 @@
 #include "fz_rt.h"
 #include "../../include/fatezero_hip.h"
 
-namespace fz_plan {
-Plan* g_recording = nullptr;
-}
-
 struct FzPlan {
     fz_plan::Plan plan;
     bool paused = false;
