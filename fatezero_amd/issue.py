@@ -162,9 +162,18 @@ class ForwardPlan:
         nbytes = tensor.numel() * tensor.element_size()
         if nbytes != slot[1]:
             raise RuntimeError(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
-        if N.lib().fz_plan_relocate(self.handle, first, count, C.c_void_p(slot[0]), nbytes, C.c_void_p(ptr)) < 0:
+        self._move(first, count, slot, nbytes, ptr, what)
+
+    def _move(self, first, count, slot, nbytes, new_ptr, what):
+        """Relocation matches argument words by VALUE; the number of words a slot's range matched when the forward was recorded is the number
+        it must match at every replay (every other argument byte is the same as then): anything else is a word that is not this pointer."""
+        n = N.lib().fz_plan_relocate(self.handle, first, count, C.c_void_p(slot[0]), nbytes, C.c_void_p(new_ptr))
+        if n < 0:
             raise RuntimeError("fz_plan_relocate failed")
-        slot[0] = ptr
+        if len(slot) > 2 and n != slot[2]:
+            raise RuntimeError(f"issue plan: {what} matched {n} argument words where the recording had {slot[2]}: a non-pointer argument holds "
+                               "a value inside the tensor's address range -- this forward cannot be replayed safely")
+        slot[0] = new_ptr
 
     def _relocate_many(self, first, count, pairs, what):
         """Several pointers of one record range at once.  Done one after the other, a tensor that landed where ANOTHER field's previous tensor
@@ -174,15 +183,11 @@ class ForwardPlan:
             for slot, t in changed:
                 self._relocate(first, count, slot, t, what)
             return
-        L = N.lib()
         for i, (slot, t) in enumerate(changed):
             nbytes = t.numel() * t.element_size()
             if nbytes != slot[1]:
                 raise RuntimeError(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
-            parked = _PARK_BASE + (i << 44)
-            if L.fz_plan_relocate(self.handle, first, count, C.c_void_p(slot[0]), nbytes, C.c_void_p(parked)) < 0:
-                raise RuntimeError("fz_plan_relocate failed")
-            slot[0] = parked
+            self._move(first, count, slot, nbytes, _PARK_BASE + (i << 44), what)
         for slot, t in changed:
             self._relocate(first, count, slot, t, what)
 
@@ -349,7 +354,14 @@ class IssuePlans:
         if keep is not None:
             keep.append(x.data)
             keep.append(temb_act)
-        self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx_kv)
+        plan = self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx_kv)
+        # how many argument words each relocatable range matches now (a move onto itself counts without changing anything): the check of _move
+        head = rec.events[0].first if rec.events else n
+        for slot in inputs.values():
+            slot.append(int(L.fz_plan_relocate(handle, 0, head, C.c_void_p(slot[0]), slot[1], C.c_void_p(slot[0]))))
+        for ev in rec.events:
+            for slot in ev.fields.values():
+                slot.append(int(L.fz_plan_relocate(handle, ev.first, ev.count, C.c_void_p(slot[0]), slot[1], C.c_void_p(slot[0]))))
         self.stats["recorded"] += 1
         return result
 

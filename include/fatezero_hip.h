@@ -375,7 +375,9 @@ int fz_peer_wait(const uint32_t* flags, uint64_t sender_mask, uint32_t epoch, ui
  * (kernel, grid, block, LDS bytes, a byte copy of the kernel arguments); fz_plan_replay re-issues records [first, first + count) on
  * `stream` with one call.  What changes between steps is data behind pointers: fz_plan_relocate rewrites, inside the argument bytes of
  * records [first, first + count), every pointer-sized, pointer-aligned word that points into [old_base, old_base + nbytes) to the same
- * offset from new_base, and returns the number of words rewritten (< 0: bad arguments).  fz_plan_pause(p, 1) ... (p, 0) brackets host work
+ * offset from new_base, and returns the number of words rewritten (< 0: bad arguments).  The match is by VALUE: an argument word that is not
+ * a pointer but happens to hold a number inside the range would move too -- the ranges are device (or pinned host) allocations, and no size, stride,
+ * count or scale argument of this library takes values up there (2^46 and beyond).  fz_plan_pause(p, 1) ... (p, 0) brackets host work
  * whose launches must NOT enter the plan (what the host repeats live at every replay: the attention controller's own kernels).
  * One recording at a time, from the one thread that issues launches; a plan never allocates device memory, never synchronises, and owns
  * nothing but host memory (the buffers its records point into are the host layer's to keep alive: fatezero_amd/issue.py).

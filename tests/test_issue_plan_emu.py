@@ -218,3 +218,24 @@ def test_relocations_that_chain_are_not_applied_twice():
     assert L.fz_plan_replay(h, 0, 2, None) == 0
     assert torch.equal(ya, K.layernorm(xb, gam, bet, eps=1e-5)) and torch.equal(yb, K.layernorm(xc, gam, bet, eps=1e-5))
     assert slots[0][0] == xb.data_ptr() and slots[1][0] == xc.data_ptr()
+
+
+def test_a_relocation_that_matches_a_non_pointer_word_is_refused():
+    """fz_plan_relocate matches argument words by value.  The host layer counts, when a forward is recorded, how many words each relocatable
+    range matches, and a replay whose relocation matches another number stops: here an int64 row count (96) sits inside the 'address range'
+    [64, 128) of a fake tensor."""
+    from fatezero_amd import kernels as K
+    from fatezero_amd.issue import ForwardPlan
+    L = _native.lib()
+    x = torch.randn(96, 320).half()
+    gam, bet = torch.ones(320).half(), torch.zeros(320).half()
+    h = C.c_void_p()
+    assert L.fz_plan_begin(C.byref(h)) == 0
+    K.layernorm(x, gam, bet, eps=1e-5)
+    assert L.fz_plan_end(h) == 0
+    plan = ForwardPlan(h, [], None, None, {}, 1, [])
+    good = [x.data_ptr(), x.numel() * 2, 1]                  # the input pointer: one word, as recorded
+    plan._move(0, 1, good, good[1], x.data_ptr(), "x")       # (onto itself: counts, changes nothing)
+    fake = [64, 64, 0]                                        # a slot whose recorded range [64, 128) matched nothing ...
+    with pytest.raises(RuntimeError, match="matched 1 argument words where the recording had 0"):
+        plan._move(0, 1, fake, 64, 1 << 40, "a fake tensor")  # ... and now matches the int64 `rows` = 96 of the launch
