@@ -134,6 +134,13 @@ def recording():
     return _recording
 
 
+def _model_switches():
+    """The module-level switches of the model code that change which kernels a forward launches (same-box A/B runs flip them at run time):
+    a plan recorded under one setting is not the launch list of another."""
+    from .video_diffusion.models import attention as A, lora as Lo, resnet as R
+    return (A.LN_FUSION, A.QKV_FUSION, A.LN_FROM_PRODUCER, R.GN_FROM_EPILOGUE, Lo.LORA_PAIR_FUSION, Lo.LORA_PAIR_GN, Lo.LORA_PAIR_ALWAYS)
+
+
 class ForwardPlan:
     """A recorded forward: the native plan, its events, the tensors it must keep alive and its output."""
 
@@ -291,7 +298,7 @@ class IssuePlans:
             if sig is None:
                 return None
         return (tuple(x.data.shape), x.b, x.f, x.h, x.w, str(x.data.device), tuple(temb_act.shape), tuple(ctx.shape), ctx.dtype,
-                type(controller), sig)
+                type(controller), sig, _model_switches())
 
     # -- record --------------------------------------------------------------------------------------------
     @classmethod
