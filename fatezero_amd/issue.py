@@ -271,8 +271,6 @@ class IssuePlans:
         self.seen = {}
         self.plans = {}
         self._probe = None
-        self.runahead = int(os.environ.get("FZ_ISSUE_RUNAHEAD", "0"))
-        self._ring = []
         self.stats = {"walked": 0, "recorded": 0, "replayed": 0, "contexts_bound": 0, "unsupported": 0, "unrecordable": []}
 
     # -- what kind of forward is this ----------------------------------------------------------------------
@@ -391,14 +389,7 @@ class IssuePlans:
                 plan.bind_context(ctx)
                 self.stats["contexts_bound"] += 1
             first = controller is None or bool(getattr(controller, "issue_events_first", False))
-            y = plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
-            if self.runahead > 0 and y.data.is_cuda:  # (trial knob: the host may be at most `runahead` replayed forwards in front of the GPU)
-                ev = torch.cuda.Event()
-                ev.record()
-                self._ring.append(ev)
-                if len(self._ring) > self.runahead:
-                    self._ring.pop(0).synchronize()
-            return y
+            return plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
         if len(self.seen) > 64:
