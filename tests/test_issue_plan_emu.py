@@ -239,3 +239,29 @@ def test_a_relocation_that_matches_a_non_pointer_word_is_refused():
     fake = [64, 64, 0]                                        # a slot whose recorded range [64, 128) matched nothing ...
     with pytest.raises(RuntimeError, match="matched 1 argument words where the recording had 0"):
         plan._move(0, 1, fake, 64, 1 << 40, "a fake tensor")  # ... and now matches the int64 `rows` = 96 of the launch
+
+
+def test_plans_follow_weights_and_model_switches(monkeypatch):
+    """New weights drop every plan (the records point at the packed weights of the old ones); a launch-list switch of the model code flipped
+    at run time selects other plans instead of replaying the wrong list."""
+    from fatezero_amd.video_diffusion.models import attention as A
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 4, 2, 16, 16, generator=g).half()
+    ctx = torch.randn(1, 77, 64, generator=g).half()
+    unet = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+    ref = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+    unet.enable_issue_plans()
+    for _ in range(3):
+        y = unet(z, 7, ctx).sample
+    assert unet._issuer.stats["replayed"] == 1 and torch.equal(y, ref(z, 7, ctx).sample)
+    sd = {k: (v * 1.25 if k.endswith("conv_in.weight") else v) for k, v in unet.state_dict().items()}
+    unet.load_state_dict(sd)
+    ref.load_state_dict(sd)
+    assert not unet._issuer.plans and not unet._issuer.seen
+    y2 = [unet(z, 7, ctx).sample for _ in range(3)][-1]                # walked, recorded, replayed -- on the new weights
+    assert unet._issuer.stats["replayed"] == 2 and torch.equal(y2, ref(z, 7, ctx).sample) and not torch.equal(y2, y)
+    monkeypatch.setattr(A, "QKV_FUSION", not A.QKV_FUSION)             # another launch list: its own walk / record / replay
+    walked = unet._issuer.stats["walked"]
+    y3 = [unet(z, 7, ctx).sample for _ in range(3)][-1]
+    assert unet._issuer.stats["walked"] == walked + 1 and unet._issuer.stats["replayed"] == 3 and len(unet._issuer.plans) == 2
+    assert torch.equal(y3, ref(z, 7, ctx).sample)
