@@ -96,10 +96,45 @@ def _is_gpu(device):
 class SpilledStep:
     """One step's maps in the host tier: `host` is the step's slab (pinned on a GPU box), `layout` = [(key, byte offset, storage shape, lk)]
     in capture order; `slot` is the staging slab of the HBM ring that currently holds a copy (None: host only)."""
-    __slots__ = ("host", "layout", "slot")
+    __slots__ = ("host", "layout", "slot", "d2h_event")
 
     def __init__(self, host, layout):
         self.host, self.layout, self.slot = host, layout, None
+        self.d2h_event = None  # copy-stream event behind the device-to-host copy that fills `host` (None: complete)
+
+    def wait_host(self):
+        """Block the HOST until `host` holds the step (readers of the reference-shaped host views come through here)."""
+        ev, self.d2h_event = self.d2h_event, None
+        if ev is not None:
+            ev.synchronize()
+
+
+class HostStepMaps(dict):
+    """`attention_store_all_step[step]` of a spilled step: {key: [host views]} whose first read waits for the device-to-host copy that is
+    still in flight when the capture pass hands the views out (the reference's `.cpu()` blocks at once, attention_store.py:86-87)."""
+
+    def __init__(self, items, spilled_step):
+        super().__init__(items)
+        self._sp = spilled_step
+
+    def _ready(self):
+        self._sp.wait_host()
+
+    def __getitem__(self, k):
+        self._ready()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._ready()
+        return super().get(k, default)
+
+    def items(self):
+        self._ready()
+        return super().items()
+
+    def values(self):
+        self._ready()
+        return super().values()
 
 
 class MapArena:
@@ -117,10 +152,19 @@ class MapArena:
     _host_pool = []  # released host slabs of the spill tier (pinning tens of GB is seconds: recycle)
 
     @classmethod
-    def _take(cls, nbytes, device, hint="disk_store=True (spills the steps that do not fit to pinned host memory), "):
+    def reset_pools(cls):
+        """Give every recycled block (HBM and host) back to the allocator: a process that wants a clean slate between jobs, and the tests."""
+        cls._pool = []
+        cls._host_pool = []
+
+    @classmethod
+    def _take(cls, nbytes, device, hint="disk_store=True (spills the steps that do not fit to pinned host memory), ", at_most=None):
+        """A block of >= nbytes: the smallest recycled one that fits -- and, with `at_most` (the spill tier's budget), is not larger than
+        that: a recycled block must never raise what a budgeted arena holds -- else a fresh one."""
         best = None
         for i, t in enumerate(cls._pool):
-            if t.device == torch.device(device) and t.numel() >= nbytes and (best is None or t.numel() < cls._pool[best].numel()):
+            if t.device == torch.device(device) and t.numel() >= nbytes and (at_most is None or t.numel() <= at_most) \
+                    and (best is None or t.numel() < cls._pool[best].numel()):
                 best = i
         if best is not None:
             return cls._pool.pop(best)
@@ -141,9 +185,9 @@ class MapArena:
         return torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
 
     def release(self):
-        if self.reserved is not None:
-            MapArena._pool.append(self.reserved)
-            self.reserved = None
+        if self._block is not None:
+            MapArena._pool.append(self._block)
+            self._block = self.reserved = None
         if self.spilled:
             self._drain_copies()
             MapArena._host_pool = [sp.host for sp in self.spilled.values()]  # (only the latest job's: a pool, not a second arena)
@@ -153,7 +197,8 @@ class MapArena:
         self.step_bytes = 0
         self.cur = None
         self.cur_off = 0
-        self.reserved = None
+        self.reserved = None              # the part of `_block` this arena hands out: exactly step_bytes * (steps reserved)
+        self._block = None                # the allocation behind it (a recycled block may be larger; the whole of it goes back to the pool)
         self.reserved_off = 0
         self.first_step_done = False
         self.total_bytes = 0
@@ -188,16 +233,21 @@ class MapArena:
 
     def reserve(self, n_steps, device):
         if self.first_step_done and self.step_bytes and n_steps > 0 and self.reserved is None:
+            at_most = None
             if self.spill:
                 budget = self._budget(device)
                 if budget is not None:
-                    n_steps = max(0, min(n_steps, (budget - self.total_bytes - SPILL_RING * self.step_bytes) // self.step_bytes))
+                    at_most = max(0, budget - self.total_bytes - SPILL_RING * self.step_bytes)
+                    n_steps = min(n_steps, at_most // self.step_bytes)
                     if n_steps == 0:
                         return
-            self.reserved = MapArena._take(self.step_bytes * n_steps, device, hint="" if self.spill else
-                                           "disk_store=True (spills the steps that do not fit to pinned host memory), ")
+            self._block = MapArena._take(self.step_bytes * n_steps, device, hint="" if self.spill else
+                                         "disk_store=True (spills the steps that do not fit to pinned host memory), ", at_most=at_most)
+            # a recycled block may be larger than asked for: the arena hands out n_steps slabs of it and no more (residency is what the
+            # budget said), and counts what it really holds
+            self.reserved = self._block[: self.step_bytes * n_steps]
             self.reserved_off = 0
-            self.total_bytes += self.step_bytes * n_steps
+            self.total_bytes += self._block.numel()
 
     def _resident_slab(self, nbytes, device):
         """The HBM slab of the next step, or None when the step goes to the spill tier."""
@@ -224,6 +274,9 @@ class MapArena:
             self.total_bytes += nbytes
             return torch.empty(shape, dtype=torch.float16, device=device)
         if self.cur is None or self.cur_off + nbytes > self.cur.numel():
+            if self.cur is not None and self._cur_slot is not None:
+                raise RuntimeError("spill tier: a step overflows its staging slab (the capture layout grew after the first step): the host copy "
+                                   "of a step is ONE slab")
             self.cur = self._resident_slab(nbytes, device)
             self._cur_slot = None
             if self.cur is None:
@@ -291,7 +344,7 @@ class MapArena:
             copy.wait_event(compute.record_event())
             with torch.cuda.stream(copy):
                 sp.host.copy_(self.ring[slot], non_blocking=True)
-                self.ring_event[slot] = copy.record_event()
+                self.ring_event[slot] = sp.d2h_event = copy.record_event()
         sp.slot = slot  # the slab still holds the step until it is claimed again
         self.spilled[step] = sp
         self.spilled_bytes += self.step_bytes
@@ -475,7 +528,7 @@ class AttentionStore(AttentionControl):
             for cm in maps[k]:
                 layout.append((k, cm.storage.data_ptr() - base, tuple(cm.storage.shape), cm.view.shape[-1]))
         sp = self.arena.spill_step(layout, slab.device)
-        self.attention_store_all_step[step] = {k: [cm.view for cm in v] for k, v in self._maps_over(sp.host, layout).items()}
+        self.attention_store_all_step[step] = HostStepMaps({k: [cm.view for cm in v] for k, v in self._maps_over(sp.host, layout).items()}, sp)
         self._all_step_maps[step] = None  # resolved through the arena from here on (maps_of_step)
 
     @staticmethod

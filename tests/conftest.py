@@ -24,3 +24,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_arena_pools():
+    """The map arena recycles released blocks through process-wide pools (MapArena._pool / _host_pool): a test must not inherit what an
+    earlier test released."""
+    from fatezero_amd.video_diffusion.prompt_attention.attention_store import MapArena
+    MapArena.reset_pools()
+    yield
+    MapArena.reset_pools()

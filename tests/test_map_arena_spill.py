@@ -90,6 +90,47 @@ def test_budget_decides_how_many_steps_stay_resident():
         check_step(plain, s, w2)
 
 
+def test_a_recycled_larger_block_does_not_raise_residency():
+    """Round-5 review: a 12-step arena released into the pool, then a budgeted store -- the pooled 11-step block must neither be handed out
+    beyond the budget nor be held unaccounted."""
+    big = AS.AttentionStore()
+    big.expected_steps = 12
+    capture(big, 12)
+    step_bytes = big.arena.step_bytes
+    big.release_arena()
+    assert [t.numel() for t in AS.MapArena._pool] == [11 * step_bytes]
+    budget = step_bytes * (1 + 3 + AS.SPILL_RING)
+    store = AS.AttentionStore(disk_store=True, hbm_budget_bytes=budget)
+    store.expected_steps = 8
+    want = capture(store, 8)
+    assert sorted(store.arena.spilled) == [4, 5, 6, 7], sorted(store.arena.spilled)
+    assert store.arena._block.numel() == 3 * step_bytes and store.arena.total_bytes == budget == store.arena_bytes
+    for s in (7, 0, 4, 3, 6, 5, 2, 1):
+        check_step(store, s, want)
+    # without a budget a recycled larger block IS reused -- sliced to the steps asked for, counted whole
+    store.release_arena()
+    big2 = AS.AttentionStore()
+    big2.expected_steps = 12
+    capture(big2, 12)
+    big2.release_arena()
+    small = AS.AttentionStore()
+    small.expected_steps = 5
+    w = capture(small, 5)
+    assert small.arena._block.numel() == 11 * step_bytes and small.arena.reserved.numel() == 4 * step_bytes
+    assert small.arena.total_bytes == 12 * step_bytes
+    for s in range(5):
+        check_step(small, s, w)
+
+
+def test_a_step_that_outgrows_its_staging_slab_is_refused():
+    store = AS.AttentionStore(disk_store=True, hbm_budget_bytes=0)
+    capture(store, 2)
+    for key, f, h, lq, lk, is_cross in LAYERS:
+        store.new_slot(key, f, h, lq, lk, is_cross, torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="overflows its staging slab"):
+        store.new_slot("up_self", 2, 4, 64, 128, False, torch.device("cpu"))
+
+
 def test_release_returns_the_host_slabs_to_the_pool():
     store = AS.AttentionStore(disk_store=True, hbm_budget_bytes=0)
     capture(store, 5)
