@@ -70,10 +70,11 @@ FZ_GEMM_NO_STATS = 1
 _P = C.c_void_p
 _SIGS = {
     "fz_gemm": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
-    "fz_ln_gemm_ok": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
-    "fz_ln_gemm_preferred": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
-    "fz_ln_gemm": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
-    "fz_ln_gemm_qkvt": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
+    "fz_ff_chain_ok": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
+    "fz_ff_chain_preferred": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
+    "fz_ff_chain_pack_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "fz_ff_chain_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "fz_ff_chain": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "fz_gemm_lnout": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int64, _P, _P]),
     "fz_gemm_ln": (C.c_int, [C.POINTER(FzGemmDesc), C.POINTER(FzGemmLn), _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_gemm_qkvt": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),

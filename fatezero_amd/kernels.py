@@ -623,87 +623,63 @@ def gemm_vt(x: torch.Tensor, w: torch.Tensor, lp: int, out: Optional[torch.Tenso
 
 
 # ------------------------------------------------------------------------------------------------------------
-# LayerNorm + projection in one launch (csrc/rowgemm.hip): the 320-channel rows of the 64x64 level
+# The FeedForward chain of the 64x64 level in one launch (csrc/ff_chain.hip)
 # ------------------------------------------------------------------------------------------------------------
-def ln_gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
-    """Shapes fz_ln_gemm carries: K = 320 (whole rows in a workgroup), output columns a multiple of 320, unit channel stride, one row stride."""
-    k = x.shape[-1]
-    return (x.dtype == torch.float16 and w.dtype == torch.float16 and x.stride(-1) == 1 and w.stride(-1) == 1 and w.shape[-1] == k and
-            bool(N.lib().fz_ln_gemm_ok(x.numel() // k, k, w.shape[0])))
+def ff_chain_ok(rows: int, channels: int, inner: int) -> bool:
+    return bool(N.lib().fz_ff_chain_ok(rows, channels, inner))
 
 
-def ln_gemm_preferred(x: torch.Tensor, w: torch.Tensor) -> bool:
-    """... and where that launch is also the faster form on MI355X (the rows fill the chip with 128-row workgroups)."""
-    k = x.shape[-1]
-    return ln_gemm_ok(x, w) and bool(N.lib().fz_ln_gemm_preferred(x.numel() // k, k, w.shape[0]))
+def ff_chain_preferred(rows: int, channels: int, inner: int) -> bool:
+    """Is the one launch the faster form on MI355X for this shape (fz_ff_chain_preferred)?"""
+    return bool(N.lib().fz_ff_chain_preferred(rows, channels, inner))
 
 
-def _row_stride(t):
-    for d in range(t.dim() - 2):
-        assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "one row stride"
-    return t.stride(-2) if t.dim() > 1 else t.shape[-1]
-
-
-def ln_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ln=None, res: Optional[torch.Tensor] = None,
-            res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """y = LN(x) @ w^T + bias (+ res) (+ res2) in ONE launch (fz_ln_gemm); ln = (gamma, beta, eps) fp16 vectors, or None for a plain
-    projection through the same row-streaming kernel.  x [..., 320], w [O, 320] with O % 320 == 0."""
-    k, o = x.shape[-1], w.shape[0]
-    rows = x.numel() // k
-    _chk16(x, w, bias, res, res2, out)
-    if out is None:
-        out = torch.empty(tuple(x.shape[:-1]) + (o,), dtype=torch.float16, device=x.device)
-    d = N.FzGemmDesc()
-    d.rows, d.in_features, d.out_features = rows, k, o
-    d.ldx, d.ldw, d.ldy = _row_stride(x), w.stride(0), _row_stride(out)
-    d.batch, d.epilogue = 1, N.FZ_GEMM_PLAIN
-    for r in (res, res2):
-        if r is not None:
-            assert r.dtype == torch.float16 and r.shape[-1] == o and r.stride(-1) == 1 and r.numel() // o == rows
-            d.ldres = _row_stride(r)
-    if res is not None and res2 is not None:
-        assert _row_stride(res) == _row_stride(res2)
-    g = b = None
-    eps = 0.0
-    if ln is not None:
-        g, b, eps = ln
-        assert g.dtype == b.dtype == torch.float16 and g.numel() == b.numel() == k and g.is_contiguous() and b.is_contiguous()
-    rc = N.lib().fz_ln_gemm(C.byref(d), x.data_ptr(), _ptr(g), _ptr(b), float(eps), w.data_ptr(), _ptr(bias), _ptr(res), _ptr(res2),
-                            out.data_ptr(), _stream(x))
+def ff_chain_pack(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor) -> torch.Tensor:
+    """GEGLU projection weight w1 [2 inner, C] (rows [val ; gate], diffusers GEGLU.proj), its bias b1 [2 inner] (or None) and the output
+    projection w2 [C, inner] -> the operand-fragment stream fz_ff_chain reads (uint8, on w1's device).  Pack once per weight set."""
+    two, c = w1.shape
+    inner = two // 2
+    if two % 2 or tuple(w2.shape) != (c, inner) or not ff_chain_ok(1, c, inner):
+        raise ValueError(f"fz_ff_chain_pack: w1 [2 inner, 320] / w2 [320, inner] with inner % 32 == 0, got {tuple(w1.shape)} / {tuple(w2.shape)}")
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    b1 = None if b1 is None else b1.contiguous()
+    for t in (w1, b1, w2):
+        if t is not None and t.dtype != torch.float16:
+            raise ValueError("fz_ff_chain_pack: fp16 operands")
+    _chk16(w1, b1, w2)
+    out = torch.empty(N.lib().fz_ff_chain_pack_bytes(c, inner), dtype=torch.uint8, device=w1.device)
+    rc = N.lib().fz_ff_chain_pack(w1.data_ptr(), _ptr(b1), w2.data_ptr(), out.data_ptr(), c, inner, _stream(w1))
     if rc:
-        N.check(rc, "fz_ln_gemm")
+        N.check(rc, "fz_ff_chain_pack")
     return out
 
 
-def ln_gemm_qkvt_ok(x: torch.Tensor, w: torch.Tensor, split: int) -> bool:
-    return x.dim() == 3 and ln_gemm_ok(x, w) and split % 320 == 0 and 0 < split < w.shape[0] and x.shape[1] % 32 == 0
-
-
-def ln_gemm_qkvt(x: torch.Tensor, w: torch.Tensor, split: int, *, ln=None):
-    """LayerNorm + the q | k | V^T projection of a self-attention in ONE launch (fz_ln_gemm_qkvt): x [N, L, 320] raw rows, w [split + Cv, 320]
-    -> (y [N, L, split] = LN(x) @ w[:split]^T,  vt [N, Cv, L] = w[split:] @ LN(x[n])^T)."""
-    n, l, k = x.shape
-    o = w.shape[0]
-    cv = o - split
-    if not ln_gemm_qkvt_ok(x, w, split) or x.stride(0) != l * x.stride(1):
-        raise ValueError("fz_ln_gemm_qkvt: x [N, L, 320] with L % 32 == 0 and a single row stride, w [split + Cv, 320], split % 320 == 0")
-    _chk16(x, w)
-    d = N.FzGemmDesc()
-    d.rows, d.in_features, d.out_features = n * l, k, o
-    d.ldx, d.ldw, d.ldy = x.stride(1), w.stride(0), split
-    d.batch, d.epilogue = 1, N.FZ_GEMM_PLAIN
-    g = b = None
+def ff_chain(xn: torch.Tensor, packed: torch.Tensor, b2: Optional[torch.Tensor], inner: int, *, res: Optional[torch.Tensor] = None, ln=None):
+    """y = Linear2(val * gelu(gate)) + b2 (+ res) with val | gate = xn W1^T + b1, and LayerNorm(y) when ln = (gamma, beta, eps) is given, in
+    ONE launch (fz_ff_chain); xn / res: [..., 320] fp16 contiguous, `packed` from ff_chain_pack.  Returns (y, y_ln or None)."""
+    c = xn.shape[-1]
+    rows = xn.numel() // c
+    if xn.dtype != torch.float16 or not xn.is_contiguous() or (res is not None and (res.dtype != torch.float16 or not res.is_contiguous()
+                                                                                    or res.shape != xn.shape)):
+        raise ValueError("fz_ff_chain: xn / res must be contiguous fp16 tensors of one shape")
+    if packed.numel() != N.lib().fz_ff_chain_pack_bytes(c, inner):
+        raise ValueError("fz_ff_chain: `packed` is not the stream of ff_chain_pack for these sizes")
+    gam = bet = None
     eps = 0.0
     if ln is not None:
-        g, b, eps = ln
-        assert g.dtype == b.dtype == torch.float16 and g.numel() == b.numel() == k
-    y = torch.empty(n, l, split, dtype=torch.float16, device=x.device)
-    vt = torch.empty(n, cv, l, dtype=torch.float16, device=x.device)
-    rc = N.lib().fz_ln_gemm_qkvt(C.byref(d), x.data_ptr(), _ptr(g), _ptr(b), float(eps), w.data_ptr(), y.data_ptr(), vt.data_ptr(), split, l,
-                                 cv * l, l, _stream(x))
+        gam, bet, eps = ln
+        if gam.dtype != torch.float16 or bet.dtype != torch.float16:
+            raise ValueError("fz_ff_chain: LayerNorm weight / bias must be fp16")
+    _chk16(xn, b2, res, gam, bet)
+    if packed.data_ptr() % 16 or packed.dtype != torch.uint8:
+        raise ValueError("fz_ff_chain: `packed` must be the 16-byte aligned uint8 stream of ff_chain_pack")
+    y = torch.empty_like(xn)
+    yln = torch.empty_like(xn) if ln is not None else None
+    rc = N.lib().fz_ff_chain(xn.data_ptr(), packed.data_ptr(), _ptr(b2), _ptr(res), y.data_ptr(), _ptr(gam), _ptr(bet), float(eps), _ptr(yln),
+                             rows, c, inner, _stream(xn))
     if rc:
-        N.check(rc, "fz_ln_gemm_qkvt")
-    return y, vt
+        N.check(rc, "fz_ff_chain")
+    return y, yln
 
 
 _qkvt_plans = {}

@@ -76,6 +76,10 @@ LN_FUSION_MAX_C = 640  # wider rows (K = 1280) want split-K in the consuming GEM
 # (one wave per row) was built and measured a LOSS for the job (profiles/r05_ln_from_producer_ab.txt).
 LN_FROM_PRODUCER = os.environ.get("FZ_NO_LN_FROM_PRODUCER") is None
 LN_FROM_PRODUCER_C = 320
+# The whole feed-forward CHAIN of a 320-channel block in ONE launch (fz_ff_chain, round 6): GEGLU up-projection -> gate -> down-projection +
+# residual + norm_temporal, the rows x 1280 intermediate in registers only, the weights streamed as pre-packed MFMA fragments.  Bit-identical
+# to fz_gemm(GEGLU) + fz_gemm_lnout; used where fz_ff_chain_preferred says the one launch is the faster form.  (env switch: same-box A/B runs)
+FF_CHAIN = os.environ.get("FZ_NO_FF_CHAIN") is None
 
 
 class Prenormed:
@@ -402,6 +406,22 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([_GEGLU(dim, dim * mult), nn.Identity(), _LinearParams(dim * mult, dim)])
         self._ln_fold = None
+        self._chain = None  # (device, fz_ff_chain's packed weight stream, b2)
+
+    def _chain_pack(self, device):
+        if self._chain is None or self._chain[0] != device:
+            g, lin = self.net[0], self.net[2]
+            w1 = g.proj.weight.detach().to(device=device, dtype=torch.float16)
+            b1 = None if g.proj.bias is None else g.proj.bias.detach().to(device=device, dtype=torch.float16)
+            w2 = lin.weight.detach().to(device=device, dtype=torch.float16)
+            b2 = None if lin.bias is None else lin.bias.detach().to(device=device, dtype=torch.float16).contiguous()
+            self._chain = (device, K.ff_chain_pack(w1, b1, w2), b2)
+        return self._chain[1], self._chain[2]
+
+    def load_state_dict(self, *a, **k):  # the packed stream must follow the parameters
+        self._chain = None
+        self._ln_fold = None
+        return super().load_state_dict(*a, **k)
 
     def apply(self, x, res=None, norm=None, stats=None, want_stats=False, ln_next=None):
         """res + Linear(h * gelu(gate)): the 8C-wide GEGLU intermediate is never written (gate applied in the epilogue of the
@@ -413,6 +433,16 @@ class FeedForward(nn.Module):
             x, norm, stats = stats.t, None, None
         if norm is not None and not (fused and _ln_ready(norm, stats, x)):
             x, norm = layer_norm_tokens(norm, x), None
+        inner = g.proj.weight.shape[0] // 2
+        if (FF_CHAIN and norm is None and not want_stats and x.dtype == torch.float16 and x.is_contiguous() and (res is None or res.is_contiguous())
+                and D.active_shard() is None and K.ff_chain_preferred(x.numel() // x.shape[-1], x.shape[-1], inner)):
+            packed, b2 = self._chain_pack(x.device)
+            ln = None
+            if ln_next is not None:
+                gam, bet = ln_next.packed(x.device)
+                ln = (gam, bet, ln_next.eps)
+            y, yln = K.ff_chain(x, packed, b2, inner, res=res, ln=ln)
+            return y, (None if yln is None else Prenormed(yln))
         if norm is not None:
             if getattr(self, "_ln_fold", None) is None or self._ln_fold[0] is not norm or self._ln_fold[1].w.device != x.device:
                 self._ln_fold = (norm, K.LnFold(g.proj.weight, g.proj.bias, norm.weight, norm.bias, norm.eps, x.device,

@@ -207,25 +207,20 @@ int fz_gemm(const FzGemmDesc* desc, const void* x, const void* w, const void* bi
 int fz_gemm_qkvt(const FzGemmDesc* desc, const void* x, const void* w, void* y, void* yt, int split_col, int64_t rows_per_frame,
                  int64_t yt_frame_stride, int64_t ldyt, void* stream);
 
-/* LayerNorm + projection in ONE launch for the 320-channel rows of the 64x64 level (csrc/rowgemm.hip): the `x = attn(norm(x)) + x` steps of
- * SpatioTemporalTransformerBlock.forward (attention.py:295-337) start with LayerNorm -> Linear(s) on the same rows -- norm1 -> to_q | to_k |
- * to_v (attention.py:340-372), norm2 -> attn2.to_q (attention_register.py:71-80), norm_temporal -> attn_temporal.to_q | to_k | to_v
- * (attention.py:327-337).  A workgroup holds 128 WHOLE rows in LDS and a 320-column slice of w in registers:
- *   xn = gamma == NULL ? x : LayerNorm(x; gamma, beta, eps)    (fp32 two-sweep statistics, rounded to fp16 as fz_layernorm stores it)
- *   y[row][o] = sum_i xn[row][i] * w[o][i] + bias[o] (+ res[row][o]) (+ res2[row][o])
- * desc: rows, in_features == 320, out_features % 320 == 0 (<= 3840), ldx, ldw, ldy, ldres; plain epilogue, no batch.  fz_ln_gemm_ok: 1 where
- * the launch exists; fz_ln_gemm_preferred: 1 where it is also the faster form on MI355X -- measured: nowhere by a useful margin (1.14-1.22x
- * with the LayerNorm fused at 8 frames, 0.76-1.05x elsewhere: profiles/r05_rowgemm_negative_result.txt), so it returns 0 and the model keeps
- * fz_layernorm + fz_gemm / fz_gemm_qkvt.
- * gamma == NULL makes it a plain projection (the out-projections + residual, proj_in), same launch.
- * fz_ln_gemm_qkvt: the same with fz_gemm_qkvt's output contract -- columns [0, split_col) token-major in y, columns >= split_col as
- * V^T in yt; split_col % 320 == 0, rows_per_frame % 32 == 0. */
-int fz_ln_gemm_ok(int64_t rows, int in_features, int out_features);
-int fz_ln_gemm_preferred(int64_t rows, int in_features, int out_features);
-int fz_ln_gemm(const FzGemmDesc* desc, const void* x, const void* gamma, const void* beta, float eps, const void* w, const void* bias,
-               const void* res, const void* res2, void* y, void* stream);
-int fz_ln_gemm_qkvt(const FzGemmDesc* desc, const void* x, const void* gamma, const void* beta, float eps, const void* w, void* y, void* yt,
-                    int split_col, int64_t rows_per_frame, int64_t yt_frame_stride, int64_t ldyt, void* stream);
+/* The FeedForward CHAIN of the 64x64-level transformer block in ONE launch (csrc/ff_chain.hip): `ff(norm3(x)) + x` and the LayerNorm that
+ * consumes it (attention.py:312-321, 327-331; ff = diffusers FeedForward [GEGLU(dim, 4 dim), Linear(4 dim, dim)] [3P]):
+ *   val | gate = xn W1^T + b1 ;  h = val * gelu_erf(gate) ;  y = h W2^T + b2 (+ res) ;  y_ln = LayerNorm(y; gamma, beta, eps)  (y_ln may be NULL)
+ * xn, res, y, y_ln: [rows][channels] fp16, contiguous rows; channels == 320; inner % 32 == 0 (SD-1.x: 1280).  The rows x inner intermediate
+ * never exists outside registers.  Weights come PRE-PACKED: fz_ff_chain_pack writes W1 [2 inner][channels] (rows [val ; gate], diffusers
+ * GEGLU.proj), b1 [2 inner] (or NULL) and W2 [channels][inner] into `packed` (fz_ff_chain_pack_bytes bytes, 16-byte aligned) as the MFMA
+ * operand fragments the kernel streams; pack once per weight set.  Results are bit-identical to fz_gemm(FZ_GEMM_GEGLU) + fz_gemm_lnout.
+ * fz_ff_chain_ok: 1 where the launch exists; fz_ff_chain_preferred: 1 where it is also the faster form on MI355X. */
+int fz_ff_chain_ok(int64_t rows, int channels, int inner);
+int fz_ff_chain_preferred(int64_t rows, int channels, int inner);
+int64_t fz_ff_chain_pack_bytes(int channels, int inner);
+int fz_ff_chain_pack(const void* w1, const void* b1, const void* w2, void* packed, int channels, int inner, void* stream);
+int fz_ff_chain(const void* xn, const void* packed, const void* b2, const void* res, void* y, const void* ln_gamma, const void* ln_beta,
+                float ln_eps, void* y_ln, int64_t rows, int channels, int inner, void* stream);
 
 /* LayerNorm fused around fz_gemm (the `norm2 / norm3 / norm_temporal` + Linear pairs of SpatioTemporalTransformerBlock,
  * attention.py:295-337: `attn(norm(x)) + x`).  Two independent halves:

@@ -1,0 +1,15 @@
+# variants of ff_chain only: compile that one file with the flag, link with the shipped objects of the others
+set -e
+mkdir -p build_tmp/ffv
+mk() { name=$1; shift
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Iinclude "$@" -c fatezero_amd/csrc/ff_chain.hip -o build_tmp/ffv/ff_$name.o 2>/dev/null
+  objs=$(ls fatezero_amd/build/hip/*.o | grep -v ff_chain)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_tmp/libfz_ff_$name.so build_tmp/ffv/ff_$name.o $objs
+}
+mk nodma -DFC_TRIAL_NODMA &
+mk burst -DFC_TRIAL_DMA_BURST &
+
+mk nogelu -DFZ_GELU_TRIAL_IDENTITY &
+
+wait
+ls -la build_tmp/libfz_ff_*.so

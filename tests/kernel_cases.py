@@ -591,67 +591,63 @@ def case_gemm_lnout(device, *, rows, k, n_res=1, bias=True, seed=0, mean_shift=0
     return {"vs_torch": e_t, "vs_layernorm_kernel": e_k}
 
 
-def case_ln_gemm(device, *, rows, o, ln=True, bias=True, n_res=0, seed=0, ldx_extra=0, lead=None, mean_shift=0.0):
-    """fz_ln_gemm (csrc/rowgemm.hip): LayerNorm + Linear (+ bias, residuals) in one launch, K = 320, vs fp32 torch with LN(x) rounded to
-    fp16 (what fz_layernorm stores and the GEMM then reads), and vs the two launches it replaces (fz_layernorm + fz_gemm) to a few fp16 ulp."""
+def case_ff_chain(device, *, rows, inner=1280, bias=True, res=True, ln=True, seed=0, lead=None, exact=True):
+    """fz_ff_chain (csrc/ff_chain.hip): GEGLU up-projection -> gate -> down-projection + residual + LayerNorm in ONE launch, C = 320.
+    BIT-IDENTICAL to the two launches it replaces (fz_gemm with the GEGLU epilogue + fz_gemm_lnout: same MFMA, same k order, same roundings)
+    and within fp16 rounding of fp32 torch (h rounded to fp16 as the two-launch form stores it)."""
     g = torch.Generator().manual_seed(seed)
-    k = 320
-    xfull = (torch.randn(rows, k + ldx_extra, generator=g) * 1.5 + mean_shift).half().to(device)
-    x = xfull[:, ldx_extra:] if ldx_extra else xfull
-    w = (torch.randn(o, k, generator=g) * k ** -0.5).half()
-    b = (torch.randn(o, generator=g) * 0.3).half() if bias else None
-    gamma = (1.0 + 0.2 * torch.randn(k, generator=g)).half()
-    beta = (0.1 * torch.randn(k, generator=g)).half()
-    res = [torch.randn(rows, o, generator=g).half().to(device) for _ in range(n_res)]
-    eps = 1e-5
-    xin = x if lead is None else x.reshape(*lead, k)
-    assert K.ln_gemm_ok(xin, w.to(device))
-    y = K.ln_gemm(xin, w.to(device), None if b is None else b.to(device), ln=(gamma.to(device), beta.to(device), eps) if ln else None,
-                  res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None).reshape(rows, o)
-    xc = x.float().cpu()
-    xn = F.layer_norm(xc, (k,), gamma.float(), beta.float(), eps).half().float() if ln else xc
-    ref = xn @ w.float().t()
+    c = 320
+    xn = (torch.randn(rows, c, generator=g) * 1.2).half()
+    w1 = (torch.randn(2 * inner, c, generator=g) * c ** -0.5).half()
+    b1 = (torch.randn(2 * inner, generator=g) * 0.3).half() if bias else None
+    w2 = (torch.randn(c, inner, generator=g) * inner ** -0.5).half()
+    b2 = (torch.randn(c, generator=g) * 0.3).half() if bias else None
+    r = (torch.randn(rows, c, generator=g) * 1.5).half() if res else None
+    gamma = (1.0 + 0.2 * torch.randn(c, generator=g)).half()
+    beta = (0.1 * torch.randn(c, generator=g)).half()
+    dev = lambda t: None if t is None else t.to(device)
+    assert K.ff_chain_ok(rows, c, inner)
+    packed = K.ff_chain_pack(dev(w1), dev(b1), dev(w2))
+    xin = dev(xn) if lead is None else dev(xn).reshape(*lead, c)
+    rin = None if r is None else (dev(r) if lead is None else dev(r).reshape(*lead, c))
+    y, yln = K.ff_chain(xin, packed, dev(b2), inner, res=rin, ln=(dev(gamma), dev(beta), 1e-5) if ln else None)
+    assert y.shape == xin.shape and (yln is None) == (not ln)
+    y = y.reshape(rows, c)
+    # fp32 torch with the one rounding the chain shares with the reference's fp16 autocast: h is an fp16 tensor
+    u = xn.float() @ w1.float().t()
     if bias:
-        ref = ref + b.float()
-    for r in res:
-        ref = ref + r.float().cpu()
+        u = u + b1.float()
+    h = (u[:, :inner] * F.gelu(u[:, inner:])).half().float()
+    ref = h @ w2.float().t()
+    if bias:
+        ref = ref + b2.float()
+    if res:
+        ref = ref + r.float()
     scale = max(1.0, float(ref.abs().max()))
     err = float((y.float().cpu() - ref).abs().max())
     assert torch.isfinite(y.float()).all() and err < 4e-3 * scale, (err, scale)
+    out = {"max_err": err}
+    if ln:
+        lref = F.layer_norm(y.float().cpu(), (c,), gamma.float(), beta.float(), 1e-5)
+        e_ln = float((yln.reshape(rows, c).float().cpu() - lref).abs().max())
+        assert e_ln < 2e-3 * max(1.0, float(lref.abs().max())), e_ln
+        out["ln_vs_torch"] = e_ln
     # the two launches it replaces
-    xn_dev = K.layernorm(x.contiguous(), gamma.to(device), beta.to(device), eps=eps) if ln else x
-    y2 = K.gemm(xn_dev, w.to(device), None if b is None else b.to(device), res=res[0] if n_res > 0 else None, res2=res[1] if n_res > 1 else None)
-    e2 = float((y.float() - y2.float()).abs().max())
-    assert e2 <= 4 * 2.0 ** -10 * scale, (e2, scale)
-    return {"max_err": err, "vs_two_launches": e2}
-
-
-def case_ln_gemm_qkvt(device, *, n, l, c=320, ln=True, seed=0):
-    """fz_ln_gemm_qkvt: LayerNorm + q | k | V^T in one launch vs fp32 torch and vs fz_layernorm + fz_gemm_qkvt."""
-    g = torch.Generator().manual_seed(seed)
-    k = 320
-    x = (torch.randn(n, l, k, generator=g) * 1.2 + 0.3).half().to(device)
-    w = (torch.randn(3 * c, k, generator=g) * k ** -0.5).half().to(device)
-    gamma = (1.0 + 0.2 * torch.randn(k, generator=g)).half().to(device)
-    beta = (0.1 * torch.randn(k, generator=g)).half().to(device)
-    eps = 1e-5
-    assert K.ln_gemm_qkvt_ok(x, w, 2 * c)
-    qk, vt = K.ln_gemm_qkvt(x, w, 2 * c, ln=(gamma, beta, eps) if ln else None)
-    assert qk.shape == (n, l, 2 * c) and vt.shape == (n, c, l)
-    xc = x.float().cpu()
-    xn = F.layer_norm(xc, (k,), gamma.float().cpu(), beta.float().cpu(), eps).half().float() if ln else xc
-    ref = xn @ w.float().cpu().t()
-    scale = max(1.0, float(ref.abs().max()))
-    e_qk = float((qk.float().cpu() - ref[..., : 2 * c]).abs().max())
-    e_vt = float((vt.float().cpu() - ref[..., 2 * c:].transpose(1, 2)).abs().max())
-    assert e_qk < 4e-3 * scale and e_vt < 4e-3 * scale, (e_qk, e_vt, scale)
-    res = {"qk_err": e_qk, "vt_err": e_vt}
-    if K.gemm_qkvt_ok(x, w, 2 * c):
-        xn_dev = K.layernorm(x, gamma, beta, eps=eps) if ln else x
-        qk2, vt2 = K.gemm_qkvt(xn_dev, w, 2 * c)
-        res["vs_two_launches"] = max(float((qk.float() - qk2.float()).abs().max()), float((vt.float() - vt2.float()).abs().max()))
-        assert res["vs_two_launches"] <= 4 * 2.0 ** -10 * scale, res
-    return res
+    wp, bp = K.pack_geglu(dev(w1), dev(b1))
+    h2 = K.gemm(dev(xn), wp, bp, geglu=True, split_k=1)   # (split_k=1: one fp32 accumulation chain over k ascending, as the chain kernel's)
+    if ln:
+        y2, yln2 = K.gemm_lnout(h2, dev(w2), dev(b2), (dev(gamma), dev(beta), 1e-5), res=dev(r), split_k=1)
+    else:
+        y2, yln2 = K.gemm(h2, dev(w2), dev(b2), res=dev(r), split_k=1), None
+    d = float((y.float() - y2.float()).abs().max())
+    out["vs_two_launches"] = d
+    if exact:
+        assert torch.equal(y, y2), d
+        if ln and yln2 is not None:
+            assert torch.equal(yln.reshape(rows, c), yln2)
+    else:
+        assert d <= 2 * 2.0 ** -10 * scale, (d, scale)
+    return out
 
 
 def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, producer="tconv", seed=0):

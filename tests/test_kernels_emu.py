@@ -323,20 +323,47 @@ def test_layernorm_out_of_the_producing_gemm_epilogue():
     assert KC.case_gemm_lnout(DEV, rows=100, k=512, n_res=1, seed=5, tile_cfg=212222, split_k=4, expect=False) is None   # split-K: reports it
 
 
-def test_layernorm_plus_projection_in_one_launch():
-    """csrc/rowgemm.hip on the emulator: 128-row workgroups (whole and ragged last one), one and several 320-column passes, LayerNorm on /
-    off, bias, one / two residuals, a strided x view, rows with a large mean (two-sweep statistics)."""
-    KC.case_ln_gemm(DEV, rows=256, o=320, n_res=1)
-    KC.case_ln_gemm(DEV, rows=200, o=640, n_res=2, ldx_extra=8, seed=1)
-    KC.case_ln_gemm(DEV, rows=128, o=320, ln=False, bias=True, n_res=1, seed=2)
-    KC.case_ln_gemm(DEV, rows=40, o=960, bias=False, lead=(5, 8), mean_shift=6.0, seed=3)
+def test_feed_forward_module_takes_the_chain_launch(monkeypatch):
+    """models/attention.py FeedForward.apply at 320 channels: with fz_ff_chain preferred the module issues ONE launch and returns (y, the
+    LayerNorm of y as a Prenormed); same numbers as the GEGLU + output-projection launches (their split-K choice at this tiny row count may
+    round h differently: a few fp16 ulp)."""
+    from fatezero_amd.video_diffusion.models import attention as A
+    from fatezero_amd.video_diffusion.models.resnet import _NormParams
+    torch.manual_seed(3)
+    ff, norm = A.FeedForward(320), _NormParams(320)
+    with torch.no_grad():
+        ff.net[0].proj.bias.normal_(0, 0.2)
+        ff.net[2].bias.normal_(0, 0.2)
+        norm.weight.normal_(1, 0.2)
+        norm.bias.normal_(0, 0.1)
+    x = torch.randn(2, 64, 320).half()
+    xn = torch.nn.functional.layer_norm(x.float(), (320,)).half()
+    log = []
+    real = K.ff_chain
+    monkeypatch.setattr(K, "ff_chain", lambda *a, **k: (log.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(K, "ff_chain_preferred", lambda rows, c, inner: K.ff_chain_ok(rows, c, inner))
+    y1, st1 = ff.apply(x, res=x, stats=A.Prenormed(xn), ln_next=norm)
+    assert log == [1] and isinstance(st1, A.Prenormed)
+    monkeypatch.setattr(A, "FF_CHAIN", False)
+    y0, st0 = ff.apply(x, res=x, stats=A.Prenormed(xn), ln_next=norm)
+    assert log == [1]
+    scale = float(y0.float().abs().max())
+    assert float((y1.float() - y0.float()).abs().max()) <= 2 * 2.0 ** -10 * scale
+    ln0 = st0.t if isinstance(st0, A.Prenormed) else K.layernorm(y0, *norm.packed(x.device), eps=norm.eps)
+    assert float((st1.t.float() - ln0.float()).abs().max()) <= 8 * 2.0 ** -10 * max(1.0, float(ln0.float().abs().max()))
+    # a new weight set re-packs the stream
+    ff2 = A.FeedForward(320)
+    assert ff2._chain is None and ff._chain is not None
 
 
-def test_layernorm_plus_qkvt_in_one_launch():
-    r = KC.case_ln_gemm_qkvt(DEV, n=3, l=64)
-    assert "vs_two_launches" in r
-    KC.case_ln_gemm_qkvt(DEV, n=2, l=96, ln=False, seed=1)   # 96 tokens per frame: a 128-row workgroup spans two frames mid sub-tile? no: 32 | 96
-    KC.case_ln_gemm_qkvt(DEV, n=1, l=160, seed=2)             # ragged last workgroup
+def test_feed_forward_chain_in_one_launch():
+    """csrc/ff_chain.hip on the emulator: 128-row workgroups (whole, several, ragged last one), with / without bias, residual, LayerNorm; a
+    small `inner` walks the stage ring's first / last iterations; bit-identical to fz_gemm(GEGLU) + fz_gemm_lnout."""
+    r = KC.case_ff_chain(DEV, rows=128, inner=64)
+    assert r["vs_two_launches"] == 0.0
+    KC.case_ff_chain(DEV, rows=200, inner=96, seed=1, lead=(5, 40))
+    KC.case_ff_chain(DEV, rows=40, inner=32, bias=False, res=False, ln=False, seed=2)
+    KC.case_ff_chain(DEV, rows=300, inner=1280, seed=3)
 
 
 def test_gemm_transposed_output():

@@ -314,15 +314,14 @@ def test_layernorm_out_of_the_producing_gemm_epilogue():
     assert KC.case_gemm_lnout(DEV, rows=512, k=1280, n_res=1, expect=False) is None   # 8x8 level rows: small tiles / split-K: reports it
 
 
-def test_layernorm_plus_projection_in_one_launch():
-    """csrc/rowgemm.hip at the 64x64-level shapes (8 / 16 frames x 4096 tokens x 320): LayerNorm + Linear (+ bias, residuals), several
-    320-column passes, a ragged last workgroup, LayerNorm + q | k | V^T -- vs fp32 torch and vs the launches it would replace."""
-    print(KC.case_ln_gemm(DEV, rows=32768, o=320, n_res=1))
-    print(KC.case_ln_gemm(DEV, rows=4096 * 3 + 200, o=640, n_res=2, seed=1))
-    print(KC.case_ln_gemm(DEV, rows=65536, o=320, ln=False, bias=True, n_res=1, seed=2))
-    print(KC.case_ln_gemm(DEV, rows=32768, o=960, bias=False, mean_shift=6.0, seed=3))
-    print(KC.case_ln_gemm_qkvt(DEV, n=8, l=4096))
-    print(KC.case_ln_gemm_qkvt(DEV, n=16, l=4096, ln=False, seed=1))
+def test_feed_forward_chain_in_one_launch():
+    """csrc/ff_chain.hip at the 64x64-level shapes (8 / 16 frames x 4096 tokens x 320, inner 1280): bit-identical to the two launches it
+    replaces, within fp16 rounding of fp32 torch; a ragged row count; no bias / residual / LayerNorm."""
+    print(KC.case_ff_chain(DEV, rows=32768))
+    print(KC.case_ff_chain(DEV, rows=65536, seed=1))
+    print(KC.case_ff_chain(DEV, rows=4096 * 3 + 200, seed=2))
+    print(KC.case_ff_chain(DEV, rows=8192, bias=False, res=False, ln=False, seed=3))
+    print(KC.case_ff_chain(DEV, rows=1000, inner=96, seed=4))
 
 
 def test_gemm_transposed_output():
