@@ -387,9 +387,11 @@ struct Plan {
     std::vector<uint64_t> args;   // (uint64_t: the relocation pass walks pointer-sized, pointer-aligned words)
 };
 
-inline Plan* g_recording = nullptr;   // the plan being recorded by this process (nullptr: none) -- ONE issuing thread, as the host layer has
-                                      // (a C++17 inline variable: one object for all translation units of the library, and the stand-alone
-                                      //  trial programs under scripts/ that include a kernel file link without csrc/plan.hip)
+inline thread_local Plan* g_recording = nullptr;   // the plan THIS THREAD is recording (nullptr: none).  Thread-local: the library keeps no
+                                                   // process-wide state -- a recording belongs to the thread that called fz_plan_begin, launches
+                                                   // other threads make meanwhile are issued and not recorded.  (a C++17 inline variable: one
+                                                   // object per thread for all translation units of the library, and the stand-alone trial
+                                                   // programs under scripts/ that include a kernel file link without csrc/plan.hip)
 
 // the arguments of one launch as an aggregate of the kernel's own parameter types: trivially copyable, pointers at their natural alignment
 template <typename... P> struct Args;

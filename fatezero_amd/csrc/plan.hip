@@ -32,7 +32,7 @@ static void fz_node_params(FzPlan* p, size_t i, hipKernelNodeParams* kp, void** 
 #endif
 
 extern "C" int fz_plan_begin(FzPlan** out) {
-    if (out == nullptr || fz_plan::g_recording != nullptr) return FZ_ERR_BAD_ARG;  // one recording at a time
+    if (out == nullptr || fz_plan::g_recording != nullptr) return FZ_ERR_BAD_ARG;  // one recording at a time per thread
     FzPlan* p = new FzPlan();
     fz_plan::g_recording = &p->plan;
     *out = p;

@@ -22,9 +22,13 @@ pointers differs between steps.  `IssuePlans.run` therefore
      all its calls are taken first and the whole launch list goes out as ONE hipGraph launch (`fz_plan_graph_launch`: kernel nodes in
      record order, the relocated ones refreshed with hipGraphExecKernelNodeSetParams).
 
-Every buffer the records point into was allocated by the recorded forward.  On the GPU those allocations come from a private
-`torch.cuda.MemPool` shared by all plans of a process (blocks freed during the forward are reused inside it exactly as the recording saw,
-and never handed to anyone else); without one (the CPU emulation backend of the tests) the plan keeps every allocation of its forward alive.
+The buffers the records point into are (a) the recorded forward's own allocations -- on the GPU out of a private `torch.cuda.MemPool`
+shared by all plans of a process (blocks freed during the forward are reused inside it exactly as the recording saw, and never handed to
+anyone else); without one (the CPU emulation backend of the tests) the plan keeps every allocation of its forward alive -- and (b) the
+process-wide scratch of the launch stream (split-K slabs, GroupNorm partials: `kernels.scratch_buffers`), which the plan holds references to;
+a plan is keyed on the launch stream and on `kernels.scratch_generation()`: when the scratch was regrown or evicted since, the forward is
+recorded again.  INVARIANT of the shared pool: persistent buffers (context K / V^T, weight packs, scratch) must exist before the recording --
+the warm-up walk is there to create them -- because a block the pool hands out later can alias what an older plan's replay overwrites.
 A torch *compute* op inside the recorded part of the forward would not be re-issued by a replay: a dispatch mode watches the recording and
 such a forward is never replayed (`IssuePlans.stats["unrecordable"]` says which op).
 
@@ -126,6 +130,11 @@ class _Recording:
         return plan
 
 
+class PlanMismatch(RuntimeError):
+    """A replay met a forward its plan does not describe (another kind of controller step, a tensor of another size, an argument word
+    that is not the pointer it was taken for)."""
+
+
 _recording = None  # the forward being recorded (attention._plan_for looks here)
 ENABLED = True     # same-box A/B runs (scripts/ab_bench.py fatezero_amd.issue ENABLED): False -> every forward is walked
 
@@ -144,8 +153,10 @@ def _model_switches():
 class ForwardPlan:
     """A recorded forward: the native plan, its events, the tensors it must keep alive and its output."""
 
-    def __init__(self, handle, events, keep, out, inputs, n_launches, ctx_kv):
+    def __init__(self, handle, events, keep, out, inputs, n_launches, ctx_kv, scratch=()):
         self.handle, self.events, self.keep, self.out = handle, events, keep, out
+        self.scratch = list(scratch)  # the stream's scratch tensors the records point into: alive as long as the plan is
+        self.graph_ok = True          # False after a failed hipGraph build / launch: this plan goes out record by record from then on
         self.inputs = inputs  # name -> [pointer the records hold, bytes]
         self.n = n_launches
         # the text context the recorded forward attended to, and ITS K / V^T projections [(module, K, V^T)]: the records of the cross-attention
@@ -168,7 +179,7 @@ class ForwardPlan:
             return
         nbytes = tensor.numel() * tensor.element_size()
         if nbytes != slot[1]:
-            raise RuntimeError(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
+            raise PlanMismatch(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
         self._move(first, count, slot, nbytes, ptr, what)
 
     def _move(self, first, count, slot, nbytes, new_ptr, what):
@@ -178,7 +189,7 @@ class ForwardPlan:
         if n < 0:
             raise RuntimeError("fz_plan_relocate failed")
         if len(slot) > 2 and n != slot[2]:
-            raise RuntimeError(f"issue plan: {what} matched {n} argument words where the recording had {slot[2]}: a non-pointer argument holds "
+            raise PlanMismatch(f"issue plan: {what} matched {n} argument words where the recording had {slot[2]}: a non-pointer argument holds "
                                "a value inside the tensor's address range -- this forward cannot be replayed safely")
         slot[0] = new_ptr
 
@@ -193,7 +204,7 @@ class ForwardPlan:
         for i, (slot, t) in enumerate(changed):
             nbytes = t.numel() * t.element_size()
             if nbytes != slot[1]:
-                raise RuntimeError(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
+                raise PlanMismatch(f"issue plan: {what} changed size ({slot[1]} -> {nbytes} bytes): the plan does not describe this forward")
             self._move(first, count, slot, nbytes, _PARK_BASE + (i << 44), what)
         for slot, t in changed:
             self._relocate(first, count, slot, t, what)
@@ -231,7 +242,7 @@ class ForwardPlan:
             plan = planner(*ev.args)
             alive.append(plan)
             if plan.n_plain != ev.n_plain or plan.mode != ev.mode:
-                raise RuntimeError("issue plan: the controller answered a different attention plan than the recorded forward "
+                raise PlanMismatch("issue plan: the controller answered a different attention plan than the recorded forward "
                                    f"(mode {ev.mode} -> {plan.mode}, plain frames {ev.n_plain} -> {plan.n_plain}): issue_signature() "
                                    "does not separate the two kinds of step")
             pairs = []
@@ -239,16 +250,19 @@ class ForwardPlan:
                 t = getattr(plan, f)
                 slot = ev.fields.get(f)
                 if (t is None) != (slot is None):
-                    raise RuntimeError(f"issue plan: AttnPlan.{f} is {'absent' if t is None else 'present'} where the recorded forward "
+                    raise PlanMismatch(f"issue plan: AttnPlan.{f} is {'absent' if t is None else 'present'} where the recorded forward "
                                        "had the opposite: issue_signature() does not separate the two kinds of step")
                 if t is not None:
                     pairs.append((slot, t))
             if pairs:
                 self._relocate_many(ev.first, ev.count, pairs, "an AttnPlan tensor")
-        if graph and at == 0:
+        if graph and at == 0 and self.graph_ok:
             rc = L.fz_plan_graph_launch(h, stream)
-            if rc:
-                N.check(rc, "fz_plan_graph_launch")
+            if rc:  # graph creation / instantiation / node update failed: nothing of this forward was issued -- the records still can be
+                self.graph_ok = False
+                rc = L.fz_plan_replay(h, 0, self.n, stream)
+                if rc:
+                    N.check(rc, "fz_plan_replay")
         elif self.n > at:
             rc = L.fz_plan_replay(h, at, self.n - at, stream)
             if rc:
@@ -295,8 +309,8 @@ class IssuePlans:
             sig = None if sig_fn is None or getattr(controller, "attention_plan", None) is None else sig_fn()
             if sig is None:
                 return None
-        return (tuple(x.data.shape), x.b, x.f, x.h, x.w, str(x.data.device), tuple(temb_act.shape), tuple(ctx.shape), ctx.dtype,
-                type(controller), sig, _model_switches())
+        return (tuple(x.data.shape), x.b, x.f, x.h, x.w, str(x.data.device), K._scratch_key(x.data)[1], tuple(temb_act.shape), tuple(ctx.shape),
+                ctx.dtype, type(controller), sig, _model_switches())
 
     # -- record --------------------------------------------------------------------------------------------
     @classmethod
@@ -359,7 +373,8 @@ class IssuePlans:
         if keep is not None:
             keep.append(x.data)
             keep.append(temb_act)
-        plan = self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx_kv)
+        plan = self.plans[key] = ForwardPlan(handle, rec.events, keep, out, inputs, n, ctx_kv, scratch=K.scratch_buffers(x.data))
+        plan.scratch_gen = K.scratch_generation()
         # how many argument words each relocatable range matches now (a move onto itself counts without changing anything): the check of _move
         head = rec.events[0].first if rec.events else n
         for slot in inputs.values():
@@ -384,12 +399,28 @@ class IssuePlans:
             if plan is None:
                 self.stats["walked"] += 1
                 return None
+            if plan.scratch_gen != K.scratch_generation():
+                # the stream's scratch was regrown or released since the recording (a later job with more frames, another stream's scratch
+                # evicting this one's): the records point at the old buffers -- which the plan kept alive, but nobody else writes them any
+                # more in the order the walk would.  Drop the plan; this forward is walked (warm-up) and the next one recorded afresh.
+                del self.plans[key]
+                self.seen[key] = 1
+                self.stats["rerecorded"] = self.stats.get("rerecorded", 0) + 1
+                self.stats["walked"] += 1
+                return self._walk_in_pool(x, temb_act, ctx)
+            first = controller is None or bool(getattr(controller, "issue_events_first", False))
             self.stats["replayed"] += 1
             if not plan.context_is_bound(ctx):
                 plan.bind_context(ctx)
                 self.stats["contexts_bound"] += 1
-            first = controller is None or bool(getattr(controller, "issue_events_first", False))
-            return plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
+            try:
+                return plan.replay(x, temb_act, controller, events_first=first, graph=first and self.graph)
+            except PlanMismatch:
+                # the controller answered another kind of step than the recorded one (its issue_signature() is incomplete) or a relocation
+                # did not match: the controller's state has advanced, so THIS forward cannot be walked instead -- the error goes up, but the
+                # kind is walked from now on: a caller that restarts the job does not meet the plan again
+                self.plans[key] = None
+                raise
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
         if len(self.seen) > 64:

@@ -225,6 +225,30 @@ def blend_mask(maps: List[torch.Tensor], alpha: torch.Tensor, th: float, out_hw:
 
 _gn_scratch = {}
 _gn_plans = {}
+_scratch_gen = [0]  # bumped whenever a scratch buffer (GroupNorm partials, split-K slabs) is allocated, regrown or evicted
+
+
+def scratch_generation() -> int:
+    """Changes whenever a process-wide scratch buffer a launch may point at was (re)allocated or released: a recorded issue plan
+    (fatezero_amd/issue.py) holds raw pointers into those buffers and is only valid for the generation it was recorded under."""
+    return _scratch_gen[0]
+
+
+def release_scratch():
+    """Give every scratch buffer (all devices, all streams) back to the allocator, e.g. between jobs of very different sizes.  Launch
+    descriptors and issue plans that point into them are dropped / recorded again (scratch_generation changes)."""
+    if _ws or _gn_scratch:
+        _scratch_gen[0] += 1
+    _ws.clear()
+    _gn_scratch.clear()
+    _gn_plans.clear()
+    del _scratch_lru[:]
+
+
+def scratch_buffers(t_or_device):
+    """The scratch tensors of the caller's (device, stream): whoever keeps raw pointers into them keeps these alive."""
+    key = _scratch_key(t_or_device)
+    return [b for b in (_ws.get(key), _gn_scratch.get(key)) if b is not None]
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span: int, groups: int, eps: float,
@@ -244,6 +268,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, span:
             buf = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
             _gn_scratch[skey] = buf
             _gn_plans.clear()  # plans hold the scratch pointer
+            _scratch_gen[0] += 1
         plan = _gn_plans[key] = (n, tokens, c, buf.data_ptr(), buf)
     n, tokens, c, scratch, _ = plan
     # cheap per-call checks (the plan is keyed on the shape only: a later non-contiguous / non-fp16 / misaligned tensor of the same
@@ -281,6 +306,7 @@ def groupnorm_cat(x1: torch.Tensor, x2: torch.Tensor, gamma: torch.Tensor, beta:
         buf = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x1.device)
         _gn_scratch[skey] = buf
         _gn_plans.clear()  # plans hold the scratch pointer
+        _scratch_gen[0] += 1
     out = torch.empty(n, tokens, c, dtype=torch.float16, device=x1.device)
     N.check(N.lib().fz_groupnorm_cat(x1.data_ptr(), c1, x2.data_ptr(), c2, out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, span,
                                      tokens, groups, eps, 1 if silu else 0, buf.data_ptr(), _stream(x1)), "fz_groupnorm_cat")
@@ -403,9 +429,11 @@ def _scratch_key(t_or_device):
         _scratch_lru.append(key)
         while len(_scratch_lru) > _SCRATCH_STREAMS_MAX:
             old = _scratch_lru.pop(0)
-            _ws.pop(old, None)
+            if _ws.pop(old, None) is not None:
+                _scratch_gen[0] += 1
             if _gn_scratch.pop(old, None) is not None:
                 _gn_plans.clear()  # plans hold the scratch pointer
+                _scratch_gen[0] += 1
     return key
 
 
@@ -414,6 +442,7 @@ def _ws_ptr(device):
     buf = _ws.get(key)
     if buf is None:
         buf = _ws[key] = torch.empty(_WS_FLOATS, dtype=torch.float32, device=device)
+        _scratch_gen[0] += 1
     return buf.data_ptr()
 
 

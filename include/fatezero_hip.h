@@ -374,7 +374,8 @@ int fz_peer_wait(const uint32_t* flags, uint64_t sender_mask, uint32_t epoch, ui
  * a pointer but happens to hold a number inside the range would move too -- the ranges are device (or pinned host) allocations, and no size, stride,
  * count or scale argument of this library takes values up there (2^46 and beyond).  fz_plan_pause(p, 1) ... (p, 0) brackets host work
  * whose launches must NOT enter the plan (what the host repeats live at every replay: the attention controller's own kernels).
- * One recording at a time, from the one thread that issues launches; a plan never allocates device memory, never synchronises, and owns
+ * The recorder is PER THREAD (thread-local; the library keeps no process-wide state): one recording at a time per thread, it sees the launches
+ * that thread makes, other threads' launches are issued unrecorded.  A plan never allocates device memory, never synchronises, and owns
  * nothing but host memory (the buffers its records point into are the host layer's to keep alive: fatezero_amd/issue.py).
  * Returns FZ_OK or a negative FZ_ERR_* code like every other entry point. */
 typedef struct FzPlan FzPlan;

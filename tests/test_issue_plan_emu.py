@@ -62,6 +62,40 @@ def test_record_relocate_replay():
     L.fz_plan_destroy(h); L.fz_plan_destroy(h3)
 
 
+def test_the_recorder_is_per_thread():
+    """include/fatezero_hip.h: no process-wide state -- a recording sees the launches of the thread that began it; another thread can launch (unrecorded)
+    and record a plan of its own at the same time."""
+    import threading
+    from fatezero_amd import kernels as K
+    L = _native.lib()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(64, 320, generator=g).half()
+    gam, bet = torch.randn(320, generator=g).half(), torch.randn(320, generator=g).half()
+    h = C.c_void_p()
+    assert L.fz_plan_begin(C.byref(h)) == 0
+    K.layernorm(x, gam, bet, eps=1e-5)
+    seen = {}
+
+    def other():
+        K.layernorm(x, gam, bet, eps=1e-5)                       # issued, not recorded into the first thread's plan
+        seen["outer"] = L.fz_plan_launches(h)
+        h2 = C.c_void_p()
+        seen["begin"] = L.fz_plan_begin(C.byref(h2))             # this thread has no recording yet: allowed
+        K.layernorm(x, gam, bet, eps=1e-5)
+        K.layernorm(x, gam, bet, eps=1e-5)
+        seen["end"] = L.fz_plan_end(h2)
+        seen["own"] = L.fz_plan_launches(h2)
+        L.fz_plan_destroy(h2)
+
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    K.layernorm(x, gam, bet, eps=1e-5)
+    assert L.fz_plan_end(h) == 0
+    assert seen == {"outer": 1, "begin": 0, "end": 0, "own": 2}, seen
+    assert L.fz_plan_launches(h) == 2
+    L.fz_plan_destroy(h)
+
+
 @pytest.mark.parametrize("name", ["pipe_f3_mid_next"])   # (pipe_small_refine_reweight: with the spill tier under it, below; more scenarios on MI355X)
 def test_pipeline_replayed_from_plans_is_bit_identical(name, monkeypatch):
     base, pipe0 = PC.run_pipeline_case(name, "cpu", return_pipe=True)
@@ -139,6 +173,11 @@ def test_replay_refuses_a_step_of_another_kind():
     ctrl.capture = True
     with pytest.raises(RuntimeError, match="issue_signature"):
         unet(z, 5, ctx)
+    # the error went up (the controller's state had advanced: this forward could not be walked instead), but that kind of forward is walked
+    # from now on: a caller that starts over does not meet the plan again
+    walked = unet._issuer.stats["walked"]
+    y = unet(z, 5, ctx).sample
+    assert unet._issuer.stats["walked"] == walked + 1 and torch.isfinite(y.float()).all()
 
 
 def test_plans_serve_the_next_job():
@@ -265,3 +304,32 @@ def test_plans_follow_weights_and_model_switches(monkeypatch):
     y3 = [unet(z, 7, ctx).sample for _ in range(3)][-1]
     assert unet._issuer.stats["walked"] == walked + 1 and unet._issuer.stats["replayed"] == 3 and len(unet._issuer.plans) == 2
     assert torch.equal(y3, ref(z, 7, ctx).sample)
+
+
+def test_a_plan_does_not_outlive_the_scratch_it_points_at():
+    """Round-5 advisor: a plan's records hold raw pointers into the process-wide scratch of the launch stream (split-K slabs, GroupNorm
+    partials).  The plan keeps those tensors alive, and a scratch that was regrown or evicted since the recording (kernels.scratch_generation)
+    makes the forward be walked and recorded again instead of replayed against the old buffers."""
+    from fatezero_amd import kernels as K
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(1, 4, 2, 16, 16, generator=g).half()
+    ctx = torch.randn(1, 77, 64, generator=g).half()
+    unet = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+    ref = PC.build_unet("tiny16", {"lora": 16}, "cpu")
+    unet.enable_issue_plans()
+    want = ref(z, 7, ctx).sample
+    for _ in range(3):
+        y = unet(z, 7, ctx).sample
+    st = unet._issuer.stats
+    assert st["replayed"] == 1 and torch.equal(y, want)
+    plan = next(iter(unet._issuer.plans.values()))
+    held = {t.data_ptr() for t in plan.scratch}
+    assert held and held == {t.data_ptr() for t in K.scratch_buffers(z)}     # the stream's scratch, referenced by the plan
+    # the scratch goes away under the plan (what a larger job's regrowth or the eviction of a fifth stream's scratch set does)
+    gen = K.scratch_generation()
+    K.release_scratch()
+    assert K.scratch_generation() != gen and not K.scratch_buffers(z)
+    assert {t.data_ptr() for t in plan.scratch} == held                      # ... but not under the plan's feet
+    ys = [unet(z, 7, ctx).sample for _ in range(3)]                           # walked again, recorded again, replayed
+    assert st.get("rerecorded") == 1 and st["recorded"] == 2 and st["replayed"] == 2
+    assert all(torch.equal(v, want) for v in ys)
