@@ -356,16 +356,23 @@ def pick_split_threshold(pipe, z0, device, steps=10, iters=10):
     return best, seen
 
 
-def cpu_baseline(pipe, ddim_steps, frames, sample_frames=3, k=1):
+# The reference's OWN modules (imported unmodified through oracle/refshim) against the port on the same UNet forward, measured once in the
+# authoring container (8 cores; profiles/r04_cpu_ref_vs_port.txt): neither /root/reference nor diffusers exists on the GPU box, so the line
+# carries the ratio instead of a second timing -- cpu_baseline.value is the PORT's; the reference's own code is slower by these factors.
+REFERENCE_OVER_PORT = {"inversion_forward": 1.195, "cfg_edit_forward": 1.785, "source": "profiles/r04_cpu_ref_vs_port.txt (3 frames x 512^2, fp32, "
+                       "8 cores of the authoring container; outputs agree to 4.8e-6)"}
+
+
+def cpu_baseline(pipe, ddim_steps, frames, sample_frames=3, k=2):
     """The CPU oracle (oracle/fatezero_oracle.py, fp32 restatement of the reference loop) on the host cores, after BASELINE.md
     section 3: after ONE warm-up step, k capture-inversion steps and k CFG edit steps (edit steps 0..k-1: inside both replace
     windows, the expensive case) of a `sample_frames`-frame 512x512 clip with the bench's weights and controller.  THREE frames:
     with [-1, 'first'] the two K/V slots of frame 2 are frames 1 and 0 -- distinct, as in the 8-frame job (a 2-frame sample has
     both slots on frame 0) -- and GroupNorm spans three frames.  Steps are homogeneous and the cost is linear in the frame count
     (sparse-causal attention: every frame attends two frames), so the job time is extrapolated as
-    T * (t_inv + t_edit) / k * frames / sample_frames.  (BASELINE.md asks for k = 2; k = 1 at 3 frames is the same ~100 s of CPU
-    work as k = 2 at 2 frames -- `--cpu-k 2` runs the longer sample.  The reference's own modules cannot be timed here: neither
-    /root/reference nor diffusers exists on the GPU box, hence kind = "port".)"""
+    T * (t_inv + t_edit) / k * frames / sample_frames.  k = 2.  The reference's own modules cannot
+    be timed here: neither /root/reference nor diffusers exists on the GPU box, hence kind = "port"; `reference_over_port` carries what the
+    reference's own code measured against the port on the same forward, and `value_reference_estimate` the port's value divided by it."""
     import platform
     from oracle.host_cpu import cpu_budget, size_torch_pool
     size_torch_pool()  # the box's cgroup CPU quota, not the 256 logical CPUs torch sees (oracle/host_cpu.py)
@@ -416,7 +423,10 @@ def cpu_baseline(pipe, ddim_steps, frames, sample_frames=3, k=1):
             cpu = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return {"value": frames / job_s, "unit": "edited frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    ref_job_s = ddim_steps * (t_inv * REFERENCE_OVER_PORT["inversion_forward"] + t_edit * REFERENCE_OVER_PORT["cfg_edit_forward"]) / k \
+        * frames / sample_frames
+    return {"value": frames / job_s, "unit": "edited frames/s", "cores": torch.get_num_threads(), "kind": "port", "k": k,
+            "reference_over_port": REFERENCE_OVER_PORT, "value_reference_estimate": frames / ref_job_s,
             "cpu_model": cpu, "logical_cpus_visible": os.cpu_count(), "cpu_budget": cpu_budget(),
             "sample": f"after 1 warm-up step ({t_warm:.1f} s): {k} capture-inversion steps ({t_inv:.1f} s) + {k} CFG edit steps "
                       f"({t_edit:.1f} s) of a {sample_frames}-frame 512x512 clip, full-size SD-1.x pseudo-3D UNet fp32 "
@@ -538,6 +548,16 @@ def install_timers(K, timer):
     if hasattr(K, "gemm_lnout"):
         timer.wrap(K, "gemm_lnout", sel_gemm_lnout)
 
+    def sel_ff_chain(xn, packed, b2, inner, **kw):  # the whole feed-forward of a 64x64-level block in one launch (csrc/ff_chain.hip)
+        if not timer.extra:
+            return None
+        c = xn.shape[-1]
+        rows = xn.numel() // c
+        n_io = 2 + (kw.get("res") is not None) + (kw.get("ln") is not None)     # xn in, y out (+ res in) (+ LayerNorm(y) out)
+        return ("ff_chain", 2.0 * rows * (c * 2 * inner + inner * c), 2.0 * (rows * c * n_io + 3 * c * inner))
+    if hasattr(K, "ff_chain"):
+        timer.wrap(K, "ff_chain", sel_ff_chain)
+
 
 def gemm_class(x, w, kw):
     """Roofline class of one projection GEMM (>= 1024 rows).  The launches fall into two regimes: plain projections with
@@ -600,6 +620,9 @@ def rooflines(summ):
                 "avg_launch_ms": ms_total / launches, "algorithmic_flops_per_launch": flops_total / launches,
                 # frames 0 and 1 of a clip see frame 0 in both [-1, 'first'] slots and read it once (the same softmax): the rate over
                 # the key tiles the kernel really contracts, beside the algorithmic one SURVEY section 8(d) defines
+                "launches_note": "every attn_flash d = 40 launch of the process between timer reset and summary: 500 per timed job (250 x 8 frames "
+                                 "+ 250 x 16 frames) plus the box calibration's 8-frame launches where they fall inside -- avg_launch_ms and "
+                                 "algorithmic_flops_per_launch are means over that mix",
                 "contracted_fraction": flops_read / flops_total,
                 "achieved_over_contracted_tiles": achieved * flops_read / flops_total}
     if roof is not None:  # q, k (two source frames' worth is re-read from L2, not algorithmic), V^T in, o out: 4 x Lq x C halves per frame
@@ -613,6 +636,8 @@ def rooflines(summ):
              "mfma", 2500.0, "TFLOP/s", 1e12),
             ("gemm_hbm", "igemm_kernel<.., MODE 0> HBM class: plain projections with K <= 640 and >= 1024 rows (algorithmic bytes "
                          "2 (rows K + rows N (1 + residuals) + K N))", "hbm", 8000.0, "GB/s", 1e9),
+            ("ff_chain", "ff_chain_kernel (64x64 level: GEGLU up-projection -> gate -> down-projection + residual + LayerNorm in one launch, "
+                         "2 rows (C 2 inner + inner C) FLOP)", "mfma", 2500.0, "TFLOP/s", 1e12),
             ("capture", "attn_self_kernel<CAPTURE> (bytes of the fp16 probability maps written to the HBM arena)", "hbm", 8000.0, "GB/s", 1e9),
             ("inject", "attn_self_kernel<INJECT> (bytes of the stored maps read back)", "hbm", 8000.0, "GB/s", 1e9)):
         sel = {k: v for k, v in summ.items() if k[0] == name}
@@ -766,7 +791,7 @@ def main():
     ap.add_argument("--latent-size", type=int, default=64,
                     help="latent height = width (64 = 512^2 frames, the judged configuration; 72 = the 576^2 frames of BASELINE cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-k", type=int, default=1, help="DDIM steps of each kind in the CPU-oracle sample (after one warm-up step)")
+    ap.add_argument("--cpu-k", type=int, default=2, help="DDIM steps of each kind in the CPU-oracle sample (after one warm-up step)")
     ap.add_argument("--cpu-cfg1", action="store_true",
                     help="also run BASELINE cfg1 (8 f x 256^2 x 10 steps) IN FULL on the CPU oracle (minutes of host time) -> cpu_baseline.cfg1_full")
     ap.add_argument("--cfg1", action="store_true",

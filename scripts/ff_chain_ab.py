@@ -76,5 +76,15 @@ for frames in frames_list:
     print(f"{frames:2d} frames ({rows:6d} rows, {(rows + 127) // 128:4d} workgroups)  two launches {t2[0]:7.1f} us (min {t2[1]:7.1f})   one launch {t1[0]:7.1f} us "
           f"(min {t1[1]:7.1f})   x{t2[0] / t1[0]:.2f}   {flop(rows) / t1[0] / 1e6:7.1f} TF/s = {flop(rows) / t1[0] / 1e6 / 2500:.3f} of the MFMA roof "
           f"(two: {flop(rows) / t2[0] / 1e6 / 2500:.3f})   bit-identical: {same}", flush=True)
+    if "timing" in libs:  # -DFC_TIMING: cycle totals per loop segment of the UP / DOWN wave of pair 0 of workgroup 0
+        import ctypes
+        buf = (ctypes.c_longlong * 16)()
+        libs["timing"].fz_ff_chain_timing.argtypes = [ctypes.c_void_p]
+        fns["timing"](0)
+        torch.cuda.synchronize()
+        libs["timing"].fz_ff_chain_timing(buf)
+        v = list(buf)
+        print("      cycles UP   wave: wait_vm %d | barrier A %d | DMA issue %d | 40 reads + MFMAs %d | bias %d | barrier B %d | U write %d | loop total %d" % tuple(v[:8]))
+        print("      cycles DOWN wave: wait_vm %d | barrier A %d | DMA issue %d | U read + gate %d | 20 reads + MFMAs %d | barrier B %d | - %d | loop total %d" % tuple(v[8:]), flush=True)
     if len(libs) > 1:
         print("      trial builds (median us): " + "  ".join(f"{k} {v[0]:.1f}" for k, v in r.items() if k not in ("two", "one")), flush=True)

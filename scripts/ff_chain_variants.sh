@@ -1,4 +1,5 @@
-# variants of ff_chain only: compile that one file with the flag, link with the shipped objects of the others
+# Trial builds of csrc/ff_chain.hip for scripts/ff_chain_ab.py (never shipped): that one file compiled with a trial flag, linked with the
+# shipped objects of the other translation units -> build_tmp/libfz_ff_<name>.so
 set -e
 mkdir -p build_tmp/ffv
 mk() { name=$1; shift
@@ -7,9 +8,9 @@ mk() { name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_tmp/libfz_ff_$name.so build_tmp/ffv/ff_$name.o $objs
 }
 mk nodma -DFC_TRIAL_NODMA &
-mk burst -DFC_TRIAL_DMA_BURST &
-
 mk nogelu -DFZ_GELU_TRIAL_IDENTITY &
-
+mk timing -DFC_TIMING &
+mk noprio -DFC_TRIAL_NOPRIO &
+mk gate0 -DFC_GATE_UP=0 &
 wait
 ls -la build_tmp/libfz_ff_*.so

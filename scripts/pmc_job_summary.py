@@ -16,6 +16,8 @@ def klass(name):
     if "attn_self_kernel" in name:  # <D, MODE, ABL>: MODE 1 = FZ_ATTN_CAPTURE, 2 = FZ_ATTN_INJECT (csrc/attn_self.hip)
         m = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"<(\d+), ?(\d+), ?(\d+)>", name)
         return ("capture" if m.group(2) == "1" else "inject") if m else "attn_self"
+    if "ff_chain_kernel" in name:
+        return "ff_chain"
     if "igemm_reduce" in name:
         return "splitk_reduce"
     if "lora_pair_kernel" in name:  # both temporal LoRA convolutions in one launch (csrc/lora_pair.hip)

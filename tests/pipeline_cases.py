@@ -603,12 +603,43 @@ GEOMETRY_CASES = {
                                          cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
                                          blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[2, 2], blend_latents=False,
                                          regime="all_stored"),
+    # THE JUDGED JOB at its own depth (opt-in, FZ_FULL_PARITY=1: minutes of GPU-executed fp32 oracle and ~225 GB of HBM for the two stores):
+    # config/teaser/jeep_posche.yaml at FULL SD-1.x width, 8 frames, 64^2 latents, T = 50 + 50 (p2p_ddim_spatial_temporal.py:132-161, 386-421),
+    # bench.py's controller: Replace + blend-masked self-attention, cross window [0, 25), self window [0, 25)
+    "cfg2_fullwidth_8f_T50": dict(kind="sd15", F=8, L=64, T=50, model_config={"lora": 160}, prompt_case="teaser_posche", is_replace=True,
+                                  cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
+                                  blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=None, blend_latents=False, regime="split",
+                                  deep=True),
+    # cfg3's geometry ONCE at full width (opt-in as well): 16 frames, ['mid'] / least_sc_channel 640, Refine + Reweight x10, the default
+    # blend_th [2, 2]; T = 4: cross window [0, 2), self window [0, 2)
+    "cfg3_fullwidth_16f_mid": dict(kind="sd15", F=16, L=64, T=4,
+                                   model_config={"lora": 160, "SparseCausalAttention_index": ["mid"], "least_sc_channel": 640},
+                                   prompt_case="style_van_gogh", is_replace=False, cross_replace={"default_": 0.5}, self_replace=0.5,
+                                   eq_params={"words": ["van", "gogh"], "values": [10, 10]}, blend_words=[["sunflower"], ["sunflower"]],
+                                   blend_th=[2, 2], blend_latents=False, regime="all_stored", deep=True),
     # miniature of the same harness for the GPU-less suite (emulator): all three windows toggle inside T = 6
     "mini_emu": dict(kind="tiny16", F=2, L=64, T=6, model_config={"lora": 16}, prompt_case="teaser_posche", is_replace=True,
                      cross_replace={"default_": 0.5}, self_replace=0.5, eq_params=None,
                      blend_words=[["silver", "jeep"], ["Porsche", "car"]], blend_th=[0.3, 0.3], blend_latents=True, regime=None),
 }
 GEOMETRY_SPLIT_TH = {"tiny40": 0.55, "sd15": FULL_BLEND_TH}  # thresholds that put 20-80 % of the mask on either side (asserted)
+
+
+class _LazyF32(list):
+    """A list of stored maps that hands out fp32 copies on the oracle's device at the moment of use (the natively captured fp16 maps of a
+    50-step full-width job are 75 GB: an eager fp32 copy for the oracle would be 150 GB more)."""
+
+    def __init__(self, items, device):
+        super().__init__(items)
+        self._dev = device
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [t.float().to(self._dev) for t in list.__getitem__(self, i)]
+        return list.__getitem__(self, i).float().to(self._dev)
+
+    def __iter__(self):
+        return (list.__getitem__(self, i).float().to(self._dev) for i in range(len(self)))
 
 
 def controller_windows(T, cross, self_replace, blend_latents):
@@ -743,10 +774,14 @@ def run_geometry_case(name, device, oracle_device=None, seed=21, fp32_leg=True):
         zT = lat[-1].float().cpu()
         edited, nsteps, nctrl = native_edit(zT)
         ost = O.StoreController()
-        ost.attention_store_all_step = [{k: [t.float().to(odev) for t in v] for k, v in d.items()} for d in store.attention_store_all_step]
+        if G.get("deep"):
+            ost.attention_store_all_step = [{k: _LazyF32(v, odev) for k, v in d.items()} for d in store.attention_store_all_step]
+        else:
+            ost.attention_store_all_step = [{k: [t.float().to(odev) for t in v] for k, v in d.items()} for d in store.attention_store_all_step]
         ost.latents_store = [t.float().to(odev) for t in store.latents_store]
         forced = list(nctrl.latent_blend.applied_mask_list) if G["blend_latents"] else None
         o_edit, osteps, octrl = oracle_edit(ost, zT, forced_applied=forced)
+        del ost
         res["edit_scale"] = float(o_edit.abs().max())
         near = masks_report(nctrl, octrl, "same_maps")
         per_step = [float((nsteps[i] - osteps[i]).abs().max()) for i in range(T)]
@@ -765,8 +800,9 @@ def run_geometry_case(name, device, oracle_device=None, seed=21, fp32_leg=True):
             return res
         # (2) the all-fp32 leg: oracle edit on the ORACLE's maps from the oracle's inverted latent vs the native edit from that latent
         zo = olat[-1].cpu()
-        edited2, _, nctrl2 = native_edit(zo)
-        p_edit, _, pctrl = oracle_edit(ostore, zo)
+        edited2, nsteps2, nctrl2 = native_edit(zo)
+        p_edit, psteps, pctrl = oracle_edit(ostore, zo)
+        res["edit_err_steps_vs_fp32"] = [float((nsteps2[i] - psteps[i]).abs().max()) for i in range(T)]
         near2 = masks_report(nctrl2, pctrl, "vs_fp32")
         em2 = (edited2 - p_edit).abs().amax(dim=(0, 1))
         res["edit_err_vs_fp32"] = float(em2.max())
@@ -804,8 +840,23 @@ GEO_BEYOND_BAND_TOL = 4e-2        # latent positions whose error leaves the 6 % 
                                   # (compounds like the count above)
 
 
+# The judged job at its own depth (cfg2_fullwidth_8f_T50) and cfg3's geometry at full width: bounds <= 2x what MI355X measured
+# (profiles/r06_parity_numbers.txt); the rest of check_geometry applies unchanged.
+GEO_DEEP = {
+    # measured (r06f): inversion 0.161 %, cross maps 9.0e-3, self maps 9.3e-4, edit on the native maps 0.646 % max / 0.306 % q99 after 50 steps,
+    # all-fp32 leg 0.693 % max / 0.310 % q99, attention-mask flips 0.151 %
+    "cfg2_fullwidth_8f_T50": dict(inv=3.2e-3, cross_map=1.8e-2, self_map=1.9e-3, edit_same_maps=1.3e-2, edit_same_maps_q99=6.1e-3,
+                                  attn_flips=3e-3, edit_vs_fp32=1.4e-2, edit_vs_fp32_q99=6.2e-3),
+    # measured (r06f): inversion 0.110 %, cross maps 8.2e-3, self maps 1.41e-3, edit 0.824 % max / 0.427 % q99, all-fp32 0.949 % / 0.432 %, no flips
+    "cfg3_fullwidth_16f_mid": dict(inv=2.2e-3, cross_map=1.7e-2, self_map=2.8e-3, edit_same_maps=1.65e-2, edit_same_maps_q99=8.6e-3,
+                                   attn_flips=1e-3, edit_vs_fp32=1.9e-2, edit_vs_fp32_q99=8.7e-3),
+}
+
+
 def check_geometry(res):
     G = GEOMETRY_CASES[res["case"]]
+    if G.get("deep") and res["case"] in GEO_DEEP:
+        return _check_deep(G, res, GEO_DEEP[res["case"]])
     assert res["outputs_finite"], res
     assert res["inv_err"] <= GEO_LATENT_TOL * res["inv_scale"], res
     assert res["map_err"] <= GEO_MAP_TOL and res["self_map_err"] <= GEO_SELF_MAP_TOL, res
@@ -836,6 +887,20 @@ def check_geometry(res):
         assert res["edit_err_vs_fp32"] <= EDIT_TOL_VS_REFERENCE * res["edit_scale"], res
     assert res["attn_mask_flips_vs_fp32"] <= GEO_ATTN_FLIP_TOL * res["attn_mask_total"], res
     assert res["edit_err_vs_fp32_q99"] <= GEO_EDIT_Q99_VS_FP32 * res["edit_scale"], res
+
+
+def _check_deep(G, res, B):
+    assert res["outputs_finite"], res
+    assert res["inv_err"] <= B["inv"] * res["inv_scale"], res
+    assert res["map_err"] <= B["cross_map"] and res["self_map_err"] <= B["self_map"], res
+    assert res["attn_mask_flips_same_maps"] == 0, res                      # identical maps on both sides: bit-exact masks
+    assert res["edit_err_same_maps"] <= B["edit_same_maps"] * res["edit_scale"], res
+    assert res["edit_err_same_maps_q99"] <= B["edit_same_maps_q99"] * res["edit_scale"], res
+    _check_regime(G, res)
+    if "edit_err_vs_fp32" in res:
+        assert res["attn_mask_flips_vs_fp32"] <= B["attn_flips"] * res["attn_mask_total"], res
+        assert res["edit_err_vs_fp32_q99"] <= B["edit_vs_fp32_q99"] * res["edit_scale"], res
+        assert res["edit_err_vs_fp32"] <= B["edit_vs_fp32"] * res["edit_scale"], res
 
 
 def _check_regime(G, res):

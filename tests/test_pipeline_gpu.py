@@ -130,6 +130,26 @@ def test_whole_job_long_clips_and_window_transitions_vs_oracle(name):
     assert _native.loaded_path().endswith("libfatezero_hip.so")
 
 
+@pytest.mark.skipif(__import__("os").environ.get("FZ_FULL_PARITY") != "1", reason="opt-in (FZ_FULL_PARITY=1): minutes of GPU-executed fp32 "
+                    "oracle and ~225 GB of HBM")
+@pytest.mark.parametrize("name", ["cfg2_fullwidth_8f_T50", "cfg3_fullwidth_16f_mid"])
+def test_judged_job_at_its_own_depth_vs_oracle(name):
+    """Round-5 review: the job the driver times -- 8 frames, full SD-1.x width, 64^2 latents, T = 50 + 50, Replace + blend-masked
+    self-attention (p2p_ddim_spatial_temporal.py:132-161, 386-421) -- against the fp32 oracle executed by torch on the GPU: latents per step of
+    the inversion and of both edit legs, captured maps at the first and the last step, masks; and cfg3's geometry (16 frames, ['mid']) once at
+    full width.  Numbers: profiles/r06_parity_numbers.txt."""
+    import json
+    import os
+    res = PC.run_geometry_case(name, "cuda", oracle_device="cuda")
+    print("geometry deep", {k: v for k, v in res.items() if not k.endswith("_steps") and k != "inv_err_steps"})
+    out = os.environ.get("FZ_PARITY_DUMP")
+    if out:
+        with open(os.path.join(out, f"parity_{name}.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    PC.check_geometry(res)
+    assert _native.loaded_path().endswith("libfatezero_hip.so")
+
+
 @pytest.mark.parametrize("name", ["unet_tiny40_default", "unet_tiny40_l72", "unet_tiny16_default", "unet_tiny16_mid", "unet_tiny16_conv1d"])
 def test_unet_vs_reference_golden(name):
     r = PC.run_unet_golden(name, "cuda")
