@@ -64,6 +64,17 @@ class FzGemmLn(C.Structure):
                 ("stats_out", C.c_void_p)]
 
 
+class FzXattnChain(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("res", C.c_void_p), ("packed", C.c_void_p), ("kv_packed", C.c_void_p), ("bias_out", C.c_void_p),
+        ("y", C.c_void_p), ("y_ln", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("y1", C.c_void_p),
+        ("rows", C.c_int64), ("rows_per_frame", C.c_int64),
+        ("frames_per_batch", C.c_int32), ("channels", C.c_int32), ("heads", C.c_int32), ("lk", C.c_int32),
+        ("scale", C.c_float), ("ln_eps", C.c_float), ("ln1_eps", C.c_float), ("front", C.c_int32),
+    ]
+
+
 FZ_GEMM_PLAIN, FZ_GEMM_GEGLU = 0, 1
 FZ_GEMM_NO_STATS = 1
 
@@ -75,6 +86,13 @@ _SIGS = {
     "fz_ff_chain_pack_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "fz_ff_chain_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "fz_ff_chain": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "fz_xattn_chain_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "fz_xattn_chain_preferred": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "fz_xattn_chain_pack_bytes": (C.c_int64, [C.c_int]),
+    "fz_xattn_chain_kv_pack_bytes": (C.c_int64, [C.c_int]),
+    "fz_xattn_chain_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "fz_xattn_chain_kv_pack": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    "fz_xattn_chain": (C.c_int, [C.POINTER(FzXattnChain), _P]),
     "fz_gemm_lnout": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int64, _P, _P]),
     "fz_gemm_ln": (C.c_int, [C.POINTER(FzGemmDesc), C.POINTER(FzGemmLn), _P, _P, _P, _P, _P, _P, _P, _P]),
     "fz_gemm_qkvt": (C.c_int, [C.POINTER(FzGemmDesc), _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),

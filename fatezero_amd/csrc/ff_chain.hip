@@ -319,12 +319,12 @@ FZ_KERNEL void __launch_bounds__(512, 2) ff_chain_kernel(FcArgs g) {
     }
     __syncthreads();
     const int l8 = lane & 7;
-    half8_t gmv[5], btv[5];
+    FzRow5 gmv, btv;
     if (g.yln != nullptr) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            gmv[i] = fz_ld_h8(g.gamma + (l8 + 8 * i) * 8);
-            btv[i] = fz_ld_h8(g.beta + (l8 + 8 * i) * 8);
+            gmv.c[i] = fz_ld_h8(g.gamma + (l8 + 8 * i) * 8);
+            btv.c[i] = fz_ld_h8(g.beta + (l8 + 8 * i) * 8);
         }
     }
 #pragma unroll
@@ -333,7 +333,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) ff_chain_kernel(FcArgs g) {
         const int64_t px = (int64_t)blk * FC_ROWS + rl;
         const bool ok = px < g.rows;
         const int64_t pxc = ok ? px : g.rows - 1;
-        half8_t v[5];
+        FzRow5 v;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const half8_t a = fz_ld_h8(Call + rl * FC_OSTR + (l8 + 8 * i) * 8);
@@ -346,38 +346,15 @@ FZ_KERNEL void __launch_bounds__(512, 2) ff_chain_kernel(FcArgs g) {
                 for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = (half_t)f[e];
-            if (ok) fz_st_h8(g.y + px * FC_C + (l8 + 8 * i) * 8, v[i]);
+            for (int e = 0; e < 8; ++e) v.c[i][e] = (half_t)f[e];
+            if (ok) fz_st_h8(g.y + px * FC_C + (l8 + 8 * i) * 8, v.c[i]);
         }
         if (g.yln == nullptr) continue;
-        // LayerNorm of the stored row: the arithmetic (and summation order) of igemm.hip's GS == -1 epilogue
-        float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                s0 += (float)v[i][e];
-                s1 += (float)v[i][e + 1];
-            }
-        const float mean = fz_sum8(s0 + s1) * (1.0f / 320.0f);
-        float q0 = 0.0f, q1 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const float d0 = (float)v[i][e] - mean, d1 = (float)v[i][e + 1] - mean;
-                q0 += d0 * d0;
-                q1 += d1 * d1;
-            }
-        const float rstd = 1.0f / sqrtf(fz_sum8(q0 + q1) * (1.0f / 320.0f) + g.eps);
+        // LayerNorm of the stored row: the out-of-line body igemm.hip's GS == -1 epilogue calls (fz_rt.h): the same bits
+        const FzRow5 o = fz_ln_row320(v, gmv, btv, g.eps);
         if (ok) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                half8_t o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mean) * rstd * (float)gmv[i][e] + (float)btv[i][e]);
-                fz_st_h8(g.yln + px * FC_C + (l8 + 8 * i) * 8, o);
-            }
+            for (int i = 0; i < 5; ++i) fz_st_h8(g.yln + px * FC_C + (l8 + 8 * i) * 8, o.c[i]);
         }
     }
 }

@@ -356,6 +356,46 @@ FZ_DEVICE f32x2 fz_exp2_poly2(f32x2 x) {
     return r;
 }
 
+// LayerNorm of ONE 320-channel row held by 8 consecutive lanes (lane l8 of the 8 holds chunks l8 + 8 i, i = 0..4, of 8 channels; gm / bt: the
+// same chunks of gamma / beta): exact two-sweep statistics in fp32 on the fp16 values, sums in a FIXED order (even / odd elements apart,
+// chunk-major, then fz_sum8's DPP tree).  ONE body shared by every launch that writes LN(y) beside y (igemm.hip GS == -1, ff_chain.hip,
+// xattn_chain.hip), with re-association switched OFF inside it: under -ffast-math the sums of an inlined copy are re-associated by the context
+// it is inlined into, and the launches that replace each other must agree bit for bit (found on MI355X: two textually identical epilogues
+// that differed by an fp16 ulp).  (Out of line it costs the caller its live registers around the call: gemm_lnout +40 %.)
+struct FzRow5 {
+    half8_t c[5];
+};
+FZ_DEVICE FzRow5 fz_ln_row320(const FzRow5& v, const FzRow5& gm, const FzRow5& bt, float eps) {
+#ifndef FZ_EMU
+#pragma clang fp reassociate(off)
+#endif
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            s0 += (float)v.c[i][e];
+            s1 += (float)v.c[i][e + 1];
+        }
+    const float mean = fz_sum8(s0 + s1) * (1.0f / 320.0f);
+    float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float d0 = (float)v.c[i][e] - mean, d1 = (float)v.c[i][e + 1] - mean;
+            q0 += d0 * d0;
+            q1 += d1 * d1;
+        }
+    const float rstd = 1.0f / sqrtf(fz_sum8(q0 + q1) * (1.0f / 320.0f) + eps);
+    FzRow5 o;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.c[i][e] = (half_t)(((float)v.c[i][e] - mean) * rstd * (float)gm.c[i][e] + (float)bt.c[i][e]);
+    return o;
+}
+
 static inline int fz_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int fz_round_up(int a, int b) { return fz_ceil_div(a, b) * b; }
 

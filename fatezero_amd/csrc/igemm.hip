@@ -1020,44 +1020,21 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
             static_assert(C::CW == 320, "the tile must hold whole 320-channel rows");
             __syncthreads();
             const int l8 = tid & 7;
-            half8_t gmv[5], btv[5];
+            FzRow5 gmv, btv;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                gmv[i] = fz_ld_h8(g.lno_gamma + (l8 + 8 * i) * 8);
-                btv[i] = fz_ld_h8(g.lno_beta + (l8 + 8 * i) * 8);
+                gmv.c[i] = fz_ld_h8(g.lno_gamma + (l8 + 8 * i) * 8);
+                btv.c[i] = fz_ld_h8(g.lno_beta + (l8 + 8 * i) * 8);
             }
             for (int rb = tid >> 3; rb < C::RP; rb += C::T >> 3) {
                 const int64_t px = b0 + ps * C::RP + rb;
-                half8_t v[5];
+                FzRow5 v;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) v[i] = fz_ld_h8(Cs + rb * C::CSTR + (l8 + 8 * i) * 8);
-                float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        s0 += (float)v[i][e];
-                        s1 += (float)v[i][e + 1];
-                    }
-                const float mean = fz_sum8(s0 + s1) * (1.0f / 320.0f);
-                float q0 = 0.0f, q1 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const float d0 = (float)v[i][e] - mean, d1 = (float)v[i][e + 1] - mean;
-                        q0 += d0 * d0;
-                        q1 += d1 * d1;
-                    }
-                const float rstd = 1.0f / sqrtf(fz_sum8(q0 + q1) * (1.0f / 320.0f) + g.lno_eps);
+                for (int i = 0; i < 5; ++i) v.c[i] = fz_ld_h8(Cs + rb * C::CSTR + (l8 + 8 * i) * 8);
+                const FzRow5 o = fz_ln_row320(v, gmv, btv, g.lno_eps);  // (one out-of-line body for every launch that writes LN(y): fz_rt.h)
                 if (px < g.Nb) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        half8_t o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mean) * rstd * (float)gmv[i][e] + (float)btv[i][e]);
-                        fz_st_h8(g.lno_y + ((int64_t)z * g.Nb + px) * g.lno_ld + (l8 + 8 * i) * 8, o);
-                    }
+                    for (int i = 0; i < 5; ++i) fz_st_h8(g.lno_y + ((int64_t)z * g.Nb + px) * g.lno_ld + (l8 + 8 * i) * 8, o.c[i]);
                 }
             }
         }
@@ -1226,7 +1203,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     g.kchunks = fz_ceil_div(g.Cin, BK);
     if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
     if (PP && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
-    g.tiles_a = fz_ceil_div(g.Ma, C::BA);
+    g.tiles_a = fz_ceil_div(g.Ma_store > g.Ma ? g.Ma_store : g.Ma, C::BA);  // (V^T padding rows [Ma, Ma_store) are written as zeros: their tiles run too)
     const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
     const int64_t nt = (int64_t)g.tiles_a * tiles_b;
     if (nt <= 0 || nt >= (1ll << 31) || batch <= 0 || batch > 65535 || g.ksplit < 1 || g.ksplit > 65535) return FZ_ERR_BAD_ARG;

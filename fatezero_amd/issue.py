@@ -211,13 +211,13 @@ class ForwardPlan:
 
     def bind_context(self, ctx):
         """A new text context of the recorded shape (the next job, the other pass): its K / V^T into the buffers the records point at."""
-        for m, kk, vt in self.ctx_kv:
-            m.project_context_into(ctx, kk, vt)
+        for m, kk, vt, kvp in self.ctx_kv:
+            m.project_context_into(ctx, kk, vt, kvp)
 
     def context_is_bound(self, ctx):
         """Do the buffers the records point at hold the projections of `ctx`?  The modules' caches say: whoever writes those buffers
         (bind_context of any plan that shares them) or replaces them (a walked forward with another context) updates the cache."""
-        for m, kk, _ in (self.ctx_kv[0], self.ctx_kv[-1]) if self.ctx_kv else ():
+        for m, kk, *_ in (self.ctx_kv[0], self.ctx_kv[-1]) if self.ctx_kv else ():
             c = m._ctx_kv
             if c is None or c[0] is not ctx or c[1] != ctx._version or c[2] is not kk:
                 return False
@@ -366,7 +366,7 @@ class IssuePlans:
             if isinstance(m, CrossAttention) and m._ctx_kv is not None:
                 if m._ctx_kv[0] is not ctx:  # (cannot happen: the recorded forward just attended to ctx)
                     raise RuntimeError("issue plan: a cross-attention layer holds the projections of another context")
-                ctx_kv.append((m, m._ctx_kv[2], m._ctx_kv[3]))
+                ctx_kv.append((m, m._ctx_kv[2], m._ctx_kv[3], m._ctx_kv[4]))
         if len(self.plans) >= self.MAX_PLANS:
             self.plans.pop(next(iter(self.plans)))
         keep = rec.keep

@@ -711,6 +711,108 @@ def ff_chain(xn: torch.Tensor, packed: torch.Tensor, b2: Optional[torch.Tensor],
     return y, yln
 
 
+# ------------------------------------------------------------------------------------------------------------
+# The cross-attention chain of the 64x64 level in one launch (csrc/xattn_chain.hip)
+# ------------------------------------------------------------------------------------------------------------
+def xattn_chain_ok(rows: int, rows_per_frame: int, channels: int, heads: int, lk: int) -> bool:
+    return bool(N.lib().fz_xattn_chain_ok(rows, rows_per_frame, channels, heads, lk))
+
+
+def xattn_chain_preferred(rows: int, rows_per_frame: int, channels: int, heads: int, lk: int) -> bool:
+    """Is the one launch the faster form on MI355X for this shape (fz_xattn_chain_preferred)?"""
+    return bool(N.lib().fz_xattn_chain_preferred(rows, rows_per_frame, channels, heads, lk))
+
+
+def xattn_chain_pack(wq: torch.Tensor, wo: torch.Tensor, front=None) -> torch.Tensor:
+    """attn2.to_q / attn2.to_out weights [320, 320] -> the operand-fragment stream fz_xattn_chain reads (uint8, on wq's device); front =
+    (wo1 [320, 320], bias1 [320] or None, gamma1, beta1): attn1.to_out and the LayerNorm behind it, for the `front` form.  Pack once per
+    weight set."""
+    wo1, bo1, g1, b1 = front if front is not None else (None, None, None, None)
+    ws = [wq.contiguous(), wo.contiguous()] + ([] if wo1 is None else [wo1.contiguous()])
+    for t in ws:
+        if t.dtype != torch.float16 or tuple(t.shape) != (320, 320):
+            raise ValueError(f"fz_xattn_chain_pack: fp16 [320, 320] weights, got {t.dtype} {tuple(t.shape)}")
+    vs = [None if t is None else t.contiguous() for t in (bo1, g1, b1)]
+    for t in vs:
+        if t is not None and (t.dtype != torch.float16 or t.numel() != 320):
+            raise ValueError("fz_xattn_chain_pack: fp16 [320] bias / LayerNorm parameters")
+    if wo1 is not None and (vs[1] is None or vs[2] is None):
+        raise ValueError("fz_xattn_chain_pack: the front form needs the LayerNorm's gamma and beta")
+    _chk16(*ws, *vs)
+    out = torch.empty(N.lib().fz_xattn_chain_pack_bytes(int(wo1 is not None)), dtype=torch.uint8, device=wq.device)
+    rc = N.lib().fz_xattn_chain_pack(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr() if wo1 is not None else None, _ptr(vs[0]), _ptr(vs[1]),
+                                     _ptr(vs[2]), out.data_ptr(), _stream(wq))
+    if rc:
+        N.check(rc, "fz_xattn_chain_pack")
+    return out
+
+
+def xattn_chain_kv_pack(k: torch.Tensor, vt: torch.Tensor, lk: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K [B, >= lk, 320] and V^T [B, 320, >= 96] of the text context (what fz_attn_cross takes) -> the per-batch fragment stream of
+    fz_xattn_chain.  Pack once per context (into `out` when given: an issue plan's records keep pointing at it)."""
+    b = k.shape[0]
+    if k.dtype != torch.float16 or vt.dtype != torch.float16 or vt.shape[0] != b or k.shape[2] < 320 or vt.shape[1] != 320 or \
+            vt.shape[2] < CROSS_KEYS or k.stride(2) != 1 or vt.stride(2) != 1 or k.shape[1] < lk:
+        raise ValueError(f"fz_xattn_chain_kv_pack: k [B, >= lk, 320] / vt [B, 320, >= 96] fp16, got {tuple(k.shape)} / {tuple(vt.shape)}")
+    _chk16(k, vt)
+    nbytes = N.lib().fz_xattn_chain_kv_pack_bytes(b)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=k.device)
+    elif out.numel() != nbytes or out.dtype != torch.uint8 or out.device != k.device:
+        raise ValueError("fz_xattn_chain_kv_pack: `out` does not fit this context")
+    rc = N.lib().fz_xattn_chain_kv_pack(k.data_ptr(), k.stride(0), k.stride(1), vt.data_ptr(), vt.stride(0), vt.stride(1), b, lk,
+                                        out.data_ptr(), _stream(k))
+    if rc:
+        N.check(rc, "fz_xattn_chain_kv_pack")
+    return out
+
+
+def xattn_chain(x: torch.Tensor, packed: torch.Tensor, kv_packed: torch.Tensor, bias_out: Optional[torch.Tensor], *, res: Optional[torch.Tensor],
+                frames_per_batch: int, heads: int, lk: int, scale: float, ln=None, front_eps: Optional[float] = None):
+    """x: [N, L, 320] fp16 contiguous.  front_eps is None: x = LayerNorm'ed hidden states, returns (y, y_ln or None) with
+    y = attn2(x, context) + res.  front_eps = eps of the LayerNorm in front (`packed` then holds attn1.to_out and that LayerNorm): x = attn1's
+    attention output, `res` its residual; returns (y, y_ln or None, y1) with y1 = to_out1(x) + res and y = attn2(LayerNorm1(y1), context) + y1.
+    (fz_xattn_chain)"""
+    n, l, c = x.shape
+    rows = n * l
+    front = front_eps is not None
+    ts = [x] + ([] if res is None else [res])
+    for t in ts:
+        if t.dtype != torch.float16 or not t.is_contiguous() or t.shape != x.shape:
+            raise ValueError("fz_xattn_chain: x / res must be contiguous fp16 tensors of one shape")
+    if not xattn_chain_ok(rows, l, c, heads, lk):
+        raise ValueError(f"fz_xattn_chain: unsupported shape {tuple(x.shape)} heads {heads} lk {lk}")
+    if packed.numel() != N.lib().fz_xattn_chain_pack_bytes(int(front)) or packed.dtype != torch.uint8 or packed.data_ptr() % 16:
+        raise ValueError("fz_xattn_chain: `packed` is not the stream of xattn_chain_pack for this form")
+    nb = (n + frames_per_batch - 1) // frames_per_batch
+    if kv_packed.numel() < N.lib().fz_xattn_chain_kv_pack_bytes(nb) or kv_packed.dtype != torch.uint8 or kv_packed.data_ptr() % 16:
+        raise ValueError("fz_xattn_chain: `kv_packed` does not cover the batch")
+    d = N.FzXattnChain()
+    keep = [x, res, bias_out]
+    y = torch.empty_like(x)
+    yln = None
+    d.x, d.res, d.packed, d.kv_packed, d.bias_out, d.y = x.data_ptr(), _ptr(res), packed.data_ptr(), kv_packed.data_ptr(), _ptr(bias_out), y.data_ptr()
+    if ln is not None:
+        gam, bet, eps = ln
+        if gam.dtype != torch.float16 or bet.dtype != torch.float16:
+            raise ValueError("fz_xattn_chain: LayerNorm weight / bias must be fp16")
+        yln = torch.empty_like(x)
+        d.y_ln, d.ln_gamma, d.ln_beta, d.ln_eps = yln.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(eps)
+        keep += [gam, bet]
+    y1 = None
+    if front:
+        if res is None:
+            raise ValueError("fz_xattn_chain: the front form needs the residual")
+        y1 = torch.empty_like(x)
+        d.front, d.y1, d.ln1_eps = 1, y1.data_ptr(), float(front_eps)
+    _chk16(*[t for t in keep if t is not None])
+    d.rows, d.rows_per_frame, d.frames_per_batch, d.channels, d.heads, d.lk, d.scale = rows, l, frames_per_batch, c, heads, lk, float(scale)
+    rc = N.lib().fz_xattn_chain(C.byref(d), _stream(x))
+    if rc:
+        N.check(rc, "fz_xattn_chain")
+    return (y, yln, y1) if front else (y, yln)
+
+
 _qkvt_plans = {}
 
 

@@ -80,6 +80,13 @@ LN_FROM_PRODUCER_C = 320
 # residual + norm_temporal, the rows x 1280 intermediate in registers only, the weights streamed as pre-packed MFMA fragments.  Bit-identical
 # to fz_gemm(GEGLU) + fz_gemm_lnout; used where fz_ff_chain_preferred says the one launch is the faster form.  (env switch: same-box A/B runs)
 FF_CHAIN = os.environ.get("FZ_NO_FF_CHAIN") is None
+# The cross-attention CHAIN of a 320-channel block in ONE launch (fz_xattn_chain, round 6): attn2.to_q -> 77-key cross-attention -> attn2.to_out +
+# residual + norm3, and (XATTN_CHAIN_FRONT) attn1.to_out + residual + norm2 in front of it in the same launch: q, the attention output and the
+# LayerNorm outputs never leave the CU, the weights and the text context's K / V^T are streamed as pre-packed MFMA fragments.  Bit-identical to
+# fz_gemm + fz_attn_cross + fz_gemm_lnout; used where no controller touches the maps (more than 32 x 32 queries: attention_store.py:83) and
+# fz_xattn_chain_preferred says the one launch is the faster form.  (env switches: same-box A/B runs)
+XATTN_CHAIN = os.environ.get("FZ_NO_XATTN_CHAIN") is None
+XATTN_CHAIN_FRONT = os.environ.get("FZ_NO_XATTN_FRONT") is None
 
 
 class Prenormed:
@@ -135,7 +142,8 @@ class CrossAttention(nn.Module):
         self._qk_fold = 1.0
         self._qkv = None
         self._qkv_self = None
-        self._ctx_kv = None
+        self._ctx_kv = None   # (ctx, its version, K, V^T, fz_xattn_chain's pack of them or None)
+        self._xchain = {}     # fz_xattn_chain's packed weights by (device, id of attn1's to_out or None)
         self._ln_fold = None  # (id of the norm, LnFold): the consuming projection with its LayerNorm folded in
 
     # -- helpers -----------------------------------------------------------------------------------------
@@ -147,15 +155,66 @@ class CrossAttention(nn.Module):
             self._qk_fold = q_fold
         return self._qk
 
-    def project_context_into(self, ctx, kk, vt):
+    def project_context_into(self, ctx, kk, vt, kvp=None):
         """K / V^T of the text context `ctx` written into EXISTING buffers (those of an earlier context of the same shape) and made this
-        module's cached projections: the launch records of a native issue plan keep pointing at valid data (fatezero_amd/issue.py)."""
+        module's cached projections: the launch records of a native issue plan keep pointing at valid data (fatezero_amd/issue.py).  `kvp`:
+        the fz_xattn_chain pack of those projections the records point at (re-packed in place)."""
         if kk.shape[:-1] != ctx.shape[:-1] or kk.device != ctx.device or ctx.dtype != kk.dtype:
             raise RuntimeError(f"issue plan: text context {tuple(ctx.shape)} / {ctx.dtype} does not fit the recorded projections {tuple(kk.shape)}")
         w, b = self.to_k.packed(ctx.dtype, ctx.device)
         K.gemm(ctx, w, b, out=kk)
         K.gemm_vt(ctx, self.to_v.packed(ctx.dtype, ctx.device)[0], K.CROSS_KEYS, out=vt)
-        self._ctx_kv = (ctx, ctx._version, kk, vt)
+        if kvp is not None:
+            K.xattn_chain_kv_pack(kk, vt, ctx.shape[1], out=kvp)
+        self._ctx_kv = (ctx, ctx._version, kk, vt, kvp)
+
+    def _context_kv(self, ctx, want_pack=False):
+        """K / V^T of the text context (and their fz_xattn_chain pack): they depend only on (ctx, weights) and the DDIM loops pass the same
+        embedding tensor at every step, so they are projected once per job instead of once per layer call (16 x 100 times per job)."""
+        kvc = self._ctx_kv
+        if kvc is None or kvc[0] is not ctx or kvc[1] != ctx._version:
+            kk = self.to_k.apply(ctx)
+            vt = K.gemm_vt(ctx, self.to_v.packed(ctx.dtype, ctx.device)[0], K.CROSS_KEYS)  # V^T straight out of the GEMM
+            kvc = self._ctx_kv = (ctx, ctx._version, kk, vt, None)
+        if want_pack and kvc[4] is None:
+            kvc = self._ctx_kv = kvc[:4] + (K.xattn_chain_kv_pack(kvc[2], kvc[3], ctx.shape[1]),)
+        return kvc[2], kvc[3], kvc[4]
+
+    def _chain_applies(self, n, lq, c, dtype, ctx):
+        """Does fz_xattn_chain carry this layer call (and is it the faster form)?  Only where no controller stores or edits the maps."""
+        return (XATTN_CHAIN and lq > 32 ** 2 and dtype == torch.float16 and ctx.dtype == torch.float16 and self.inner_dim == c
+                and self.to_q.bias is None and D.active_shard() is None and K.xattn_chain_preferred(n * lq, lq, c, self.heads, ctx.shape[1]))
+
+    def _chain_weights(self, device, front=None):
+        """fz_xattn_chain's packed weights; front = (attn1's to_out, the LayerNorm behind it) for the front form."""
+        key = (str(device), None if front is None else (id(front[0]), id(front[1])))
+        p = self._xchain.get(key)
+        if p is None:
+            wq = self.to_q.packed(torch.float16, device)[0]
+            wo = self.to_out[0].packed(torch.float16, device)[0]
+            fr = None
+            if front is not None:
+                w1, b1 = front[0].packed(torch.float16, device)
+                fr = (w1, b1) + tuple(front[1].packed(device))
+            p = self._xchain[key] = K.xattn_chain_pack(wq, wo, fr)
+        return p
+
+    def forward_cross_after(self, x: Tokens, o1, attn1_out, hs, norm_in, ctx, clip: int, ln_next):
+        """attn1's output projection + residual + `norm_in` AND this cross-attention + residual + `ln_next` in ONE launch (fz_xattn_chain, front
+        form): o1 = attn1's attention output [N, L, C], hs = attn1's residual.  Falls back to the separate launches when the controller wants
+        the maps of this call.  Returns what forward_cross returns."""
+        n, lq, c = o1.shape
+        plan = _plan_for(self.controller, True, self.place_in_unet, n, clip, self.heads, lq, ctx.shape[1], o1.device)
+        if plan is None or (plan.mode == K.FZ_ATTN_FLASH):
+            _, _, kvp = self._context_kv(ctx, want_pack=True)
+            packed = self._chain_weights(o1.device, (attn1_out, norm_in))
+            g3, b3 = ln_next.packed(o1.device)
+            bo = self.to_out[0].packed(o1.dtype, o1.device)[1]
+            y, yln, _ = K.xattn_chain(o1, packed, kvp, bo, res=hs, frames_per_batch=clip, heads=self.heads, lk=ctx.shape[1], scale=self.scale,
+                                      ln=(g3, b3, ln_next.eps), front_eps=norm_in.eps)
+            return y, Prenormed(yln)
+        hs1, st = _out_proj(attn1_out, o1, hs, False, norm_in)
+        return self.forward_cross(x.like(hs1), ctx, clip, residual=hs1, norm=norm_in, stats=st, ln_next=ln_next, plan=plan)
 
     def _generic_controller_call(self, controller, is_cross, q, k, vt, out, clip, lq, lk_total, run_capture, run_inject):
         """Reference protocol for a controller that only has __call__: materialise P, call it, apply the result.
@@ -172,12 +231,25 @@ class CrossAttention(nn.Module):
         run_inject(p)
 
     # -- cross attention (attention_register.py:71-128) ------------------------------------------------------
-    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None, norm=None, stats=None, want_stats=False, ln_next=None):
+    def forward_cross(self, x: Tokens, ctx, clip: int, residual=None, norm=None, stats=None, want_stats=False, ln_next=None, plan=False):
         """x.data: hidden states [N, L, C] -- LayerNorm'ed, or RAW together with (`norm`, `stats` = the row sums their producer
         wrote): the LayerNorm then rides in the to_q GEMM (fz_gemm_ln); ctx: [B, 77, Dctx] fp16.  Returns residual +
         to_out(attention) (the block's `hidden_states = attn2(...) + hidden_states`, attention.py:303-311, fused into the GEMM
         epilogue), plus that result's row statistics when want_stats."""
         n, lq, c = x.data.shape
+        ctrl = self.controller
+        if plan is False:  # (a plan handed in was already taken from the controller for THIS call: forward_cross_after's fall-back)
+            if (ln_next is not None and residual is not None and residual.is_contiguous() and not want_stats
+                    and self._chain_applies(n, lq, c, x.data.dtype, ctx)):
+                plan = _plan_for(ctrl, True, self.place_in_unet, n, clip, self.heads, lq, ctx.shape[1], x.data.device)
+                if plan is None or plan.mode == K.FZ_ATTN_FLASH:  # to_q -> cross-attention -> to_out + residual + LayerNorm in one launch
+                    xn = stats.t if isinstance(stats, Prenormed) else (x.data if norm is None else layer_norm_tokens(norm, x.data))
+                    _, _, kvp = self._context_kv(ctx, want_pack=True)
+                    g3, b3 = ln_next.packed(xn.device)
+                    y, yln = K.xattn_chain(xn.contiguous(), self._chain_weights(xn.device), kvp, self.to_out[0].packed(xn.dtype, xn.device)[1],
+                                           res=residual, frames_per_batch=clip, heads=self.heads, lk=ctx.shape[1], scale=self.scale,
+                                           ln=(g3, b3, ln_next.eps))
+                    return y, Prenormed(yln)
         if isinstance(stats, Prenormed):  # LN(x) came out of the producing projection's epilogue
             q = self.to_q.apply(stats.t)
         elif norm is not None:
@@ -190,20 +262,12 @@ class CrossAttention(nn.Module):
                 q = self.to_q.apply(layer_norm_tokens(norm, x.data))
         else:
             q = self.to_q.apply(x.data)
-        # K / V^T of the text context depend only on (ctx, weights): the DDIM loops pass the same embedding tensor at
-        # every step, so they are projected once per job instead of once per layer call (16 x 100 times per job)
-        kvc = self._ctx_kv
-        if kvc is not None and kvc[0] is ctx and kvc[1] == ctx._version:
-            kk, vt = kvc[2], kvc[3]
-        else:
-            kk = self.to_k.apply(ctx)
-            vt = K.gemm_vt(ctx, self.to_v.packed(ctx.dtype, ctx.device)[0], K.CROSS_KEYS)  # V^T straight out of the GEMM
-            self._ctx_kv = (ctx, ctx._version, kk, vt)
+        kk, vt, _ = self._context_kv(ctx)
         lk = ctx.shape[1]
         out = torch.empty(n, lq, self.inner_dim, dtype=q.dtype, device=q.device)
         kw = dict(clip_len=clip, heads=self.heads, lk=lk, scale=self.scale)
-        ctrl = self.controller
-        plan = _plan_for(ctrl, True, self.place_in_unet, n, clip, self.heads, lq, lk, q.device)
+        if plan is False:
+            plan = _plan_for(ctrl, True, self.place_in_unet, n, clip, self.heads, lq, lk, q.device)
         if plan is None:
             if lq > 32 ** 2:
                 K.attn_cross(q, kk, vt, out, mode=K.FZ_ATTN_FLASH, **kw)
@@ -276,6 +340,7 @@ class CrossAttention(nn.Module):
         self._qkv = None
         self._qkv_self = None
         self._ctx_kv = None
+        self._xchain = {}
         self._ln_fold = None
         return super().load_state_dict(*a, **k)
 
@@ -321,7 +386,7 @@ class _ShardedKV:
 class SparseCausalAttention(CrossAttention):
     """attention.py:340-422 / attention_register.py:131-218: frame f attends the K/V of frames idx_j(f)."""
 
-    def forward_self(self, x: Tokens, clip: int, index_list, residual=None, want_stats=False, ln_next=None):
+    def forward_self(self, x: Tokens, clip: int, index_list, residual=None, want_stats=False, ln_next=None, raw_out=False):
         n, lq, c = x.data.shape
         xn = x.data
         # head dims with a free MFMA contraction slot (SD-1.x: 40): the softmax scale and log2(e) go into Wq, q comes out of
@@ -381,6 +446,8 @@ class SparseCausalAttention(CrossAttention):
                                 row_mask=plan.row_mask, **rest, **kw)
                 elif not (plan.mode == K.FZ_ATTN_FLASH and plan.capture_first is not None):
                     K.attn_self(q, kk, vt, out, mode=plan.mode, p=plan.p, **rest, **kw)
+        if raw_out:  # the output projection rides in the launch that follows (forward_cross_after)
+            return out
         return _out_proj(self.to_out[0], out, residual, want_stats, ln_next)
 
 
@@ -489,11 +556,16 @@ class SpatioTemporalTransformerBlock(nn.Module):
         # them (fz_gemm_ln; `st` is None where that form does not apply and the LayerNorm kernel runs instead).  norm1 stays a
         # kernel: its output also feeds the transposed V projection.
         n1 = prenorm1 if prenorm1 is not None else layer_norm_tokens(self.norm1, hs)
-        hs, st = self.attn1.forward_self(x.like(n1), clip, self.sc_index, residual=hs,
-                                         want_stats=LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C, ln_next=self.norm2 if lnp else None)
         want = LN_FUSION and hs.shape[-1] <= LN_FUSION_MAX_C
-        hs, st = self.attn2.forward_cross(x.like(hs), ctx, clip, residual=hs, norm=self.norm2, stats=st, want_stats=want,
-                                          ln_next=self.norm3 if lnp else None)
+        if (lnp and XATTN_CHAIN_FRONT and not want and hs.is_contiguous()
+                and self.attn2._chain_applies(hs.shape[0], hs.shape[1], hs.shape[2], hs.dtype, ctx)):
+            # attn1.to_out + residual + norm2 -> attn2 (to_q, cross-attention, to_out) + residual + norm3: ONE launch behind the self-attention
+            o1 = self.attn1.forward_self(x.like(n1), clip, self.sc_index, raw_out=True)
+            hs, st = self.attn2.forward_cross_after(x, o1, self.attn1.to_out[0], hs, self.norm2, ctx, clip, self.norm3)
+        else:
+            hs, st = self.attn1.forward_self(x.like(n1), clip, self.sc_index, residual=hs, want_stats=want, ln_next=self.norm2 if lnp else None)
+            hs, st = self.attn2.forward_cross(x.like(hs), ctx, clip, residual=hs, norm=self.norm2, stats=st, want_stats=want,
+                                              ln_next=self.norm3 if lnp else None)
         hs, st = self.ff.apply(hs, res=hs, norm=self.norm3, stats=st, want_stats=want, ln_next=self.norm_temporal if lnp else None)
         hs = self.attn_temporal.forward_temporal(hs, x.b, clip, residual=hs, norm=self.norm_temporal, stats=st)
         return x.like(hs)

@@ -126,6 +126,8 @@ class UNetPseudo3DConditionModel(nn.Module):
             for a in ("_packed", "_qk", "_qkv", "_ctx_kv", "_ln_fold", "_chain"):
                 if hasattr(m, a):
                     setattr(m, a, None)
+            if hasattr(m, "_xchain"):
+                m._xchain = {}
 
     def load_state_dict(self, *a, **k):
         self.invalidate_packed()

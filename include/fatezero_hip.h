@@ -222,6 +222,47 @@ int fz_ff_chain_pack(const void* w1, const void* b1, const void* w2, void* packe
 int fz_ff_chain(const void* xn, const void* packed, const void* b2, const void* res, void* y, const void* ln_gamma, const void* ln_beta,
                 float ln_eps, void* y_ln, int64_t rows, int channels, int inner, void* stream);
 
+/* The CROSS-ATTENTION CHAIN of the 64x64-level transformer block in ONE launch (csrc/xattn_chain.hip): `attn2(norm2(x), context) + x` and the
+ * LayerNorm that consumes it (attention.py:303-311 through the patched forward attention_register.py:71-128; diffusers CrossAttention [3P]):
+ *   q = xn Wq^T ;  P = softmax(q_h K_h^T * scale) over the lk text keys ;  o_h = P V_h ;  y = o Wo^T + bias_out + res ;  y_ln = LayerNorm(y)
+ * and with `front` != 0 the step in front of it as well (attention.py:295-301): x is then attn1's attention output and
+ *   y1 = x Wo1^T + bias_out1 + res ;  xn = LayerNorm(y1; ln1_gamma, ln1_beta, ln1_eps) ;  ... ;  y = o Wo^T + bias_out + y1
+ * (bias_out1, ln1_gamma, ln1_beta travel in the pack).
+ * No controller reads or edits maps of more than 32 x 32 queries (attention_store.py:83, attention_util.py:104): this is the plain branch.
+ * x, res, y, y_ln, y1: [rows][channels] fp16, contiguous rows; channels == 320, heads == 8; rows_per_frame % 128 == 0; frame n uses text context
+ * n / frames_per_batch.  Operands come PRE-PACKED as the MFMA fragments the kernel streams: fz_xattn_chain_pack (Wq, Wo [320][320] and, for
+ * `front`, Wo1 with its bias (or NULL) and the LayerNorm's gamma / beta -- wo1 == NULL packs the form without it;
+ * fz_xattn_chain_pack_bytes(with_front) bytes) once per weight set; fz_xattn_chain_kv_pack
+ * (K [batch][lk][320] and V^T [batch][320][>= 96] as fz_attn_cross takes them; fz_xattn_chain_kv_pack_bytes(batch) bytes) once per context.
+ * Results are bit-identical to fz_gemm + fz_attn_cross(FZ_ATTN_FLASH) + fz_gemm_lnout (and fz_gemm_lnout in front).
+ * fz_xattn_chain_ok: 1 where the launch exists; fz_xattn_chain_preferred: 1 where it is also the faster form on MI355X. */
+typedef struct FzXattnChain {
+    const void* x;          /* front == 0: LayerNorm'ed hidden states;  front != 0: attn1's attention output             */
+    const void* res;        /* residual (front == 0: of attn2, may be NULL;  front != 0: of attn1, required)             */
+    const void* packed;     /* fz_xattn_chain_pack                                                                        */
+    const void* kv_packed;  /* fz_xattn_chain_kv_pack                                                                     */
+    const void* bias_out;   /* [channels] or NULL                                                                         */
+    void* y;
+    void* y_ln;             /* or NULL                                                                                    */
+    const void* ln_gamma;
+    const void* ln_beta;
+    void* y1;               /* front: attn1's result                                                                      */
+    int64_t rows, rows_per_frame;
+    int32_t frames_per_batch, channels, heads, lk;
+    float scale;            /* softmax scale (head_dim ** -0.5)                                                           */
+    float ln_eps, ln1_eps;
+    int32_t front;
+} FzXattnChain;
+int fz_xattn_chain_ok(int64_t rows, int64_t rows_per_frame, int channels, int heads, int lk);
+int fz_xattn_chain_preferred(int64_t rows, int64_t rows_per_frame, int channels, int heads, int lk);
+int64_t fz_xattn_chain_pack_bytes(int with_front);
+int64_t fz_xattn_chain_kv_pack_bytes(int batch);
+int fz_xattn_chain_pack(const void* wq, const void* wo, const void* wo1, const void* bias_out1, const void* ln1_gamma, const void* ln1_beta,
+                        void* packed, void* stream);
+int fz_xattn_chain_kv_pack(const void* k, int64_t k_batch_stride, int64_t k_row_stride, const void* vt, int64_t vt_batch_stride,
+                           int64_t vt_chan_stride, int batch, int lk, void* packed, void* stream);
+int fz_xattn_chain(const FzXattnChain* desc, void* stream);
+
 /* LayerNorm fused around fz_gemm (the `norm2 / norm3 / norm_temporal` + Linear pairs of SpatioTemporalTransformerBlock,
  * attention.py:295-337: `attn(norm(x)) + x`).  Two independent halves:
  *   stats_out  the GEMM that PRODUCES a LayerNorm input (out-projection + residual) also writes, per output row, the sum and the

@@ -12,7 +12,7 @@ from fatezero_amd import kernels as K
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 NAMES = ["attn_self", "attn_cross", "attn_temporal", "blend_mask", "groupnorm", "groupnorm_cat", "groupnorm_stats", "groupnorm_apply",
-         "groupnorm_from_partial", "gemm_gn", "gemm_lnout", "gemm", "gemm_batched", "gemm_vt", "gemm_qkvt", "conv3x3", "temporal_conv3", "lora_pair",
+         "groupnorm_from_partial", "gemm_gn", "gemm_lnout", "ff_chain", "gemm", "gemm_batched", "gemm_vt", "gemm_qkvt", "conv3x3", "temporal_conv3", "lora_pair",
          "layernorm", "geglu", "softmax_rows", "transpose_pad", "latent_update", "accumulate"]
 events = []
 depth = [0]

@@ -650,6 +650,94 @@ def case_ff_chain(device, *, rows, inner=1280, bias=True, res=True, ln=True, see
     return out
 
 
+def case_xattn_chain(device, *, n, tokens, clip=1, lk=77, front=False, bias=True, ln=True, seed=0, exact=True):
+    """fz_xattn_chain (csrc/xattn_chain.hip): attn2 of a 320-channel block -- to_q -> 77-key cross-attention -> to_out + residual + LayerNorm --
+    in ONE launch; `front`: attn1.to_out + residual + norm2 in front of it in the same launch.  BIT-IDENTICAL to the launches it replaces
+    (fz_gemm + fz_attn_cross + fz_gemm_lnout, and fz_gemm_lnout in front) and within fp16 rounding of fp32 torch."""
+    g = torch.Generator().manual_seed(seed)
+    c, heads, dh = 320, 8, 40
+    nb = (n + clip - 1) // clip
+    x = (torch.randn(n, tokens, c, generator=g) * 1.2).half()
+    res = (torch.randn(n, tokens, c, generator=g) * 1.5).half()
+    wq = (torch.randn(c, c, generator=g) * c ** -0.5 * 2.0).half()
+    wk = (torch.randn(c, 768, generator=g) * 768 ** -0.5 * 2.0).half()
+    wv = (torch.randn(c, 768, generator=g) * 768 ** -0.5).half()
+    wo = (torch.randn(c, c, generator=g) * c ** -0.5).half()
+    bo = (torch.randn(c, generator=g) * 0.3).half() if bias else None
+    wo1 = (torch.randn(c, c, generator=g) * c ** -0.5).half()
+    bo1 = (torch.randn(c, generator=g) * 0.3).half() if bias else None
+    ctx = torch.randn(nb, lk, 768, generator=g).half()
+    gam = [(1.0 + 0.2 * torch.randn(c, generator=g)).half() for _ in range(2)]
+    bet = [(0.1 * torch.randn(c, generator=g)).half() for _ in range(2)]
+    dev = lambda t: None if t is None else t.to(device)
+    scale = dh ** -0.5
+    assert K.xattn_chain_ok(n * tokens, tokens, c, heads, lk)
+    kk = K.gemm(dev(ctx), dev(wk))
+    vt = K.gemm_vt(dev(ctx), dev(wv), K.CROSS_KEYS)
+    kvp = K.xattn_chain_kv_pack(kk, vt, lk)
+    packed = K.xattn_chain_pack(dev(wq), dev(wo), (dev(wo1), dev(bo1), dev(gam[0]), dev(bet[0])) if front else None)
+    lnp = (dev(gam[1]), dev(bet[1]), 1e-5) if ln else None
+    kw = dict(res=dev(res), frames_per_batch=clip, heads=heads, lk=lk, scale=scale, ln=lnp)
+    if front:
+        y, yln, y1 = K.xattn_chain(dev(x), packed, kvp, dev(bo), front_eps=1e-5, **kw)
+    else:
+        y, yln = K.xattn_chain(dev(x), packed, kvp, dev(bo), **kw)
+        y1 = None
+    assert (yln is None) == (not ln)
+    # ---- the launches it replaces
+    if front:
+        # (tile 254122 = 320 x 128: the whole-row tile the 64x64 level takes; small test shapes would get another one and no LayerNorm)
+        y1r, xnr = K.gemm_lnout(dev(x), dev(wo1), dev(bo1), (dev(gam[0]), dev(bet[0]), 1e-5), res=dev(res), split_k=1, tile_cfg=254122)
+        assert xnr is not None
+        resr = y1r
+    else:
+        xnr, resr = dev(x), dev(res)
+    q = K.gemm(xnr, dev(wq), split_k=1)
+    o = torch.empty_like(q)
+    K.attn_cross(q, kk, vt, o, clip_len=clip, heads=heads, lk=lk, scale=scale)
+    if ln:
+        yr, ylnr = K.gemm_lnout(o, dev(wo), dev(bo), lnp, res=resr, split_k=1, tile_cfg=254122)
+    else:
+        yr, ylnr = K.gemm(o, dev(wo), dev(bo), res=resr, split_k=1), None
+    out = {"vs_launches": float((y.float() - yr.float()).abs().max())}
+    if front:
+        out["y1_vs_launch"] = float((y1.float() - y1r.float()).abs().max())
+    # ---- fp32 torch on the fp16 operands (q, o and the LayerNorm output rounded to fp16 as every fp16 pipeline stores them)
+    xf, rf = x.float(), res.float()
+    if front:
+        h1 = (xf @ wo1.float().t() + (bo1.float() if bias else 0.0)).half().float() + rf
+        h1 = h1.half().float()
+        xn = F.layer_norm(h1, (c,), gam[0].float(), bet[0].float(), 1e-5).half().float()
+        rf = h1
+    else:
+        xn = xf
+    qf = (xn @ wq.float().t()).half().float().reshape(n, tokens, heads, dh).permute(0, 2, 1, 3)
+    kf = kk.float().cpu().reshape(nb, lk, heads, dh).permute(0, 2, 1, 3)
+    vf = vt.float().cpu()[:, :, :lk].reshape(nb, heads, dh, lk).permute(0, 1, 3, 2)
+    bidx = torch.arange(n) // clip
+    pr = (qf @ kf[bidx].transpose(-1, -2) * scale).softmax(-1)
+    of = (pr @ vf[bidx]).permute(0, 2, 1, 3).reshape(n, tokens, c).half().float()
+    ref = of @ wo.float().t() + (bo.float() if bias else 0.0) + rf
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((y.float().cpu() - ref).abs().max())
+    assert torch.isfinite(y.float()).all() and err < 6e-3 * sc, (err, sc)
+    out["max_err"] = err
+    if ln:
+        lref = F.layer_norm(y.float().cpu(), (c,), gam[1].float(), bet[1].float(), 1e-5)
+        e_ln = float((yln.float().cpu() - lref).abs().max())
+        assert e_ln < 2e-3 * max(1.0, float(lref.abs().max())), e_ln
+        out["ln_vs_torch"] = e_ln
+    if exact:
+        if front:
+            assert torch.equal(y1, y1r), out
+        assert torch.equal(y, yr), out
+        if ln and ylnr is not None:
+            assert torch.equal(yln, ylnr)
+    else:
+        assert out["vs_launches"] <= 2 * 2.0 ** -10 * sc, out
+    return out
+
+
 def case_gn_from_epilogue(device, *, n, clip, tokens, cin, cout, groups=32, producer="tconv", seed=0):
     """GroupNorm statistics out of the PRODUCING launch's epilogue (fz_temporal_conv3_gn / fz_gemm_gn -> fz_groupnorm_from_partials): the
     producer's output must be bit-identical to the plain launch, and GroupNorm(+SiLU) from the epilogue's partials must match both the

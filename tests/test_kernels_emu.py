@@ -366,6 +366,89 @@ def test_feed_forward_chain_in_one_launch():
     KC.case_ff_chain(DEV, rows=300, inner=1280, seed=3)
 
 
+def test_cross_attention_chain_in_one_launch():
+    """csrc/xattn_chain.hip on the emulator: to_q -> 77-key cross-attention -> to_out + residual + LayerNorm in one launch, with and without
+    attn1's output projection + norm2 in front; several frames / text contexts / workgroups per frame, fewer keys, no bias / LayerNorm;
+    bit-identical to fz_gemm + fz_attn_cross + fz_gemm_lnout."""
+    r = KC.case_xattn_chain(DEV, n=1, tokens=128)
+    assert r["vs_launches"] == 0.0
+    KC.case_xattn_chain(DEV, n=4, tokens=256, clip=2, seed=1)
+    KC.case_xattn_chain(DEV, n=2, tokens=128, bias=False, ln=False, seed=2, lk=50)
+    r = KC.case_xattn_chain(DEV, n=1, tokens=128, front=True, seed=3)
+    assert r["vs_launches"] == 0.0 and r["y1_vs_launch"] == 0.0
+    KC.case_xattn_chain(DEV, n=3, tokens=256, clip=2, front=True, seed=4)
+    KC.case_xattn_chain(DEV, n=2, tokens=128, front=True, bias=False, ln=False, seed=5, lk=96)
+
+
+def test_gemm_vt_pads_rows_beyond_a_short_context():
+    """fz_gemm(transpose_out): columns [rows, rows_store) are zeros also when they lie in a column tile no input row falls into (a context of
+    <= 64 keys padded to 96: the second 64-wide tile holds padding only)."""
+    for l in (50, 56, 64):
+        KC.case_gemm_vt(DEV, n=2, l=l, k=64, c=80, lp=96)
+
+
+def test_transformer_block_takes_the_cross_attention_chain(monkeypatch):
+    """models/attention.py SpatioTemporalTransformerBlock at 320 channels with more than 32 x 32 tokens per frame: with fz_xattn_chain preferred
+    attn1's output projection, norm2, attn2 and norm3 are ONE launch (front form) -- or attn2 + norm3 alone (XATTN_CHAIN_FRONT off) -- and the
+    block's output is that of the separate launches.  A controller still sees its layer calls in the reference's order."""
+    from fatezero_amd.video_diffusion.models import attention as A
+    from fatezero_amd.video_diffusion.models.resnet import Tokens
+    torch.manual_seed(5)
+    blk = A.SpatioTemporalTransformerBlock(320, 8, 40, cross_attention_dim=64).half()
+    with torch.no_grad():
+        for prm in blk.parameters():
+            if prm.dim() == 1:
+                prm.add_(torch.randn_like(prm) * 0.1)
+        blk.attn_temporal.to_out[0].weight.normal_(0, 0.02)
+    n, l = 2, 1152
+    x = Tokens((torch.randn(n, l, 320) * 0.8).half(), 1, 2, 36, 32)
+    ctx = torch.randn(1, 77, 64).half()
+
+    class Ctl:  # the built-in controllers' planning interface: counts the layer calls, everything plain
+        def __init__(self):
+            self.calls = []
+
+        def attention_plan(self, is_cross, place, n_frames, clip_len, heads, lq, lk, device):
+            self.calls.append((is_cross, lq, lk))
+            return A.AttnPlan(n_frames)
+
+    log = []
+    real = K.xattn_chain
+    monkeypatch.setattr(K, "xattn_chain", lambda *a, **k: (log.append(k.get("front_eps") is not None), real(*a, **k))[1])
+    monkeypatch.setattr(K, "xattn_chain_preferred", lambda rows, rpf, c, h, lk: K.xattn_chain_ok(rows, rpf, c, h, lk))
+    monkeypatch.setattr(K, "ff_chain_preferred", lambda rows, c, inner: False)
+    outs = []
+    for front, chain in ((True, True), (False, True), (False, False)):
+        monkeypatch.setattr(A, "XATTN_CHAIN_FRONT", front)
+        monkeypatch.setattr(A, "XATTN_CHAIN", chain)
+        ctl = Ctl()
+        blk.attn1.controller = blk.attn2.controller = ctl
+        blk.attn1.place_in_unet = blk.attn2.place_in_unet = "down"
+        outs.append(blk.forward_tokens(x, ctx).data)
+        assert ctl.calls == [(False, l, 2 * l), (True, l, 77)]
+    assert log == [True, False]
+    assert torch.isfinite(outs[0].float()).all()
+    # (bit-identity with the separate launches is case_xattn_chain's subject, on the whole-row tile the 64x64 level takes; at this row count the
+    #  separate launches get another tile and a stand-alone fz_layernorm, whose summation order differs from the epilogue's by an fp16 ulp)
+    tol = 4 * 2.0 ** -10 * float(outs[2].float().abs().max())
+    assert float((outs[0].float() - outs[2].float()).abs().max()) <= tol and float((outs[1].float() - outs[2].float()).abs().max()) <= tol
+    # a controller that wants the maps of this call gets the separate launches
+    monkeypatch.setattr(A, "XATTN_CHAIN_FRONT", True)
+    monkeypatch.setattr(A, "XATTN_CHAIN", True)
+
+    class Capt(Ctl):
+        def attention_plan(self, is_cross, place, n_frames, clip_len, heads, lq, lk, device):
+            self.calls.append((is_cross, lq, lk))
+            if is_cross:
+                p = torch.zeros(n_frames, heads, lq, K.CROSS_P_STRIDE, dtype=torch.float16)
+                return A.AttnPlan(0, mode=K.FZ_ATTN_CAPTURE, p=p)
+            return A.AttnPlan(n_frames)
+    ctl = Capt()
+    blk.attn1.controller = blk.attn2.controller = ctl
+    y = blk.forward_tokens(x, ctx).data
+    assert log == [True, False] and float((y.float() - outs[2].float()).abs().max()) <= tol and len(ctl.calls) == 2
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=2, l=64, k=64, c=80, lp=64)
     KC.case_gemm_vt(DEV, n=3, l=77, k=64, c=40, lp=96)

@@ -324,6 +324,17 @@ def test_feed_forward_chain_in_one_launch():
     print(KC.case_ff_chain(DEV, rows=1000, inner=96, seed=4))
 
 
+def test_cross_attention_chain_in_one_launch():
+    """csrc/xattn_chain.hip at the 64x64-level shapes (8 / 16 frames x 4096 tokens x 320, 8 heads of 40, 77 text keys, two text contexts at
+    16 frames): bit-identical to fz_gemm + fz_attn_cross + fz_gemm_lnout (and fz_gemm_lnout in front), within fp16 rounding of fp32 torch."""
+    print(KC.case_xattn_chain(DEV, n=8, tokens=4096, clip=8))
+    print(KC.case_xattn_chain(DEV, n=16, tokens=4096, clip=8, seed=1))
+    print(KC.case_xattn_chain(DEV, n=8, tokens=4096, clip=8, front=True, seed=2))
+    print(KC.case_xattn_chain(DEV, n=16, tokens=4096, clip=8, front=True, seed=3))
+    print(KC.case_xattn_chain(DEV, n=3, tokens=1024, clip=2, front=True, bias=False, ln=False, seed=4, lk=60))
+    print(KC.case_gemm_vt(DEV, n=2, l=50, k=64, c=80, lp=96))
+
+
 def test_gemm_transposed_output():
     KC.case_gemm_vt(DEV, n=8, l=4096, k=320, c=320, lp=4096)
     KC.case_gemm_vt(DEV, n=4, l=1024, k=640, c=640, lp=1024)
