@@ -34,6 +34,7 @@
 // v1 form) instead of inside the MFMA cluster before it
 #ifdef FZ_IGEMM_TRIALS
 __attribute__((weak)) int fz_igemm_trial_no_pp = 0;
+extern "C" { __attribute__((weak)) int fz_igemm_trial_no_kg2 = 0; }  // same-process A/B of the K-group substitution (scripts/ab_lib_flag.py)
 __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute under split-K as well when a K slice has at least this many K-64 steps
 #endif
 // The shipped library reads NO environment variable: the A/B switches of rounds 3-4 (tile order, K slices on XCDs, split-K launch cost)
@@ -48,6 +49,7 @@ __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute 
 #define FZ_PP_NOSTAGGER 4
 #define FZ_PP_PREP_IN_R 8
 #define FZ_PP_K32 16  /* a phase is a whole K tile of 32: one barrier pair per tile, the sub-step-1 fragments re-read inside the cluster */
+#define FZ_KG2 32     /* (ring loop) TWO K groups of WA x WB waves: group g contracts k sub-steps [2 g, 2 g + 2) of every K-64 tile; merged through LDS */
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
 __device__ long long fz_igemm_timing[2][8];
 __device__ long long fz_igemm_timing2[2][2];
@@ -121,8 +123,15 @@ struct IgCfg {
     static_assert(BK == 32 || BK == 64, "K step of 32 or 64 halves");
     // PP: the phase-interleaved ("ping-pong") K loop -- two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) staggered by one
     // barrier, so that one group's MFMA cluster runs while the other group issues fragment reads and LDS-DMA
-    static_assert(!PP || (BK == 32 && NS == 4 && WA * WB == 8), "ping-pong loop: K step 32, 4 slots, 8 waves = two groups of 4");
-    static constexpr int NW = WA * WB, T = 64 * NW;
+    static_assert(!(PP & FZ_PP_ON) || (BK == 32 && NS == 4 && WA * WB == 8), "ping-pong loop: K step 32, 4 slots, 8 waves = two groups of 4");
+    // K groups (FZ_KG2): the 320 x 128 tile as 2 x 2 waves of 5 x 2 MFMA tiles, twice -- each group contracts half of every K-64 step.  Why:
+    // with 8 waves of 5 x 1 tiles the same output tile costs 6 fragment reads per 5 MFMAs and its LDS is busy ~94 % of the matrix time
+    // (8 x 6 ds_read_b128 = 192 LDS cycles + ~110 of LDS-DMA landing per 320 cycles of MFMA per SIMD): the tile is LDS-bound.  5 x 2 tiles
+    // read 7 fragments per 10 MFMAs (~69 %); the two groups' accumulators meet once, in the epilogue.
+    static constexpr int KG = (PP & FZ_KG2) ? 2 : 1;
+    static_assert(KG == 1 || (!(PP & FZ_PP_ON) && BK == 64), "K groups: ring loop, K step 64");
+    static constexpr int NWG = WA * WB;          // waves of one K group = owners of the output tile
+    static constexpr int NW = KG * NWG, T = 64 * NW;
     static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
     static constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
     static constexpr int RPI = 64 / CPR;       // tile rows covered by one LDS-DMA wave instruction (1 KB)
@@ -166,12 +175,13 @@ struct IgCfg {
 // then skips its statistics kernel.  Own instantiations per group width (10 / 20: 320 / 640 channels over 32 groups), so that the
 // statistics pass is straight-line code with its LDS loads in flight together.
 template <int WA, int TA, int WB, int TB, int BK, int NS, int MODE, bool GEGLU, bool LN = false, int PP = 0, bool VT = false, int GS = 0>
-FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::WAVES_PER_SIMD)) igemm_kernel(IgArgs g) {
+FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), (IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::WAVES_PER_SIMD)) igemm_kernel(IgArgs g) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
     const int tid = threadIdx.x, wave = fz_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wa = wave / WB, wb = wave % WB;
+    const int kg = C::KG > 1 ? wave / C::NWG : 0, wq_ = C::KG > 1 ? wave - kg * C::NWG : wave;  // K group, wave inside the group
+    const int wa = wq_ / WB, wb = wq_ % WB;
 #ifdef FZ_IGEMM_TIMING
     const long long tk_entry = clock64();
 #endif
@@ -333,21 +343,22 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
     const char* const b_tile = reinterpret_cast<const char*>(B + b0 * g.ldb);
     const char* a_k = a_tile;
     const char* b_k = b_tile;
-    constexpr bool B_SADDR = PP && MODE == 0;  // plain B rows: scalar base + per-lane offset as well
+    constexpr bool PPL = (PP & FZ_PP_ON) != 0;  // the ping-pong loop (the other bits of PP: its trial forms, and FZ_KG2 for the ring loop)
+    constexpr bool B_SADDR = PPL && MODE == 0;  // plain B rows: scalar base + per-lane offset as well
     auto prep_a = [&]() {
         const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offset along K
-        if constexpr (PP != 0) {
+        if constexpr (PPL) {
             a_k = a_tile + ka;
             return;
         }
         if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
             FZ_COLD_PATH();
 #pragma unroll
-            for (int i = 0; i < C::ACH; ++i) asrc[i] = asc[i] * 8 < ktail && !(PP && apad[i]) ? aptr[i] + ka : zero;
+            for (int i = 0; i < C::ACH; ++i) asrc[i] = asc[i] * 8 < ktail && !(PPL && apad[i]) ? aptr[i] + ka : zero;
         } else {
 #pragma unroll
             for (int i = 0; i < C::ACH; ++i) {
-                if (PP && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
+                if (PPL && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
                     asrc[i] = apad[i] ? zero : aptr[i] + ka;
                 } else {
                     asrc[i] = aptr[i] + ka;
@@ -359,7 +370,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
 #pragma unroll
         for (int i = 0; i < C::ACH; ++i) {
-            if constexpr (PP != 0) {
+            if constexpr (PPL) {
                 const bool pad = (i + 1) * C::NW * C::RPI > C::BA && (i * C::NW + wave) * C::RPI >= C::BA;  // wave-uniform
                 fz_glds16_so(pad ? zero : a_k, aoff[i], Ab + (i * C::NW + wave) * 1024);
             } else {
@@ -392,7 +403,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
             kb += ((int64_t)(ky - 1) * g.Wi + (kx - 1)) * g.ldb * 2;
             need = (1 << ky) | (8 << kx);
         }
-        if (!PP && ikc == g.kchunks - 1 && ktail < BK) {
+        if (!PPL && ikc == g.kchunks - 1 && ktail < BK) {
             FZ_COLD_PATH();
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
@@ -456,7 +467,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
 #ifdef FZ_IGEMM_TIMING
     const long long tk_loop = clock64();
 #endif
-    if constexpr (PP) {
+    if constexpr (PPL) {
         // ---- phase-interleaved loop (cdna_hip_programming.md "The 256^2 8-phase template", T3+T4+T5) --------------------------------
         // K tiles of 32 in a 4-slot ring; a PHASE is one k sub-step of 16:   R: { ds_read the phase's fragments, issue a slice of
         // LDS-DMA }  s_barrier  M: { TA x TB MFMAs at raised priority }  s_barrier.  The waves of group wa = 1 (waves 4-7: the second
@@ -676,7 +687,8 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
         const half_t* As = smem + buf * C::STAGE;
         const half_t* Bs = As + C::A_HALVES;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        for (int kq = 0; kq < BK / 16 / C::KG; ++kq) {
+            const int kk = C::KG > 1 ? kg * (BK / 16 / C::KG) + kq : kq;  // (K groups: this group's half of the K step)
             const int co = ((2 * kk + hi) ^ fsw) * 8;
             half8_t af[TA], bf[TB];
 #pragma unroll
@@ -705,7 +717,34 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
 #endif
     FZ_TK_FLUSH();
 
+    // ---- K groups: the accumulators of group 1 join those of group 0 through LDS (fixed order: group 0 + group 1), as many tiles per pass
+    //      as the ring holds; from here on group 0 owns the output tile, group 1 only lends its threads to the cooperative store loops
+    if constexpr (C::KG > 1) {
+        constexpr int NACC = TA * TB, PERP = (C::LDS_HALVES * 2) / (C::NWG * 4096) < NACC ? (C::LDS_HALVES * 2) / (C::NWG * 4096) : NACC;
+        static_assert(PERP >= 1, "K-group merge staging");
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int p0 = 0; p0 < NACC; p0 += PERP) {
+            __syncthreads();  // the ring (p0 == 0) / the previous pass's readers are done with the LDS
+            if (kg == 1) {
+#pragma unroll
+                for (int a = p0; a < p0 + PERP && a < NACC; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wq_ * PERP + (a - p0)) * 16 + r) * 64 + lane] = acc[a / TB][a % TB][r];
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int a = p0; a < p0 + PERP && a < NACC; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a / TB][a % TB][r] += red[((wq_ * PERP + (a - p0)) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    const bool owner = C::KG == 1 || kg == 0;
+
     // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
+    if (g.part != nullptr && !owner) return;
     if (g.part != nullptr) {
         float* P = g.part + ((int64_t)(ks * gridDim.z + z) * g.Nb) * g.Ma;
 #pragma unroll
@@ -867,7 +906,7 @@ FZ_KERNEL void __launch_bounds__(64 * WA * WB, (IgCfg<WA, TA, WB, TB, BK, NS, GE
     const bool vec_ok = (g.ldy % 8) == 0 && (g.y_bs % 8) == 0 && (g.ldres % 8) == 0 && (g.res_bs % 8) == 0 && (g.temb_stride % 8) == 0;
     for (int ps = 0; ps < WB / C::WBP; ++ps) {
         __syncthreads();  // main loop (ps = 0) / the previous pass's readers are done with the LDS
-        if (wb / C::WBP == ps) {
+        if (wb / C::WBP == ps && owner) {
             const int rl = (wb % C::WBP) * TB * 32 + l31;
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
@@ -1202,7 +1241,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
     if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
-    if (PP && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
+    if ((PP & FZ_PP_ON) && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
     g.tiles_a = fz_ceil_div(g.Ma_store > g.Ma ? g.Ma_store : g.Ma, C::BA);  // (V^T padding rows [Ma, Ma_store) are written as zeros: their tiles run too)
     const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
     const int64_t nt = (int64_t)g.tiles_a * tiles_b;
@@ -1360,6 +1399,9 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
             if (cfg == 522222) return ig_launch<5, 2, 2, 2, 64, 2, MODE, false, false>(g, batch, stream);
         }
 #endif
+        if constexpr (!LN) {  // 320 x 128 as TWO K groups of 2 x 2 waves of 5 x 2 MFMA tiles (IgCfg::KG): the LDS-lean form of 254122
+            if (cfg == 252222) return ig_launch<2, 5, 2, 2, 64, 2, MODE, false, false, FZ_KG2>(g, batch, stream);
+        }
         switch (cfg) {
             case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false, LN>(g, batch, stream);
             case 254122: return ig_launch<2, 5, 4, 1, 64, 2, MODE, false, LN>(g, batch, stream);
@@ -1506,6 +1548,18 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         if (pp_ok) {
             if (cfg == 254222) cfg = 254218;
             if (cfg == 244222) cfg = 244218;
+        }
+        // The 320 x 128 tile of a long-K 3x3 convolution runs as TWO K groups of 2 x 2 waves of 5 x 2 MFMA tiles (252222, IgCfg::KG): 7 fragment
+        // reads per 10 MFMAs instead of 6 per 5 -- the 8-wave 5 x 1 form is LDS-bound.  Same-process interleaved A/B on MI355X
+        // (profiles/r06_kg_tile_ab.txt): +4.6 ... +7 % on the Cin >= 640 convolutions of the 8-frame 64^2 / 16-frame 32^2 launches, equal at
+        // Cin = 320 (nine K-64 steps per tap set: prologue / epilogue-bound) -- exactly those; not under short split-K slices (the merge of the
+        // two groups' accumulators through LDS costs ~1 us per tile).
+        {
+            bool kg_ok = (MODE == 1 || MODE == 3) && cfg == 254122 && g.Cin >= 640 && k64_per_slice >= 8;
+#ifdef FZ_IGEMM_TRIALS
+            if (fz_igemm_trial_no_kg2) kg_ok = false;
+#endif
+            if (kg_ok) cfg = 252222;
         }
         // GEGLU with a short K: the epilogue (64 gelu per lane) is longer than the K loop, and with one 8-wave workgroup per CU nothing
         // runs under it.  The 128 x 256 tile fits a CU twice; same-process A/B on MI355X (profiles/r03_igemm_shortk_two_wg_per_cu.txt):

@@ -86,7 +86,7 @@ FF_CHAIN = os.environ.get("FZ_NO_FF_CHAIN") is None
 # fz_gemm + fz_attn_cross + fz_gemm_lnout; used where no controller touches the maps (more than 32 x 32 queries: attention_store.py:83) and
 # fz_xattn_chain_preferred says the one launch is the faster form.  (env switches: same-box A/B runs)
 XATTN_CHAIN = os.environ.get("FZ_NO_XATTN_CHAIN") is None
-XATTN_CHAIN_FRONT = os.environ.get("FZ_NO_XATTN_FRONT") is None
+XATTN_CHAIN_FRONT = os.environ.get("FZ_XATTN_FRONT") is not None  # (the front form measured EQUAL for the job, profiles/r06_xattn_chain_job_ab.txt: opt-in)
 
 
 class Prenormed:

@@ -154,14 +154,14 @@ def test_conv3x3_small_cin_and_cout():
 
 
 @pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 3), (254222, 2), (254122, 4), (158122, 1),
-                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2)])
+                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2), (252222, 1), (252222, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     # (the ping-pong tiles ..18 have no ragged-K path: Cin a multiple of 32 there)
     KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=96 if tile_cfg % 100 == 18 else 72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218])
+@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222])
 def test_gemm_tile_shapes(tile_cfg):
     KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
 
@@ -272,6 +272,19 @@ def test_gemm_split_k_ragged_tile_counts(rows, o, tile_cfg, split_k):
 def test_conv3x3_split_k_slices_mapped_onto_xcds(n, h, w, cin, cout, tile_cfg, split_k):
     """The same for the convolutions, the launches the flat grid is shipped for (both K orders)."""
     KC.case_conv3x3(DEV, n=n, h=h, w=w, cin=cin, cout=cout, with_temb=True, with_res=True, fpb=n, tile_cfg=tile_cfg, split_k=split_k)
+
+
+def test_k_group_tile_merges_its_two_halves():
+    """Tile 252222 (csrc/igemm.hip IgCfg::KG): 320 x 128 as TWO K groups of 2 x 2 waves of 5 x 2 MFMA tiles -- each group contracts half of
+    every K-64 step, the accumulators meet through LDS in two passes (7 + 3 tiles).  Full tiles, ragged rows / columns / K tails, every conv
+    mode (stride 2, nearest-2x, chunk-outer K order), the temporal convolution and split-K slabs; the result is that of tile 254122 to the
+    rounding of the other summation order."""
+    KC.case_gemm(DEV, rows=384, k=320, o=640, n_res=1, tile_cfg=252222)
+    KC.case_gemm(DEV, rows=200, k=72, o=328, n_res=2, tile_cfg=252222)
+    KC.case_gemm(DEV, rows=130, k=1024, o=320, n_res=1, tile_cfg=252222, split_k=4)
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252222)
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252222)
+    KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=64, upsample=True, tile_cfg=252222)
 
 
 def test_gemm_grouped_tile_order_covers_every_tile_once():
