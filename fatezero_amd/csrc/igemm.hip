@@ -49,7 +49,8 @@ __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute 
 #define FZ_PP_NOSTAGGER 4
 #define FZ_PP_PREP_IN_R 8
 #define FZ_PP_K32 16  /* a phase is a whole K tile of 32: one barrier pair per tile, the sub-step-1 fragments re-read inside the cluster */
-#define FZ_KG2 32     /* (ring loop) TWO K groups of WA x WB waves: group g contracts k sub-steps [2 g, 2 g + 2) of every K-64 tile; merged through LDS */
+#define FZ_KG2 32     /* TWO K groups of WA x WB waves: group g contracts k sub-steps [2 g, 2 g + 2) of every K-64 tile (ring loop); merged through LDS */
+#define FZ_KGPP 64    /* with FZ_KG2: the two K groups in PING-PONG -- K tiles of 32, group g contracts sub-step g of every tile while the other group reads */
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
 __device__ long long fz_igemm_timing[2][8];
 __device__ long long fz_igemm_timing2[2][2];
@@ -129,7 +130,9 @@ struct IgCfg {
     // (8 x 6 ds_read_b128 = 192 LDS cycles + ~110 of LDS-DMA landing per 320 cycles of MFMA per SIMD): the tile is LDS-bound.  5 x 2 tiles
     // read 7 fragments per 10 MFMAs (~69 %); the two groups' accumulators meet once, in the epilogue.
     static constexpr int KG = (PP & FZ_KG2) ? 2 : 1;
-    static_assert(KG == 1 || (!(PP & FZ_PP_ON) && BK == 64), "K groups: ring loop, K step 64");
+    static constexpr bool KGPP = (PP & FZ_KGPP) != 0;
+    static_assert(KG == 1 || (!(PP & FZ_PP_ON) && (KGPP ? (BK == 32 && NS == 4) : BK == 64)), "K groups: ring loop with K step 64, or their own ping-pong loop");
+    static_assert(!KGPP || KG == 2, "the K-group ping-pong loop needs the two groups");
     static constexpr int NWG = WA * WB;          // waves of one K group = owners of the output tile
     static constexpr int NW = KG * NWG, T = 64 * NW;
     static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
@@ -344,21 +347,22 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     const char* a_k = a_tile;
     const char* b_k = b_tile;
     constexpr bool PPL = (PP & FZ_PP_ON) != 0;  // the ping-pong loop (the other bits of PP: its trial forms, and FZ_KG2 for the ring loop)
-    constexpr bool B_SADDR = PPL && MODE == 0;  // plain B rows: scalar base + per-lane offset as well
+    constexpr bool SADDR = PPL || (PP & FZ_KGPP) != 0;  // LDS-DMA in the scalar-base form (no ragged K on these loops): no address VALU per K tile
+    constexpr bool B_SADDR = SADDR && MODE == 0;  // plain B rows: scalar base + per-lane offset as well
     auto prep_a = [&]() {
         const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offset along K
-        if constexpr (PPL) {
+        if constexpr (SADDR) {
             a_k = a_tile + ka;
             return;
         }
         if (ikc == g.kchunks - 1 && ktail < BK) {  // wave-uniform: ragged last chunk of a tap, chunks past Cin read zeros
             FZ_COLD_PATH();
 #pragma unroll
-            for (int i = 0; i < C::ACH; ++i) asrc[i] = asc[i] * 8 < ktail && !(PPL && apad[i]) ? aptr[i] + ka : zero;
+            for (int i = 0; i < C::ACH; ++i) asrc[i] = asc[i] * 8 < ktail && !(SADDR && apad[i]) ? aptr[i] + ka : zero;
         } else {
 #pragma unroll
             for (int i = 0; i < C::ACH; ++i) {
-                if (PPL && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
+                if (SADDR && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
                     asrc[i] = apad[i] ? zero : aptr[i] + ka;
                 } else {
                     asrc[i] = aptr[i] + ka;
@@ -370,7 +374,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
 #pragma unroll
         for (int i = 0; i < C::ACH; ++i) {
-            if constexpr (PPL) {
+            if constexpr (SADDR) {
                 const bool pad = (i + 1) * C::NW * C::RPI > C::BA && (i * C::NW + wave) * C::RPI >= C::BA;  // wave-uniform
                 fz_glds16_so(pad ? zero : a_k, aoff[i], Ab + (i * C::NW + wave) * 1024);
             } else {
@@ -403,7 +407,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
             kb += ((int64_t)(ky - 1) * g.Wi + (kx - 1)) * g.ldb * 2;
             need = (1 << ky) | (8 << kx);
         }
-        if (!PPL && ikc == g.kchunks - 1 && ktail < BK) {
+        if (!SADDR && ikc == g.kchunks - 1 && ktail < BK) {
             FZ_COLD_PATH();
 #pragma unroll
             for (int i = 0; i < C::BCH; ++i) {
@@ -663,6 +667,100 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         for (; j < ntile; ++j) pp_tile(j, std::false_type());
         }
         if (!(PP & FZ_PP_NOSTAGGER) && !late) fz_barrier_raw();  // every wave passes the same number of barriers
+    } else if constexpr (C::KGPP) {
+        // ---- the two K groups in ping-pong -----------------------------------------------------------------------------------------------
+        // K tiles of 32 in a 4-slot ring (tile j in slot j % 4); group g (one wave of each group per SIMD) contracts k sub-step g of every
+        // tile.  ONE barrier per sub-step: in interval 2 j - 1 group 0 READS its fragments of tile j (7 ds_read_b128) and fires its LDS-DMA
+        // pieces of tile j + 3 while group 1 runs the 10 MFMAs of (tile j - 1, sub-step 1); in interval 2 j the roles swap -- the matrix pipe
+        // of a SIMD always has one wave's cluster to run while the other wave does LDS / VMEM / address work, and nobody issues VALU beside
+        // its own MFMAs.  Every wave fires its pieces of every tile (uniform counts: the counted vmcnt): tile j + 3 goes out in the wave's
+        // read interval of tile j, i.e. after the barrier that follows the last read of tile j - 1, whose slot it takes (WAR); tile j + 1
+        // must be complete at the barrier that ends interval 2 j (first read: interval 2 j + 1): every wave waits there with two younger
+        // tiles in flight (RAW).  The fragments travel in registers across the barrier between a group's read and its MFMAs.
+        static_assert(2 * C::PER < 64, "vmcnt field");
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < ntile) issue(s);
+        if (ntile > 2) {
+            fz_wait_vm<2 * C::PER>();
+        } else if (ntile > 1) {
+            fz_wait_vm<C::PER>();
+        } else {
+            fz_wait_vm0();
+        }
+        fz_barrier_nodrain();
+        const int oa = arow + (((kg ? 2 : 0) + hi) ^ fsw) * 8;                  // this group's k sub-step of a tile: per-lane halves offsets
+        const int ob = C::A_HALVES + brow + (((kg ? 2 : 0) + hi) ^ fsw) * 8;
+        half8_t af[TA], bf[TB];
+        // A wave's LDS-DMA pieces of tile j + 3 go out in TWO halves: the B pieces (with their address VALU: the per-lane im2col pointers)
+        // in its read interval of tile j, the A pieces (scalar base + constant lane offsets: no VALU) between the MFMAs of the cluster that
+        // follows -- four pieces in the read interval made it twice as long as a cluster (an LDS-DMA issue costs 100-185 cycles beside
+        // LDS reads, ~60 among MFMAs: MI355X_MICROARCH.md).
+        auto kp_read = [&](int j) {   // this group's fragments of tile j + the B pieces of tile j + 3 (the slot tile j - 1 left)
+            const fz_lds_addr ra = fz_lds_addr_of(smem + (j & 3) * C::STAGE + oa), rb = fz_lds_addr_of(smem + (j & 3) * C::STAGE + ob);
+#pragma unroll
+            for (int q = 0; q < TB; ++q) bf[q] = fz_lds_ld_h8(rb, q * 32 * BK * 2);
+#pragma unroll
+            for (int i = 0; i < TA; ++i) af[i] = fz_lds_ld_h8(ra, i * 32 * BK * 2);
+            if (j + 3 < ntile) {
+                prep_a();
+                prep_b();
+                fire_b((j + 3) & 3);
+            }
+        };
+        auto kp_mma = [&](int j) {    // the cluster of (tile j, this group's sub-step) + the A pieces of tile j + 3
+            fz_setprio_hi();
+            const bool fire = j + 3 < ntile;
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+#pragma unroll
+                for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+                if (i == 1 && fire) fire_a((j + 3) & 3);
+            }
+            fz_setprio_lo();
+        };
+        // (one straight-line loop per group -- the same number of barriers in both: two per tile.  Bare barriers: a group's fragment reads stay
+        //  in flight across the one behind its read interval -- its MFMAs wait for them -- and the slot they read is refilled two barriers later
+        //  at the earliest, by an LDS-DMA that takes longer to land than any ds_read to return.  The counted wait at the end of interval 2 j --
+        //  tile j + 1 complete -- leaves tiles j + 2 and j + 3 in flight; group 1 has only fired the B pieces of tile j + 3 by then.)
+        if (kg == 0) {
+            for (int j = 0; j < ntile; ++j) {
+                kp_read(j);            // interval 2 j - 1
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();
+                FZ_SCHED_FENCE();
+                kp_mma(j);             // interval 2 j
+                if (j + 1 < ntile) {
+                    if (j + 3 < ntile) {
+                        fz_wait_vm<2 * C::PER>();
+                    } else {
+                        fz_wait_vm0();
+                    }
+                }
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();
+                FZ_SCHED_FENCE();
+            }
+        } else {
+            for (int j = 0; j < ntile; ++j) {
+                if (j >= 1) kp_mma(j - 1);  // interval 2 j - 1: (tile j - 1, sub-step 1) + the A pieces of tile j + 2
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();
+                FZ_SCHED_FENCE();
+                kp_read(j);            // interval 2 j
+                if (j + 1 < ntile) {
+                    if (j + 3 < ntile) {
+                        fz_wait_vm<C::PER + C::BCH>();
+                    } else {
+                        fz_wait_vm0();
+                    }
+                }
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();
+                FZ_SCHED_FENCE();
+            }
+            kp_mma(ntile - 1);         // interval 2 ntile - 1
+        }
     } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -1241,7 +1339,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
     if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
-    if ((PP & FZ_PP_ON) && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
+    if ((PP & (FZ_PP_ON | FZ_KGPP)) && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
     g.tiles_a = fz_ceil_div(g.Ma_store > g.Ma ? g.Ma_store : g.Ma, C::BA);  // (V^T padding rows [Ma, Ma_store) are written as zeros: their tiles run too)
     const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
     const int64_t nt = (int64_t)g.tiles_a * tiles_b;
@@ -1401,6 +1499,7 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
 #endif
         if constexpr (!LN) {  // 320 x 128 as TWO K groups of 2 x 2 waves of 5 x 2 MFMA tiles (IgCfg::KG): the LDS-lean form of 254122
             if (cfg == 252222) return ig_launch<2, 5, 2, 2, 64, 2, MODE, false, false, FZ_KG2>(g, batch, stream);
+            if (cfg == 252218) return ig_launch<2, 5, 2, 2, 32, 4, MODE, false, false, FZ_KG2 | FZ_KGPP>(g, batch, stream);  // ... in ping-pong
         }
         switch (cfg) {
             case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false, LN>(g, batch, stream);

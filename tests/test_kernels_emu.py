@@ -154,14 +154,14 @@ def test_conv3x3_small_cin_and_cout():
 
 
 @pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 3), (254222, 2), (254122, 4), (158122, 1),
-                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2), (252222, 1), (252222, 2)])
+                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2), (252222, 1), (252222, 2), (252218, 1), (252218, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     # (the ping-pong tiles ..18 have no ragged-K path: Cin a multiple of 32 there)
     KC.case_conv3x3(DEV, n=2, h=7, w=9, cin=96 if tile_cfg % 100 == 18 else 72, cout=48, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
 
 
-@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222])
+@pytest.mark.parametrize("tile_cfg", [0, 254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222, 252218])
 def test_gemm_tile_shapes(tile_cfg):
     KC.case_gemm(DEV, rows=300, k=96, o=136, n_res=2, tile_cfg=tile_cfg)
 
@@ -285,6 +285,21 @@ def test_k_group_tile_merges_its_two_halves():
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252222)
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252222)
     KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=64, upsample=True, tile_cfg=252222)
+
+
+@pytest.mark.parametrize("k", [32, 64, 96, 128, 160, 224, 256, 320])
+def test_k_group_pingpong_tile_counts(k):
+    """Tile 252218: the two K groups in ping-pong (csrc/igemm.hip KGPP: K tiles of 32, group g contracts sub-step g of every tile while the
+    other group reads / fires LDS-DMA, one barrier per sub-step): 1 .. 10 K tiles walk the prologue / steady state / tail of its ring."""
+    KC.case_gemm(DEV, rows=200, k=k, o=328, n_res=1, tile_cfg=252218)
+
+
+def test_k_group_pingpong_conv_modes():
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252218)
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252218)
+    KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=64, upsample=True, tile_cfg=252218)
+    KC.case_conv3x3(DEV, n=4, h=8, w=8, cin=96, cout=320, with_res=True, fpb=4, tile_cfg=252218, split_k=3)
+    KC.case_gemm(DEV, rows=130, k=1024, o=320, n_res=1, tile_cfg=252218, split_k=4)
 
 
 def test_gemm_grouped_tile_order_covers_every_tile_once():

@@ -195,7 +195,7 @@ def test_conv3x3_small_levels_and_ends(kw):
 
 
 @pytest.mark.parametrize("tile_cfg,split_k", [(254222, 1), (254122, 1), (244222, 1), (224223, 1), (222222, 1), (212222, 1), (222222, 4), (244222, 2), (254222, 4), (254122, 2), (158122, 1), (158122, 2),
-                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2), (252222, 1), (252222, 2)])
+                                              (254218, 1), (244218, 1), (254218, 4), (244218, 2), (252222, 1), (252222, 2), (252218, 1), (252218, 2)])
 def test_conv3x3_every_tile_shape(tile_cfg, split_k):
     KC.case_conv3x3(DEV, n=4, h=16, w=16, cin=640, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=tile_cfg,
                     split_k=split_k)
@@ -225,7 +225,7 @@ def test_gemm_geglu_two_workgroups_per_cu_tile_forced():
     KC.case_gemm(DEV, rows=333, k=320, o=2560, geglu=True, bias=False, tile_cfg=224212)
 
 
-@pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222])
+@pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222, 252218])
 def test_gemm_every_tile_shape(tile_cfg):
     KC.case_gemm(DEV, rows=3000, k=640, o=960, n_res=1, tile_cfg=tile_cfg)
     KC.case_gemm(DEV, rows=520, k=1280, o=320, tile_cfg=tile_cfg, split_k=4)
