@@ -101,7 +101,7 @@ def build_pipeline(device, seed=0, model_config=None):
     return pipe
 
 
-PMC_JOB_FILES = ("r05_pmc_job.json", "r04_pmc_job.json")  # newest in-situ pass first
+PMC_JOB_FILES = ("r06_pmc_job.json", "r05_pmc_job.json", "r04_pmc_job.json")  # newest in-situ pass first
 
 # The same tree measured 2.14 - 2.48 s per job across boxes of this pool (an UNCHANGED flash kernel moved 9 % between the round-3 and the
 # round-4 driver box), so the line carries a normaliser: `box` = a fixed flash launch and a fixed 1 GB copy timed BEFORE the warm-up, the
@@ -558,6 +558,19 @@ def install_timers(K, timer):
     if hasattr(K, "ff_chain"):
         timer.wrap(K, "ff_chain", sel_ff_chain)
 
+    def sel_xattn_chain(x, packed, kv_packed, bias_out, **kw):  # attn2 of a 64x64-level block in one launch (csrc/xattn_chain.hip)
+        if not timer.extra:
+            return None
+        n, l, c = x.shape
+        rows, lk, front = n * l, kw.get("lk", 77), kw.get("front_eps") is not None
+        # 2 rows (2 C C + 2 lk C) FLOP (to_q, to_out, Q K^T, P V; + 2 rows C C with attn1.to_out in front) = 26 FLOP per algorithmic byte:
+        # far below the chip's ridge of 312 -- the launch is priced against the HBM roof on the bytes it must move
+        n_io = 3 + (kw.get("ln") is not None) + (1 if front else 0)                           # x, res in, y out (+ LayerNorm(y)) (+ y1)
+        nbytes = 2.0 * rows * c * n_io + float(packed.numel() + kv_packed.numel())
+        return ("xattn_chain", nbytes, nbytes)
+    if hasattr(K, "xattn_chain"):
+        timer.wrap(K, "xattn_chain", sel_xattn_chain)
+
 
 def gemm_class(x, w, kw):
     """Roofline class of one projection GEMM (>= 1024 rows).  The launches fall into two regimes: plain projections with
@@ -638,6 +651,8 @@ def rooflines(summ):
                          "2 (rows K + rows N (1 + residuals) + K N))", "hbm", 8000.0, "GB/s", 1e9),
             ("ff_chain", "ff_chain_kernel (64x64 level: GEGLU up-projection -> gate -> down-projection + residual + LayerNorm in one launch, "
                          "2 rows (C 2 inner + inner C) FLOP)", "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("xattn_chain", "xattn_chain_kernel (64x64 level: to_q -> 77-key cross-attention -> to_out + residual + LayerNorm in one launch; roof: HBM "
+                            "on its algorithmic bytes 2 rows C (x, res, y, LN(y)) + the packed operands)", "hbm", 8000.0, "GB/s", 1e9),
             ("capture", "attn_self_kernel<CAPTURE> (bytes of the fp16 probability maps written to the HBM arena)", "hbm", 8000.0, "GB/s", 1e9),
             ("inject", "attn_self_kernel<INJECT> (bytes of the stored maps read back)", "hbm", 8000.0, "GB/s", 1e9)):
         sel = {k: v for k, v in summ.items() if k[0] == name}

@@ -11,7 +11,7 @@ for r in rows:
     m = re.search(r'igemm_kernel<([^>]*)>', n)
     if m:
         a = [x.strip() for x in m.group(1).split(',')]
-        key = f"igemm {['gemm','conv3x3','tconv','conv3x3'][int(a[6])]}{' geglu' if a[7]=='true' else ''} tile {a[0]}{a[1]}{a[2]}{a[3]}"
+        key = f"igemm {['gemm','conv3x3','tconv','conv3x3'][int(a[6])]}{' geglu' if a[7]=='true' else ''} tile {a[0]}{a[1]}{a[2]}{a[3]}{' K-groups' if len(a) > 9 and a[9].isdigit() and int(a[9]) & 32 else ''}"
     elif 'lora_pair_kernel' in n: key = 'lora_pair_kernel (both temporal LoRA convolutions)'
     elif 'Cijk' in n: key = 'hipBLASLt Cijk'
     elif 'at::native' in n: key = 'torch ' + re.sub(r'.*native::(\(anonymous namespace\)::)?', '', n)[:40]

@@ -18,6 +18,8 @@ def klass(name):
         return ("capture" if m.group(2) == "1" else "inject") if m else "attn_self"
     if "ff_chain_kernel" in name:
         return "ff_chain"
+    if "xattn_chain_kernel" in name:
+        return "xattn_chain"
     if "igemm_reduce" in name:
         return "splitk_reduce"
     if "lora_pair_kernel" in name:  # both temporal LoRA convolutions in one launch (csrc/lora_pair.hip)
