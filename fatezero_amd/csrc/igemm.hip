@@ -50,6 +50,7 @@ __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute 
 #define FZ_PP_PREP_IN_R 8
 #define FZ_PP_K32 16  /* a phase is a whole K tile of 32: one barrier pair per tile, the sub-step-1 fragments re-read inside the cluster */
 #define FZ_KG2 32     /* TWO K groups of WA x WB waves: group g contracts k sub-steps [2 g, 2 g + 2) of every K-64 tile (ring loop); merged through LDS */
+#define FZ_KGSPREAD 128  /* with FZ_KG2 (ring loop): the LDS-DMA pieces of the next tile go out one by one BETWEEN the MFMAs of the current one */
 #define FZ_KGPP 64    /* with FZ_KG2: the two K groups in PING-PONG -- K tiles of 32, group g contracts sub-step g of every tile while the other group reads */
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
 __device__ long long fz_igemm_timing[2][8];
@@ -443,6 +444,16 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         prep_b();
         fire_b(buf);
     };
+    // (FZ_KGSPREAD) one piece of the prepared tile: p in [0, ACH) = A pieces, [ACH, PER) = B pieces -- the VGPR-address form of the ring loop
+    auto fire_piece = [&](int buf, int p) {
+        char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i)
+            if (i == p) fz_glds16(asrc[i], Ab + (i * C::NW + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < C::BCH; ++i)
+            if (C::ACH + i == p) fz_glds16(bsrc[i], Ab + C::A_HALVES * 2 + (i * C::NW + wave) * 1024);
+    };
     auto pin_a = [&]() {};  // (A: scalar base in the ping-pong loop, nothing per lane)
     auto pin_b = [&]() {  // the prepared addresses exist as registers from here on (not re-derived next to the DMA instruction)
         if constexpr (!B_SADDR) {
@@ -776,10 +787,17 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         FZ_TK(1);
         fz_barrier_nodrain();
         FZ_TK(2);
-        if (it + NS - 1 < ntile) {
-            int nb = buf + NS - 1;
-            nb = nb >= NS ? nb - NS : nb;
-            issue(nb);
+        constexpr bool SPREAD = (PP & FZ_KGSPREAD) != 0;
+        const bool more = it + NS - 1 < ntile;
+        int nb = buf + NS - 1;
+        nb = nb >= NS ? nb - NS : nb;
+        if (more) {
+            if constexpr (SPREAD) {   // the addresses now, the pieces between the MFMAs below
+                prep_a();
+                prep_b();
+            } else {
+                issue(nb);
+            }
         }
         FZ_TK(3);
         const half_t* As = smem + buf * C::STAGE;
@@ -794,9 +812,13 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
 #pragma unroll
             for (int j = 0; j < TB; ++j) bf[j] = fz_ld_h8(Bs + brow + j * 32 * BK + co);
 #pragma unroll
-            for (int i = 0; i < TA; ++i)
+            for (int i = 0; i < TA; ++i) {
 #pragma unroll
                 for (int j = 0; j < TB; ++j) acc[i][j] = fz_mfma_32x32x16_f16(af[i], bf[j], acc[i][j]);
+                if constexpr (SPREAD) {   // one LDS-DMA piece behind every TB MFMAs: 10 slots per K step for the PER = 7 pieces
+                    if (more && kq * TA + i < C::PER) fire_piece(nb, kq * TA + i);
+                }
+            }
         }
         FZ_TK(4);
         FZ_TK_ADD(0, tk0, tk1);
@@ -1500,6 +1522,7 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
         if constexpr (!LN) {  // 320 x 128 as TWO K groups of 2 x 2 waves of 5 x 2 MFMA tiles (IgCfg::KG): the LDS-lean form of 254122
             if (cfg == 252222) return ig_launch<2, 5, 2, 2, 64, 2, MODE, false, false, FZ_KG2>(g, batch, stream);
             if (cfg == 252218) return ig_launch<2, 5, 2, 2, 32, 4, MODE, false, false, FZ_KG2 | FZ_KGPP>(g, batch, stream);  // ... in ping-pong
+            if (cfg == 252226) return ig_launch<2, 5, 2, 2, 64, 2, MODE, false, false, FZ_KG2 | FZ_KGSPREAD>(g, batch, stream);  // ... DMA pieces spread
         }
         switch (cfg) {
             case 254222: return ig_launch<2, 5, 4, 2, 64, 2, MODE, false, LN>(g, batch, stream);

@@ -285,6 +285,11 @@ def test_k_group_tile_merges_its_two_halves():
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252222)
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252222)
     KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=64, upsample=True, tile_cfg=252222)
+    # 252226: the same tile with the next tile's LDS-DMA pieces issued one by one between the MFMAs (FZ_KGSPREAD)
+    KC.case_gemm(DEV, rows=200, k=72, o=328, n_res=2, tile_cfg=252226)
+    KC.case_gemm(DEV, rows=130, k=1024, o=320, n_res=1, tile_cfg=252226, split_k=4)
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252226)
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=72, cout=96, stride=2, tile_cfg=252226)
 
 
 @pytest.mark.parametrize("k", [32, 64, 96, 128, 160, 224, 256, 320])
