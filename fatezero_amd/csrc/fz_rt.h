@@ -102,6 +102,12 @@ FZ_DEVICE void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with a cache policy (AUX: 1 = sc0, 2 = nt, 16 = sc1; sc1 / nt loads are served by L2 and leave the CU's vector L1 alone)
+template <int AUX>
+FZ_DEVICE void fz_glds16_aux(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
 // the same with a wave-uniform 64-bit base (kept in scalar registers) plus a per-lane 32-bit byte offset: the SGPR-base addressing
 // form of the instruction -- advancing the base is scalar work, no VALU per issue
 FZ_DEVICE void fz_glds16_so(const char* sbase_uniform, uint32_t lane_byte_off, void* lds_wave_base) {
@@ -110,6 +116,14 @@ FZ_DEVICE void fz_glds16_so(const char* sbase_uniform, uint32_t lane_byte_off, v
     // register for the compiler as well (it rewrites it in front of every LDS-DMA builtin), so clobbering it here is safe.)
     const uint32_t lds = (uint32_t)(uintptr_t)lds_wave_base;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_byte_off), "s"(sbase_uniform)
+                 : "memory", "m0");
+}
+#ifndef FZ_A_CPOL_ASM
+#define FZ_A_CPOL_ASM ""   /* trial builds: " nt" / " sc1" / " sc1 nt" on the weight operand's LDS-DMA (scalar-base form) */
+#endif
+FZ_DEVICE void fz_glds16_so_a(const char* sbase_uniform, uint32_t lane_byte_off, void* lds_wave_base) {
+    const uint32_t lds = (uint32_t)(uintptr_t)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" FZ_A_CPOL_ASM ::"s"(lds), "v"(lane_byte_off), "s"(sbase_uniform)
                  : "memory", "m0");
 }
 FZ_DEVICE void fz_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -244,6 +258,9 @@ static inline void fz_glds16(const void* gsrc_lane, void* lds_wave_base) {
 static inline void fz_glds16_so(const char* sbase_uniform, uint32_t lane_byte_off, void* lds_wave_base) {
     fz_glds16(sbase_uniform + lane_byte_off, lds_wave_base);
 }
+template <int AUX>
+static inline void fz_glds16_aux(const void* gsrc_lane, void* lds_wave_base) { fz_glds16(gsrc_lane, lds_wave_base); }
+static inline void fz_glds16_so_a(const char* sbase_uniform, uint32_t lane_byte_off, void* lds_wave_base) { fz_glds16_so(sbase_uniform, lane_byte_off, lds_wave_base); }
 static inline void fz_wait_vm0() { fz_emu::dma_wait(0); }
 template <int N>
 static inline void fz_wait_vm() { fz_emu::dma_wait(N); }

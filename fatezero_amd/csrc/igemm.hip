@@ -44,12 +44,17 @@ __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute 
 #else
 #define FZ_TUNING_FLAG(name) false
 #endif
+#ifndef FZ_A_AUX
+#define FZ_A_AUX 0   /* cache policy of the weight operand's LDS-DMA (trial builds: 2 = nt, 16 = sc1: served by L2, the vector L1 left to the pixel rows) */
+#endif
 #define FZ_PP_ON 1
 #define FZ_PP_NOPRIO 2
 #define FZ_PP_NOSTAGGER 4
 #define FZ_PP_PREP_IN_R 8
 #define FZ_PP_K32 16  /* a phase is a whole K tile of 32: one barrier pair per tile, the sub-step-1 fragments re-read inside the cluster */
 #define FZ_KG2 32     /* TWO K groups of WA x WB waves: group g contracts k sub-steps [2 g, 2 g + 2) of every K-64 tile (ring loop); merged through LDS */
+#define FZ_LC 256      /* LOADER / CONSUMER waves: WA x WB consumer waves (one per SIMD) own the output tile and only read fragments + run MFMAs;
+                          as many loader waves (their SIMD partners) issue ALL the LDS-DMA; K tiles of 32, 4 slots */
 #define FZ_KGSPREAD 128  /* with FZ_KG2 (ring loop): the LDS-DMA pieces of the next tile go out one by one BETWEEN the MFMAs of the current one */
 #define FZ_KGPP 64    /* with FZ_KG2: the two K groups in PING-PONG -- K tiles of 32, group g contracts sub-step g of every tile while the other group reads */
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
@@ -130,21 +135,24 @@ struct IgCfg {
     // with 8 waves of 5 x 1 tiles the same output tile costs 6 fragment reads per 5 MFMAs and its LDS is busy ~94 % of the matrix time
     // (8 x 6 ds_read_b128 = 192 LDS cycles + ~110 of LDS-DMA landing per 320 cycles of MFMA per SIMD): the tile is LDS-bound.  5 x 2 tiles
     // read 7 fragments per 10 MFMAs (~69 %); the two groups' accumulators meet once, in the epilogue.
+    static constexpr bool LC = (PP & FZ_LC) != 0;
+    static_assert(!LC || (!(PP & (FZ_PP_ON | FZ_KG2)) && BK == 32 && NS == 4 && WA * WB == 4), "loader / consumer loop: K step 32, 4 slots, 4 + 4 waves");
     static constexpr int KG = (PP & FZ_KG2) ? 2 : 1;
     static constexpr bool KGPP = (PP & FZ_KGPP) != 0;
     static_assert(KG == 1 || (!(PP & FZ_PP_ON) && (KGPP ? (BK == 32 && NS == 4) : BK == 64)), "K groups: ring loop with K step 64, or their own ping-pong loop");
     static_assert(!KGPP || KG == 2, "the K-group ping-pong loop needs the two groups");
     static constexpr int NWG = WA * WB;          // waves of one K group = owners of the output tile
-    static constexpr int NW = KG * NWG, T = 64 * NW;
+    static constexpr int NW = (LC ? 2 : KG) * NWG, T = 64 * NW;
+    static constexpr int NDW = LC ? NWG : NW;     // waves that issue LDS-DMA (LC: the loader waves only)
     static constexpr int BA = WA * TA * 32, BB = WB * TB * 32;
     static constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
     static constexpr int RPI = 64 / CPR;       // tile rows covered by one LDS-DMA wave instruction (1 KB)
     // LDS-DMA instructions per wave per K step; a tile whose rows do not split evenly over the waves is padded with
     // instructions that fetch (clamped) rows nobody reads, so that EVERY wave issues the same number per K step -- the
     // counted vmcnt of the ring depends on it
-    static constexpr int ACH = (BA / RPI + NW - 1) / NW, BCH = (BB / RPI + NW - 1) / NW;
+    static constexpr int ACH = (BA / RPI + NDW - 1) / NDW, BCH = (BB / RPI + NDW - 1) / NDW;
     static constexpr int PER = ACH + BCH;
-    static constexpr int A_HALVES = ACH * NW * 512, B_HALVES = BCH * NW * 512;  // 1 KB = 512 halves per instruction
+    static constexpr int A_HALVES = ACH * NDW * 512, B_HALVES = BCH * NDW * 512;  // 1 KB = 512 halves per instruction
     static constexpr int STAGE = A_HALVES + B_HALVES;
     static constexpr int LDS_HALVES = NS * STAGE;
     static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS ring exceeds 160 KB");
@@ -184,7 +192,8 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     FZ_DYN_SMEM(raw);
     half_t* smem = reinterpret_cast<half_t*>(raw);
     const int tid = threadIdx.x, wave = fz_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int kg = C::KG > 1 ? wave / C::NWG : 0, wq_ = C::KG > 1 ? wave - kg * C::NWG : wave;  // K group, wave inside the group
+    const int kg = (C::KG > 1 || C::LC) ? wave / C::NWG : 0, wq_ = (C::KG > 1 || C::LC) ? wave - kg * C::NWG : wave;  // K group (LC: 1 = loader), wave inside it
+    const int dwave = C::LC ? wq_ : wave;   // index among the waves that issue LDS-DMA
     const int wa = wq_ / WB, wb = wq_ % WB;
 #ifdef FZ_IGEMM_TIMING
     const long long tk_entry = clock64();
@@ -239,7 +248,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     uint32_t aoff[C::ACH], boff[C::BCH];
 #pragma unroll
     for (int i = 0; i < C::ACH; ++i) {
-        const int row = (i * C::NW + wave) * C::RPI + lane / C::CPR;
+        const int row = (i * C::NDW + dwave) * C::RPI + lane / C::CPR;
         asc[i] = pos ^ C::swz(row);
         int ar = a0 + row;
         ar = ar < g.Ma ? ar : g.Ma - 1;
@@ -266,7 +275,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     bool bok[C::BCH];
 #pragma unroll
     for (int i = 0; i < C::BCH; ++i) {
-        const int row = (i * C::NW + wave) * C::RPI + lane / C::CPR;
+        const int row = (i * C::NDW + dwave) * C::RPI + lane / C::CPR;
         bsc[i] = pos ^ C::swz(row);
         int64_t br = b0 + row;
         bok[i] = br < g.Nb;
@@ -348,7 +357,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     const char* a_k = a_tile;
     const char* b_k = b_tile;
     constexpr bool PPL = (PP & FZ_PP_ON) != 0;  // the ping-pong loop (the other bits of PP: its trial forms, and FZ_KG2 for the ring loop)
-    constexpr bool SADDR = PPL || (PP & FZ_KGPP) != 0;  // LDS-DMA in the scalar-base form (no ragged K on these loops): no address VALU per K tile
+    constexpr bool SADDR = PPL || (PP & (FZ_KGPP | FZ_LC)) != 0;  // LDS-DMA in the scalar-base form (no ragged K on these loops): no address VALU per K tile
     constexpr bool B_SADDR = SADDR && MODE == 0;  // plain B rows: scalar base + per-lane offset as well
     auto prep_a = [&]() {
         const int64_t ka = (int64_t)(itap * g.Cin + ikc * BK) * 2;  // wave-uniform byte offset along K
@@ -363,7 +372,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         } else {
 #pragma unroll
             for (int i = 0; i < C::ACH; ++i) {
-                if (SADDR && (i + 1) * C::NW * C::RPI > C::BA) {  // the only instruction slot that can be padding
+                if (SADDR && (i + 1) * C::NDW * C::RPI > C::BA) {  // the only instruction slot that can be padding
                     asrc[i] = apad[i] ? zero : aptr[i] + ka;
                 } else {
                     asrc[i] = aptr[i] + ka;
@@ -376,10 +385,10 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
 #pragma unroll
         for (int i = 0; i < C::ACH; ++i) {
             if constexpr (SADDR) {
-                const bool pad = (i + 1) * C::NW * C::RPI > C::BA && (i * C::NW + wave) * C::RPI >= C::BA;  // wave-uniform
-                fz_glds16_so(pad ? zero : a_k, aoff[i], Ab + (i * C::NW + wave) * 1024);
+                const bool pad = (i + 1) * C::NDW * C::RPI > C::BA && (i * C::NDW + dwave) * C::RPI >= C::BA;  // wave-uniform
+                fz_glds16_so_a(pad ? zero : a_k, aoff[i], Ab + (i * C::NDW + dwave) * 1024);
             } else {
-                fz_glds16(asrc[i], Ab + (i * C::NW + wave) * 1024);
+                fz_glds16_aux<FZ_A_AUX>(asrc[i], Ab + (i * C::NDW + dwave) * 1024);
             }
         }
     };
@@ -432,9 +441,9 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
 #pragma unroll
         for (int i = 0; i < C::BCH; ++i) {
             if constexpr (B_SADDR) {
-                fz_glds16_so(b_k, boff[i], Bb + (i * C::NW + wave) * 1024);
+                fz_glds16_so(b_k, boff[i], Bb + (i * C::NDW + dwave) * 1024);
             } else {
-                fz_glds16(bsrc[i], Bb + (i * C::NW + wave) * 1024);
+                fz_glds16(bsrc[i], Bb + (i * C::NDW + dwave) * 1024);
             }
         }
     };
@@ -449,10 +458,10 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         char* Ab = reinterpret_cast<char*>(smem + buf * C::STAGE);
 #pragma unroll
         for (int i = 0; i < C::ACH; ++i)
-            if (i == p) fz_glds16(asrc[i], Ab + (i * C::NW + wave) * 1024);
+            if (i == p) fz_glds16(asrc[i], Ab + (i * C::NDW + dwave) * 1024);
 #pragma unroll
         for (int i = 0; i < C::BCH; ++i)
-            if (C::ACH + i == p) fz_glds16(bsrc[i], Ab + C::A_HALVES * 2 + (i * C::NW + wave) * 1024);
+            if (C::ACH + i == p) fz_glds16(bsrc[i], Ab + C::A_HALVES * 2 + (i * C::NDW + dwave) * 1024);
     };
     auto pin_a = [&]() {};  // (A: scalar base in the ping-pong loop, nothing per lane)
     auto pin_b = [&]() {  // the prepared addresses exist as registers from here on (not re-derived next to the DMA instruction)
@@ -678,6 +687,69 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
         for (; j < ntile; ++j) pp_tile(j, std::false_type());
         }
         if (!(PP & FZ_PP_NOSTAGGER) && !late) fz_barrier_raw();  // every wave passes the same number of barriers
+    } else if constexpr (C::LC) {
+        // ---- loader / consumer waves ---------------------------------------------------------------------------------------------------
+        // What the ingest microbenchmark says (scripts/ubench_ingest.hip, profiles/r06_ubench_ingest.txt): a wave's burst of LDS-DMA issues
+        // (100-185 cycles a piece while the CU's address path is busy) and its MFMA cluster SERIALISE, and in the ring loop both waves of a SIMD
+        // do both in lockstep -- 56 KB of L2-resident operands take 0.74 us alone, 1.16 us beside 20 MFMAs per wave.  Here the two kinds of
+        // work live in different waves of a SIMD: waves 0-3 (one per SIMD) own the 320 x 128 tile as 2 x 2 waves of 5 x 2 MFMA tiles and do
+        // nothing but fragment reads and MFMAs; waves 4-7 issue every LDS-DMA piece (7 per K-32 tile each) and their address arithmetic.
+        // K tiles of 32 in a 4-slot ring, ONE barrier per tile.  Barrier B(j) -- in front of step j -- has tiles <= j + 1 landed (the
+        // loaders' counted wait in front of it): a consumer contracts tile j with the fragments of (j, sub-step 0) already in registers
+        // (read during step j - 1), reads (j, 1) and then (j + 1, 0) one cluster ahead of their use -- its matrix pipe never waits for an LDS
+        // read behind a barrier.  The loaders refill the slot tile j - 1 left (all its fragments were read before B(j)) with tile j + 3.
+        static_assert(2 * C::PER < 64, "vmcnt field");
+        const bool loader = kg == 1;
+        const int oa0 = arow + (hi ^ fsw) * 8, oa1 = arow + ((2 + hi) ^ fsw) * 8;   // per-lane halves offsets of k sub-steps 0 / 1
+        const int ob0 = C::A_HALVES + brow + (hi ^ fsw) * 8, ob1 = C::A_HALVES + brow + ((2 + hi) ^ fsw) * 8;
+        if (loader) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (t < ntile) issue(t);
+            if (ntile > 2) {
+                fz_wait_vm<C::PER>();     // tiles 0, 1 landed; tile 2 in flight
+            } else {
+                fz_wait_vm0();
+            }
+            fz_barrier_raw();             // B(0)
+            for (int j = 0; j < ntile; ++j) {
+                if (j + 3 < ntile) {
+                    issue((j + 3) & 3);
+                    fz_wait_vm<C::PER>();  // tile j + 2 landed (tile j + 3 in flight)
+                } else {
+                    fz_wait_vm0();
+                }
+                fz_barrier_raw();         // B(j + 1)
+            }
+        } else {
+            half8_t af0[TA], bf0[TB], af1[TA], bf1[TB];
+            auto rd = [&](half8_t* af, half8_t* bf, int slot, int oa, int ob) {
+                const fz_lds_addr ra = fz_lds_addr_of(smem + slot * C::STAGE + oa), rb = fz_lds_addr_of(smem + slot * C::STAGE + ob);
+#pragma unroll
+                for (int q = 0; q < TB; ++q) bf[q] = fz_lds_ld_h8(rb, q * 32 * BK * 2);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) af[i] = fz_lds_ld_h8(ra, i * 32 * BK * 2);
+            };
+            auto mm = [&](const half8_t* af, const half8_t* bf) {
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int q = 0; q < TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+            };
+            fz_barrier_raw();             // B(0)
+            rd(af0, bf0, 0, oa0, ob0);
+            for (int j = 0; j < ntile; ++j) {
+                rd(af1, bf1, j & 3, oa1, ob1);
+                FZ_SCHED_FENCE();
+                mm(af0, bf0);
+                FZ_SCHED_FENCE();
+                if (j + 1 < ntile) rd(af0, bf0, (j + 1) & 3, oa0, ob0);
+                FZ_SCHED_FENCE();
+                mm(af1, bf1);
+                FZ_SCHED_FENCE();
+                fz_barrier_raw();         // B(j + 1)
+            }
+        }
     } else if constexpr (C::KGPP) {
         // ---- the two K groups in ping-pong -----------------------------------------------------------------------------------------------
         // K tiles of 32 in a 4-slot ring (tile j in slot j % 4); group g (one wave of each group per SIMD) contracts k sub-step g of every
@@ -861,7 +933,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
             }
         }
     }
-    const bool owner = C::KG == 1 || kg == 0;
+    const bool owner = (C::KG == 1 && !C::LC) || kg == 0;
 
     // ---- split-K: fp32 partial slab, reduced by igemm_reduce_kernel ---------------------------------------------
     if (g.part != nullptr && !owner) return;
@@ -1361,7 +1433,7 @@ static int ig_launch(IgArgs g, int batch, void* stream) {
     typedef IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP> C;
     g.kchunks = fz_ceil_div(g.Cin, BK);
     if (g.ksplit > g.taps * g.kchunks) return FZ_ERR_BAD_ARG;
-    if ((PP & (FZ_PP_ON | FZ_KGPP)) && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
+    if ((PP & (FZ_PP_ON | FZ_KGPP | FZ_LC)) && (g.Cin % BK)) return FZ_ERR_UNSUPPORTED;  // the ping-pong loop has no ragged-K path (every SD width is a multiple of 32)
     g.tiles_a = fz_ceil_div(g.Ma_store > g.Ma ? g.Ma_store : g.Ma, C::BA);  // (V^T padding rows [Ma, Ma_store) are written as zeros: their tiles run too)
     const int64_t tiles_b = (g.Nb + C::BB - 1) / C::BB;
     const int64_t nt = (int64_t)g.tiles_a * tiles_b;
@@ -1522,6 +1594,7 @@ static int ig_dispatch_cfg(int cfg, const IgArgs& g, int batch, void* stream) {
         if constexpr (!LN) {  // 320 x 128 as TWO K groups of 2 x 2 waves of 5 x 2 MFMA tiles (IgCfg::KG): the LDS-lean form of 254122
             if (cfg == 252222) return ig_launch<2, 5, 2, 2, 64, 2, MODE, false, false, FZ_KG2>(g, batch, stream);
             if (cfg == 252218) return ig_launch<2, 5, 2, 2, 32, 4, MODE, false, false, FZ_KG2 | FZ_KGPP>(g, batch, stream);  // ... in ping-pong
+            if (cfg == 252214) return ig_launch<2, 5, 2, 2, 32, 4, MODE, false, false, FZ_LC>(g, batch, stream);  // 4 consumer + 4 loader waves
             if (cfg == 252226) return ig_launch<2, 5, 2, 2, 64, 2, MODE, false, false, FZ_KG2 | FZ_KGSPREAD>(g, batch, stream);  // ... DMA pieces spread
         }
         switch (cfg) {

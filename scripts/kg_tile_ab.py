@@ -8,6 +8,11 @@ import torch
 sys.path.insert(0, ".")
 from fatezero_amd import kernels as K
 from fatezero_amd import _native as N
+import os
+if os.environ.get("FZ_TRIAL_LIB"):  # an alternative build of the kernel library (same ABI)
+    N.use_test_backend(os.path.abspath(os.environ["FZ_TRIAL_LIB"]))
+    N._is_test_backend = False
+    print("library:", os.environ["FZ_TRIAL_LIB"])
 
 dev = "cuda"
 torch.manual_seed(0)

@@ -299,6 +299,22 @@ def test_k_group_pingpong_tile_counts(k):
     KC.case_gemm(DEV, rows=200, k=k, o=328, n_res=1, tile_cfg=252218)
 
 
+@pytest.mark.parametrize("k", [32, 64, 96, 128, 160, 224, 320])
+def test_loader_consumer_tile_counts(k):
+    """Tile 252214 (csrc/igemm.hip FZ_LC): four consumer waves (fragment reads + MFMAs only) + four loader waves (every LDS-DMA piece): 1 .. 10
+    K tiles walk the prologue / steady state / tail of its 4-slot ring."""
+    KC.case_gemm(DEV, rows=200, k=k, o=328, n_res=1, tile_cfg=252214)
+
+
+def test_loader_consumer_conv_modes():
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252214)
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252214)
+    KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=64, upsample=True, tile_cfg=252214)
+    KC.case_conv3x3(DEV, n=4, h=8, w=8, cin=96, cout=320, with_res=True, fpb=4, tile_cfg=252214, split_k=3)
+    KC.case_gemm(DEV, rows=130, k=1024, o=320, n_res=1, tile_cfg=252214, split_k=4)
+    KC.case_gemm(DEV, rows=384, k=320, o=640, n_res=1, tile_cfg=252214)
+
+
 def test_k_group_pingpong_conv_modes():
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252218)
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252218)
