@@ -34,7 +34,7 @@
 // v1 form) instead of inside the MFMA cluster before it
 #ifdef FZ_IGEMM_TRIALS
 __attribute__((weak)) int fz_igemm_trial_no_pp = 0;
-extern "C" { __attribute__((weak)) int fz_igemm_trial_no_kg2 = 0; }  // same-process A/B of the K-group substitution (scripts/ab_lib_flag.py)
+extern "C" { __attribute__((weak)) int fz_igemm_trial_no_kg2 = 0; __attribute__((weak)) int fz_igemm_trial_no_halo = 0; }  // same-process A/B of the K-group substitution (scripts/ab_lib_flag.py)
 __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute under split-K as well when a K slice has at least this many K-64 steps
 #endif
 // The shipped library reads NO environment variable: the A/B switches of rounds 3-4 (tile order, K slices on XCDs, split-K launch cost)
@@ -2134,6 +2134,12 @@ static int temporal_conv3_impl(const void* x, const void* wt, const void* res, c
     return rc != FZ_OK ? rc : ((gn_partial != nullptr && !want) ? FZ_GEMM_NO_STATS : FZ_OK);
 }
 
+// csrc/conv_halo.hip: the stride-1 convolution with the pixel rows + halo resident in LDS across the nine taps (tile id FZ_TILE_CONV_HALO)
+int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride);
+int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
+                        void* y, int n, int h, int w, int cin, int cout, void* stream);
+#define FZ_TILE_CONV_HALO 154299
+
 extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
                           void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
                           void* workspace, int64_t workspace_floats, int tile_cfg, int split_k, void* stream) {
@@ -2147,6 +2153,21 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
     g.Ho = (hu + 2 - 3) / stride + 1;
     g.Wo = (wu + 2 - 3) / stride + 1;
     if (conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout) != FZ_OK) return FZ_ERR_UNSUPPORTED;
+    if (tile_cfg == FZ_TILE_CONV_HALO) {
+        if (stride != 1 || upsample || split_k > 1 || !fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
+        return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, stream);
+    }
+    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip ONCE (200-320 workgroups: the 8-frame launches of the
+    // 64^2 level, the 16-frame ones of 32^2): +20 ... +28 % there on MI355X (profiles/r06_conv_halo_ab.txt); with 512 tiles (16 frames x 64^2) it
+    // equals the 320 x 256 ping-pong tile, with 128 (8 frames x 32^2) the split-K launch of the implicit GEMM is ahead.
+    if (tile_cfg == 0 && split_k <= 1 && stride == 1 && !upsample && fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) {
+        const int64_t tiles = (int64_t)(cout / 160) * (g.Nb / 256);
+        bool take = tiles >= 200 && tiles <= 320;
+#ifdef FZ_IGEMM_TRIALS
+        if (fz_igemm_trial_no_halo) take = false;
+#endif
+        if (take) return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, stream);
+    }
     if (cin % 8) {  // conv_in (4 input channels): direct VALU convolution
         if (cout % 8 || upsample || cin != 4 || (int64_t)9 * cin * cout * 2 > 64 * 1024 || (temb && g.temb_stride % 8))
             return FZ_ERR_UNSUPPORTED;

@@ -315,6 +315,17 @@ def test_loader_consumer_conv_modes():
     KC.case_gemm(DEV, rows=384, k=320, o=640, n_res=1, tile_cfg=252214)
 
 
+def test_conv3x3_with_the_pixel_halo_resident_in_lds():
+    """csrc/conv_halo.hip (tile id 154299): the stride-1 3x3 convolution whose workgroups keep their pixel rows + halo in LDS across the nine
+    taps (4 consumer waves, 2 weight-loader waves, 2 pixel-loader waves): one / several tiles per frame, image borders at every tile edge,
+    W = 32 and 64, one and several Cin chunks (the halo double buffer), two channel tiles, time-embedding rows + residual."""
+    KC.case_conv3x3(DEV, n=2, h=8, w=32, cin=64, cout=160, tile_cfg=154299)
+    KC.case_conv3x3(DEV, n=2, h=16, w=32, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=154299)
+    KC.case_conv3x3(DEV, n=1, h=8, w=64, cin=192, cout=160, with_res=True, tile_cfg=154299, seed=3)
+    with pytest.raises(Exception):   # shapes it does not carry are refused, not mangled
+        KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=160, tile_cfg=154299)
+
+
 def test_k_group_pingpong_conv_modes():
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252218)
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252218)

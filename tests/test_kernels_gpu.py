@@ -225,6 +225,14 @@ def test_gemm_geglu_two_workgroups_per_cu_tile_forced():
     KC.case_gemm(DEV, rows=333, k=320, o=2560, geglu=True, bias=False, tile_cfg=224212)
 
 
+def test_conv3x3_with_the_pixel_halo_resident_in_lds():
+    """csrc/conv_halo.hip at the judged shapes: 8 / 16 frames x 64^2 x 320 -> 320 (+ time embedding + residual), 640 -> 320, 32^2 x 640 -> 640."""
+    print(KC.case_conv3x3(DEV, n=8, h=64, w=64, cin=320, cout=320, with_temb=True, with_res=True, fpb=8, tile_cfg=154299))
+    print(KC.case_conv3x3(DEV, n=16, h=64, w=64, cin=640, cout=320, with_res=True, fpb=8, tile_cfg=154299, seed=1))
+    print(KC.case_conv3x3(DEV, n=16, h=32, w=32, cin=640, cout=640, with_temb=True, fpb=8, tile_cfg=154299, seed=2))
+    print(KC.case_conv3x3(DEV, n=3, h=8, w=32, cin=64, cout=160, tile_cfg=154299, seed=3))
+
+
 @pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222, 252218])
 def test_gemm_every_tile_shape(tile_cfg):
     KC.case_gemm(DEV, rows=3000, k=640, o=960, n_res=1, tile_cfg=tile_cfg)
