@@ -200,38 +200,25 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         };
         const fz_lds_addr a_kk[2] = {fz_lds_addr_of(Aring) + arow + ((hi ^ asw) << 4), fz_lds_addr_of(Aring) + arow + (((2 + hi) ^ asw) << 4)};
         const int hi4 = hi << 4;
-        int rj = 0, rt = 0, rc = 0, rh = 0, rkk = 0;       // read cursor: step, tap, chunk, K half, k sub-step
-        fz_lds_addr tb[CH_TB];
-        int tu[CH_TB];
-        auto tap_terms = [&]() {
+        // (branch-free: a branch in here is a basic-block boundary between two clusters -- nothing of it can sink into the MFMAs' shadow)
+        int rs = 0, rt = 0, rc = 0;                          // read cursor: k sub-step counter (4 per tap), tap, chunk
+        auto next_addr = [&]() -> Fa {                      // the cursor's addresses; then one sub-step on
+            const int rkk = rs & 1, rh = (rs >> 1) & 1, rj = rs >> 1;
             const int ky = rt / 3, kx = rt - 3 * ky, sh = (ky - 1) * W2 + (kx - 1);
-            const fz_lds_addr hs = fz_lds_addr_of(Hbuf + (rc & 1) * g.hb_bytes);
+            const fz_lds_addr hs = fz_lds_addr_of(Hbuf) + (rc & 1) * g.hb_bytes;
+            const int S = (4 * rh + 2 * rkk) << 4;
+            Fa f;
+            f.a = (rkk ? a_kk[1] : a_kk[0]) + (rj & 3) * CH_ASLOT;
 #pragma unroll
             for (int q = 0; q < CH_TB; ++q) {
                 const int hp = hp0[q] + sh;
-                tb[q] = hs + hp * 128;
-                tu[q] = hi4 ^ ((hp << 3) & 0x70);           // (hi << 4) ^ (((hp >> 1) & 7) << 4)
+                f.b[q] = hs + hp * 128 + ((hi4 ^ ((hp << 3) & 0x70)) ^ S);
             }
-        };
-        tap_terms();
-        auto next_addr = [&]() -> Fa {                      // the cursor's addresses; then one sub-step on
-            Fa f;
-            f.a = a_kk[rkk] + (rj & 3) * CH_ASLOT;
-            const int S = (4 * rh + 2 * rkk) << 4;
-#pragma unroll
-            for (int q = 0; q < CH_TB; ++q) f.b[q] = tb[q] + (tu[q] ^ S);
-            rkk ^= 1;
-            if (rkk == 0) {
-                ++rj;
-                rh ^= 1;
-                if (rh == 0) {
-                    if (++rt == 9) {
-                        rt = 0;
-                        ++rc;
-                    }
-                    tap_terms();
-                }
-            }
+            const int adv = (rs & 3) == 3;                   // the next sub-step opens a new tap
+            const int rt2 = rt + adv, wrap = rt2 == 9;
+            rt = wrap ? 0 : rt2;
+            rc += wrap;
+            ++rs;
             return f;
         };
         auto rd = [&](half8_t* af, half8_t* bf, const Fa& f) {
@@ -263,12 +250,17 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
             // (weight tile j + 1 and, at a chunk's end, the next halo tile landed before B(j): the fragments of (j + 1, 0) are read in step j)
             // (the reads are UNCONDITIONAL -- behind the last step they fetch LDS bytes nobody uses: a read under a branch makes hipcc's merged
             //  lgkmcnt wait in front of the next cluster drain half of the reads just issued)
+#ifndef CH_FENCES
+#define CH_FENCE() ((void)0)   /* (the address arithmetic of the next reads may sink into the clusters' shadow) */
+#else
+#define CH_FENCE() FZ_SCHED_FENCE()
+#endif
             f0 = next_addr();                               // (j + 1, 0)
-            FZ_SCHED_FENCE();
+            CH_FENCE();
             mm_rd(af0, bf0, af1, bf1, f1);                  // cluster (j, 0) + the reads of (j, 1)
             FZ_SCHED_FENCE();
             f1 = next_addr();                               // (j + 1, 1)
-            FZ_SCHED_FENCE();
+            CH_FENCE();
             mm_rd(af1, bf1, af0, bf0, f0);                  // cluster (j, 1) + the reads of (j + 1, 0)
             FZ_SCHED_FENCE();
             {

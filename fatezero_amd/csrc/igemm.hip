@@ -2157,12 +2157,12 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
         if (stride != 1 || upsample || split_k > 1 || !fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
         return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, stream);
     }
-    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip ONCE (200-320 workgroups: the 8-frame launches of the
-    // 64^2 level, the 16-frame ones of 32^2): +20 ... +28 % there on MI355X (profiles/r06_conv_halo_ab.txt); with 512 tiles (16 frames x 64^2) it
-    // equals the 320 x 256 ping-pong tile, with 128 (8 frames x 32^2) the split-K launch of the implicit GEMM is ahead.
+    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip once or twice (200-512 workgroups: the 8- and 16-frame
+    // launches of the 64^2 level, the 16-frame ones of 32^2): +26 % / +21 ... +28 % at one wave of tiles, +1 ... +6 % at two on MI355X
+    // (profiles/r06_conv_halo_ab.txt); with 128 tiles (8 frames x 32^2) the split-K launch of the implicit GEMM is ahead.
     if (tile_cfg == 0 && split_k <= 1 && stride == 1 && !upsample && fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) {
         const int64_t tiles = (int64_t)(cout / 160) * (g.Nb / 256);
-        bool take = tiles >= 200 && tiles <= 320;
+        bool take = tiles >= 200 && tiles <= 512;
 #ifdef FZ_IGEMM_TRIALS
         if (fz_igemm_trial_no_halo) take = false;
 #endif
