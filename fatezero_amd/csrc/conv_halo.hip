@@ -37,6 +37,8 @@ static_assert(CH_BB * CH_OSTR * 2 <= 160 * 1024, "epilogue staging");
 
 #ifdef CH_TIMING  // trial build: cycle totals of consumer wave 0, weight loader 4 and pixel loader 6 of workgroup 0
 __device__ long long ch_timing[3][4];
+__device__ long long ch_timing3[16];   // wall stamps (10 ns) relative to kernel entry of workgroup 0: [0..2] pixel loader after setup / issue / wait; [4..6] weight loader same; [8..11] epilogue after sync / staging / sync / stores
+__device__ long long ch_timing2[12];   // workgroup 0, thread 0: {wall, clock} at entry / loop start / loop end / exit; [8..9] min entry / max exit (wall) of all workgroups
 #define CH_T0() const long long tt0 = clock64()
 #define CH_T1(slot) tacc[slot] += clock64() - tt0
 #else
@@ -51,11 +53,13 @@ struct ChArgs {
     const half_t* temb;    // rows of Cout values, one per temb_group consecutive pixels, or null
     const half_t* res;     // [N H W][Cout] or null
     half_t* y;             // [N H W][Cout]
-    int64_t temb_stride, temb_group;
+    int64_t temb_stride;
+    int temb_frames;       // frames per time-embedding row
     int N, H, W, Cin, Cout;
     int tiles_a;           // Cout / 160
     int hb_bytes;          // bytes of one halo buffer (pieces of 1 KB)
     int np;                // LDS-DMA pieces of a halo tile
+    int w2_magic;          // ceil(65536 / (W + 2)): halo pixel / (W + 2) == (halo pixel * w2_magic) >> 16 for every halo pixel of a tile (host-checked)
 };
 
 FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
@@ -74,12 +78,15 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     const int fn = (int)(px0 / hw), y0 = (int)((px0 - (int64_t)fn * hw) / W);
     unsigned char* const Aring = raw;
     unsigned char* const Hbuf = raw + CH_NAS * CH_ASLOT;
+    unsigned char* const Cpre = Hbuf + 2 * g.hb_bytes;      // 1 KB: bias | time-embedding row of the tile (beyond the epilogue's staging area)
     const int nchunk = g.Cin >> 6, nstep = nchunk * 18;     // a step = (chunk, tap, K half)
     const char* zero = reinterpret_cast<const char*>(ch_zero_page);
 
 #ifdef CH_TIMING
     long long tacc[4] = {0, 0, 0, 0};
     const long long tstart = clock64();
+    const long long w_entry = wall_clock64();
+    long long w_ls = 0, c_ls = 0;
 #endif
     f32x16 acc[CH_TA][CH_TB];
 #pragma unroll
@@ -87,41 +94,65 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
 #pragma unroll
         for (int q = 0; q < CH_TB; ++q) acc[i][q] = fz_zero_f16v();
 
+    // Halo piece p covers halo pixels [8 p, 8 p + 8): lane = (pixel 8 p + lane / 8, physical 16-byte chunk lane % 8) fetches logical chunk
+    // (lane % 8) ^ ((pixel >> 1) & 7) of that pixel -- the swizzle the consumers' ds_read_b128 undo -- or zeros outside the image / the tile.
+    // The per-lane source of a piece for chunk 0 (null: the zero page).  Cheap on purpose (the first version -- a division and 64-bit index
+    // arithmetic per piece, all 25 pieces in the two pixel loaders -- took 3.6 us of set-up + 1.5 us of issue in front of the first MFMA:
+    // profiles/r06_conv_halo_ab.txt): a multiply-shift for the row, 32-bit offsets from the frame's base.
+    const half_t* const xf = g.x + (int64_t)fn * hw * g.Cin;
+    auto piece_src = [&](int p) __attribute__((always_inline)) -> const char* {
+        const int hp = 8 * p + (lane >> 3), pc = lane & 7;
+        const int yy = (hp * g.w2_magic) >> 16, xx = hp - yy * W2;
+        const int iy = y0 + yy - 1, ix = xx - 1;
+        const bool ok = yy < R + 2 && iy >= 0 && iy < g.H && ix >= 0 && ix < W;
+        const int lc = pc ^ ((hp >> 1) & 7);
+        return ok ? reinterpret_cast<const char*>(xf) + (uint32_t)(((iy * W + ix) * g.Cin + lc * 8) * 2) : nullptr;
+    };
+    // chunk 0 of the halo tile: ALL eight waves fetch it (pieces wave, wave + 8, ..: at most 7 each), then take their roles
+    {
+#pragma unroll 1   /* (rolled: straight-line code that runs once pays for its instruction fetches) */
+        for (int p = wave; p < g.np; p += 8) {
+            const char* s0 = piece_src(p);
+            fz_glds16(s0 != nullptr ? s0 : zero + lane * 16, Hbuf + p * 1024);
+        }
+        // one more piece behind the halo buffers: bias (lanes 0-19) and the tile's time-embedding row (lanes 20-39) for the epilogue
+        if (wave == 3) {
+            const char* s0 = zero + lane * 16;
+            if (lane < 20 && g.bias != nullptr) s0 = reinterpret_cast<const char*>(g.bias + a0 + lane * 8);
+            if (lane >= 20 && lane < 40 && g.temb != nullptr)
+                s0 = reinterpret_cast<const char*>(g.temb + (int64_t)(fn / g.temb_frames) * g.temb_stride + a0 + (lane - 20) * 8);
+            fz_glds16(s0, Cpre);
+        }
+    }
+
     if (wave >= 6) {
         // ================================================ pixel loaders ===================================================================
-        // piece p covers halo pixels [8 p, 8 p + 8): lane = (pixel 8 p + lane / 8, physical 16-byte chunk lane % 8) fetches logical chunk
-        // (lane % 8) ^ ((pixel >> 1) & 7) of that pixel -- the swizzle the consumers' ds_read_b128 undo -- or zeros outside the image / the tile
+        // Two pieces per step (26 slots for the <= 25 pieces of the next chunk's tile), their sources worked out on the spot: ~25 VALU per
+        // piece, in a wave that otherwise waits at barriers (a per-piece table cost 3.6 us of set-up in front of the first MFMA).
         const int bl = wave - 6;
-        const int npl = (g.np - bl + 1) / 2;   // pieces of this loader: bl, bl + 2, ...
-        // per-lane source of every piece of this loader for chunk 0 (null: the zero page); a chunk adds 128 bytes
-        const char* src[25];
-#pragma unroll
-        for (int i = 0; i < 25; ++i) {
-            const int p = bl + 2 * i;
-            const int hp = 8 * p + (lane >> 3), pc = lane & 7;
-            const int yy = hp / W2, xx = hp - yy * W2;
-            const int iy = y0 + yy - 1, ix = xx - 1;
-            const bool ok = i < npl && yy < R + 2 && iy >= 0 && iy < g.H && ix >= 0 && ix < W;
-            const int lc = pc ^ ((hp >> 1) & 7);
-            src[i] = ok ? reinterpret_cast<const char*>(g.x + (((int64_t)fn * g.H + iy) * W + ix) * g.Cin + lc * 8) : nullptr;
-        }
-        auto fire = [&](int i, int chunk, int buf) {
-            const char* s = src[i] != nullptr ? src[i] + chunk * 128 : zero + lane * 16;
-            fz_glds16(s, Hbuf + buf * g.hb_bytes + (bl + 2 * i) * 1024);
+        auto fire = [&](int p, int chunk) __attribute__((always_inline)) {
+            const char* s0 = piece_src(p);
+            fz_glds16(s0 != nullptr ? s0 + chunk * 128 : zero + lane * 16, Hbuf + (chunk & 1) * g.hb_bytes + p * 1024);
         };
-#pragma unroll
-        for (int i = 0; i < 25; ++i)
-            if (i < npl) fire(i, 0, 0);
+#ifdef CH_TIMING
+        const long long w_p0 = wall_clock64(), w_p1 = w_p0;
+#endif
         fz_wait_vm0();
+#ifdef CH_TIMING
+        if (blockIdx.x == 0 && tid == 384) { ch_timing3[0] = w_p0 - w_entry; ch_timing3[1] = w_p1 - w_entry; ch_timing3[2] = wall_clock64() - w_entry; }
+#endif
         fz_barrier_raw();                                   // B(0)
         for (int c = 0; c < nchunk; ++c) {
             const bool more = c + 1 < nchunk;
-#pragma unroll
+#pragma unroll 1
             for (int s = 0; s < 18; ++s) {
-                if (more && s < 13) {                       // two pieces per step: 26 slots for the <= 25 pieces
-                    if (2 * s < npl) fire(2 * s, c + 1, (c + 1) & 1);
-                    if (2 * s + 1 < npl) fire(2 * s + 1, c + 1, (c + 1) & 1);
+#ifndef CH_NO_DMA   /* (trial flag: the steady state without a single LDS-DMA -- results are garbage) */
+                if (more && s < 13) {
+                    const int p = bl + 4 * s;               // this loader's pieces bl, bl + 2, ..: two per step
+                    if (p < g.np) fire(p, c + 1);
+                    if (p + 2 < g.np) fire(p + 2, c + 1);
                 }
+#endif
                 if (s == 16) {
                     CH_T0();
                     fz_wait_vm0();                          // the next chunk's tile is complete in front of B(18 c + 17)
@@ -153,20 +184,31 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) fz_glds16_so(base, aoff[i], Aring + (j & 3) * CH_ASLOT + (al + 2 * i) * 1024);
         };
+#ifdef CH_TIMING
+        const long long w_a0 = wall_clock64();
+#endif
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < nstep) issue(j);
+#ifdef CH_TIMING
+        const long long w_a1 = wall_clock64();
+#endif
         if (nstep > 2) {
             fz_wait_vm<5>();                                // tiles 0, 1 landed; tile 2 in flight
         } else {
             fz_wait_vm0();
         }
+#ifdef CH_TIMING
+        if (blockIdx.x == 0 && tid == 256) { ch_timing3[4] = w_a0 - w_entry; ch_timing3[5] = w_a1 - w_entry; ch_timing3[6] = wall_clock64() - w_entry; }
+#endif
         fz_barrier_raw();                                   // B(0)
         for (int j = 0; j < nstep; ++j) {
             {
                 CH_T0();
                 if (j + 3 < nstep) {
+#ifndef CH_NO_DMA
                     issue(j + 3);                           // into the slot tile j - 1 left (all its fragments were read before B(j))
+#endif
                     CH_T1(2);
                     fz_wait_vm<5>();                        // tile j + 2 landed
                 } else {
@@ -229,11 +271,20 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         };
         // one cluster (10 MFMAs on the fragments in af / bf) with the 7 reads of the NEXT fragments interleaved, one behind each of the first MFMAs
         auto mm_rd = [&](const half8_t* af, const half8_t* bf, half8_t* afn, half8_t* bfn, const Fa& fn) {
+#ifndef CH_NO_READS   /* (trial: the MFMAs alone, on stale fragments) */
             rd(afn, bfn, fn);
+#endif
+#ifdef CH_NO_MFMA     /* (trial: the reads alone; each fragment is consumed by an empty asm) */
+#pragma unroll
+            for (int i = 0; i < CH_TA; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+            for (int q = 0; q < CH_TB; ++q) asm volatile("" ::"v"(bf[q]));
+#else
 #pragma unroll
             for (int i = 0; i < CH_TA; ++i)
 #pragma unroll
                 for (int q = 0; q < CH_TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
+#endif
 #ifndef FZ_EMU
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
@@ -243,7 +294,11 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
 #endif
         };
+        fz_wait_vm0();                                      // (this wave's pieces of the first halo chunk)
         fz_barrier_raw();                                   // B(0)
+#ifdef CH_TIMING
+        w_ls = wall_clock64(); c_ls = clock64();
+#endif
         Fa f0 = next_addr(), f1 = next_addr();              // (0, 0), (0, 1)
         rd(af0, bf0, f0);
         for (int j = 0; j < nstep; ++j) {
@@ -263,35 +318,62 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
             CH_FENCE();
             mm_rd(af1, bf1, af0, bf0, f0);                  // cluster (j, 1) + the reads of (j + 1, 0)
             FZ_SCHED_FENCE();
+#ifdef CH_TIMING_CONSUMER   /* (two s_memtime + a full lgkmcnt drain per step: ~100 cycles of the consumers' 640) */
             {
                 CH_T0();
                 fz_barrier_raw();                           // B(j + 1)
                 CH_T1(1);
             }
+#else
+            fz_barrier_raw();                               // B(j + 1)
+#endif
         }
     }
 #ifdef CH_TIMING
+    const long long w_le = wall_clock64(), c_le = clock64();
     tacc[3] = clock64() - tstart;
     if (blockIdx.x == 0 && (tid == 0 || tid == 256 || tid == 384))
         for (int i = 0; i < 4; ++i) ch_timing[tid == 0 ? 0 : (tid == 256 ? 1 : 2)][i] = tacc[i];
 #endif
 
-    // ---- epilogue (igemm.hip's): + bias (fp32) -> fp16 tile through LDS [256 pixels][160 + 8] -> (+ temb row) (+ res) -> full-row 16-byte stores
+    // ---- epilogue (igemm.hip's arithmetic): + bias (fp32) -> fp16 tile through LDS [256 pixels][160 + 8] -> (+ temb row) (+ res) -> full-row
+    // 16-byte stores.  What is fetched from memory is on its way before it is needed: bias and the tile's time-embedding row came into LDS
+    // with the first halo chunk (a tile lies inside one frame: one row for all of it), the residual rows are requested before the staging
+    // (loader waves) / behind it (consumers: their accumulators are dead then) -- the first version's epilogue was 5.2 us, 2.8 of them the
+    // staging waiting for its bias loads.
+    constexpr int OCH = CH_BA / 8, NOUT = CH_BB * OCH / 512;
+    static_assert(CH_BB * OCH % 512 == 0, "the output loop's trip count");
+    const half_t* const res_t = g.res != nullptr ? g.res + px0 * g.Cout + a0 : nullptr;
+    half_t* const y_t = g.y + px0 * g.Cout + a0;
+    half8_t rv[NOUT];
+    auto load_res = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const int id = tid + 512 * k, pl = id / OCH, ch = id - pl * OCH;
+            rv[k] = fz_ld_h8(res_t + (uint32_t)(pl * g.Cout + ch * 8));
+        }
+    };
+    if (wave >= 4 && res_t != nullptr) load_res();
     __syncthreads();
+#ifdef CH_TIMING
+    const long long w_e0 = wall_clock64();
+#endif
     half_t* Cs = reinterpret_cast<half_t*>(raw);
+    const half_t* const bias_l = reinterpret_cast<const half_t*>(Cpre);
+    const half_t* const temb_l = reinterpret_cast<const half_t*>(Cpre) + CH_BA;
     if (wave < 4) {
+        half4_t bvs[CH_TA][4];   // (all of them first: read one by one, each ds_read was waited for on the spot -- 20 LDS latencies in a row)
+#pragma unroll
+        for (int i = 0; i < CH_TA; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) bvs[i][gq] = *reinterpret_cast<const half4_t*>(bias_l + i * 32 + 8 * gq + 4 * hi);
+        FZ_SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < CH_TA; ++i)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int co = i * 32 + 8 * gq + 4 * hi;
-                half4_t bv;
-                if (g.bias != nullptr) {
-                    bv = *reinterpret_cast<const half4_t*>(g.bias + a0 + co);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[e] = (half_t)0.0f;
-                }
+                const half4_t bv = bvs[i][gq];                                        // (zeros without a bias: + 0.0f changes nothing)
 #pragma unroll
                 for (int q = 0; q < CH_TB; ++q) {
                     half4_t v;
@@ -300,38 +382,71 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
                     *reinterpret_cast<half4_t*>(Cs + (64 * wave + 32 * q + l31) * CH_OSTR + co) = v;
                 }
             }
+        FZ_SCHED_FENCE();
+        if (res_t != nullptr) load_res();
     }
+#ifdef CH_TIMING
+    const long long w_e1 = wall_clock64();
+#endif
     __syncthreads();
-    constexpr int OCH = CH_BA / 8;
-    for (int id = tid; id < CH_BB * OCH; id += 512) {
-        const int pl = id / OCH, ch = id - pl * OCH;
-        const int64_t px = px0 + pl;
-        const int co = a0 + ch * 8;
-        const half8_t v = fz_ld_h8(Cs + pl * CH_OSTR + ch * 8);
+#ifdef CH_TIMING
+    const long long w_e2 = wall_clock64();
+#endif
+    half8_t cv[NOUT], tv[NOUT];   // (LDS reads first, arithmetic + stores behind them)
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int id = tid + 512 * k, pl = id / OCH, ch = id - pl * OCH;
+        cv[k] = fz_ld_h8(Cs + pl * CH_OSTR + ch * 8);
+        if (g.temb != nullptr) tv[k] = fz_ld_h8(temb_l + ch * 8);
+    }
+    FZ_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int id = tid + 512 * k, pl = id / OCH, ch = id - pl * OCH;
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        for (int e = 0; e < 8; ++e) f[e] = (float)cv[k][e];
         if (g.temb != nullptr) {
-            const half8_t t = fz_ld_h8(g.temb + (px / g.temb_group) * g.temb_stride + co);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += (float)t[e];
+            for (int e = 0; e < 8; ++e) f[e] += (float)tv[k][e];
         }
-        if (g.res != nullptr) {
-            const half8_t r = fz_ld_h8(g.res + px * g.Cout + co);
+        if (res_t != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+            for (int e = 0; e < 8; ++e) f[e] += (float)rv[k][e];
         }
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
-        fz_st_h8(g.y + px * g.Cout + co, o);
+        fz_st_h8(y_t + (uint32_t)(pl * g.Cout + ch * 8), o);
     }
+#ifdef CH_TIMING
+    if (tid == 0) {
+        const long long w_x = wall_clock64(), c_x = clock64();
+        atomicMin((unsigned long long*)&ch_timing2[8], (unsigned long long)w_entry);
+        atomicMax((unsigned long long*)&ch_timing2[9], (unsigned long long)w_x);
+        if (blockIdx.x == 0) {
+            ch_timing3[8] = w_e0 - w_entry; ch_timing3[9] = w_e1 - w_entry; ch_timing3[10] = w_e2 - w_entry; ch_timing3[11] = w_x - w_entry;
+            ch_timing2[0] = w_entry; ch_timing2[1] = tstart; ch_timing2[2] = w_ls; ch_timing2[3] = c_ls;
+            ch_timing2[4] = w_le; ch_timing2[5] = c_le; ch_timing2[6] = w_x; ch_timing2[7] = c_x;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 //                                                   host side
 // ---------------------------------------------------------------------------------------------------------------
 #ifdef CH_TIMING
+extern "C" int fz_conv_halo_timing3(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ch_timing3), sizeof(long long) * 16) == hipSuccess ? FZ_OK : FZ_ERR_LAUNCH;
+}
+extern "C" int fz_conv_halo_timing2(long long* out, int reset) {
+    if (reset) {
+        long long z[12] = {0}; z[8] = 0x7fffffffffffffffll;
+        return hipMemcpyToSymbol(HIP_SYMBOL(ch_timing2), z, sizeof(z)) == hipSuccess ? FZ_OK : FZ_ERR_LAUNCH;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ch_timing2), sizeof(long long) * 12) == hipSuccess ? FZ_OK : FZ_ERR_LAUNCH;
+}
 extern "C" int fz_conv_halo_timing(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ch_timing), sizeof(long long) * 12) == hipSuccess ? FZ_OK : FZ_ERR_LAUNCH;
 }
@@ -342,7 +457,7 @@ int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride)
     if (n <= 0 || w < 32 || w > 128 || CH_BB % w || (h * w) % CH_BB || cin % 64 || cin < 64 || cout % CH_BA) return 0;
     if (temb_stride % 8) return 0;
     const int np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
-    return np <= 50 && (int64_t)n * h * w < (1ll << 31);
+    return np <= 50 && (int64_t)n * h * w < (1ll << 31) && (int64_t)h * w * cin * 2 < (1ll << 31);
 }
 
 int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
@@ -355,12 +470,17 @@ int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const v
     g.res = (const half_t*)res;
     g.y = (half_t*)y;
     g.temb_stride = temb_stride;
-    g.temb_group = temb_group;
+    if (temb != nullptr && (temb_group <= 0 || temb_group % ((int64_t)h * w))) return FZ_ERR_UNSUPPORTED;   // whole frames per row
+    g.temb_frames = temb != nullptr ? (int)(temb_group / ((int64_t)h * w)) : 1;
     g.N = n; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout;
     g.tiles_a = cout / CH_BA;
     g.np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
     g.hb_bytes = g.np * 1024;
-    const size_t ring = (size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes, stage = (size_t)CH_BB * CH_OSTR * 2;
+    g.w2_magic = 65536 / (w + 2) + 1;
+    for (int hp = 0; hp < 8 * g.np; ++hp)
+        if (((hp * g.w2_magic) >> 16) != hp / (w + 2)) return FZ_ERR_UNSUPPORTED;   // (never for the widths fz_conv_halo_ok admits)
+    const size_t ring = (size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes + 1024, stage = (size_t)CH_BB * CH_OSTR * 2;
+    if ((size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes < stage) return FZ_ERR_UNSUPPORTED;   // the bias / temb piece must lie beyond the staging area
     const size_t lds = ring > stage ? ring : stage;
     if (lds > 160 * 1024) return FZ_ERR_UNSUPPORTED;
     const int64_t nwg = (int64_t)g.tiles_a * ((int64_t)n * h * w / CH_BB);

@@ -59,7 +59,7 @@ __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute 
 #define FZ_KGPP 64    /* with FZ_KG2: the two K groups in PING-PONG -- K tiles of 32, group g contracts sub-step g of every tile while the other group reads */
 #ifdef FZ_IGEMM_TIMING  // scripts/igemm_timeline.hip: s_memtime totals per loop segment of waves 0 and 4 of workgroup 0 (never in the product)
 __device__ long long fz_igemm_timing[2][8];
-__device__ long long fz_igemm_timing2[2][2];
+__device__ long long fz_igemm_timing2[2][6];   // [0..1] set-up / whole kernel (s_memtime ticks); [2..5] wall clock (10 ns) at entry / K loop start / K loop end / exit
 #define FZ_TK_DECL() long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define FZ_TK(i)                              \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -196,6 +196,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     const int dwave = C::LC ? wq_ : wave;   // index among the waves that issue LDS-DMA
     const int wa = wq_ / WB, wb = wq_ % WB;
 #ifdef FZ_IGEMM_TIMING
+    const long long tw_entry = wall_clock64();
     const long long tk_entry = clock64();
 #endif
     // ---- tile of this workgroup: XCD-aware (blocks b, b+8, b+16.. share an XCD and get consecutive tiles, which share
@@ -489,6 +490,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     const int ntile = kt1 - kt0;
     FZ_TK_DECL();
 #ifdef FZ_IGEMM_TIMING
+    const long long tw_loop = wall_clock64();
     const long long tk_loop = clock64();
 #endif
     if constexpr (PPL) {
@@ -904,6 +906,7 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
 
 #ifdef FZ_IGEMM_TIMING
     tacc_[7] = clock64() - tk_loop;   // the K loop as a whole (prologue fetch included)
+    const long long tw_loop_end = wall_clock64();
     tacc_[3] += 0;
     const long long tk_setup = tk_loop - tk_entry;  // pointer set-up before the loop
 #endif
@@ -1335,6 +1338,10 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (tid & 255) == 0) {
         fz_igemm_timing2[tid >> 8][0] = tk_setup;
         fz_igemm_timing2[tid >> 8][1] = clock64() - tk_entry;   // whole kernel, entry to the last store issued
+        fz_igemm_timing2[tid >> 8][2] = tw_entry;
+        fz_igemm_timing2[tid >> 8][3] = tw_loop;
+        fz_igemm_timing2[tid >> 8][4] = tw_loop_end;
+        fz_igemm_timing2[tid >> 8][5] = wall_clock64();
     }
 #endif
 }

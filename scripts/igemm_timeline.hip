@@ -166,11 +166,12 @@ int main(int argc, char** argv) {
             hipDeviceSynchronize();
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
-            long long t[2][8], t2[2][2];
+            long long t[2][8], t2[2][6];
             hipMemcpyFromSymbol(t, HIP_SYMBOL(fz_igemm_timing), sizeof(t));
             hipMemcpyFromSymbol(t2, HIP_SYMBOL(fz_igemm_timing2), sizeof(t2));
-            printf("%s cfg %8d: wave 0 of workgroup 0: set-up %lld ticks, K loop %lld ticks, whole kernel %lld ticks; launch %.1f us\n", p.name, cfg,
-                   t2[0][0], t[0][7], t2[0][1], ms * 1e3);
+            printf("%s cfg %8d: wave 0 of workgroup 0: set-up %lld ticks, K loop %lld ticks, whole kernel %lld ticks; launch %.1f us | wall clock: entry -> K loop %.2f us, K loop %.2f us, "
+                   "epilogue %.2f us\n", p.name, cfg, t2[0][0], t[0][7], t2[0][1], ms * 1e3, (t2[0][3] - t2[0][2]) / 100.0, (t2[0][4] - t2[0][3]) / 100.0, (t2[0][5] - t2[0][4]) / 100.0);
+            if (getenv("FZ_TIMELINE_BRIEF")) continue;
             for (int w = 0; w < 2; ++w) {
                 const double n = t[w][6] > 0 ? (double)t[w][6] : 1.0;
                 double sum = 0;

@@ -322,6 +322,7 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     KC.case_conv3x3(DEV, n=2, h=8, w=32, cin=64, cout=160, tile_cfg=154299)
     KC.case_conv3x3(DEV, n=2, h=16, w=32, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=154299)
     KC.case_conv3x3(DEV, n=1, h=8, w=64, cin=192, cout=160, with_res=True, tile_cfg=154299, seed=3)
+    KC.case_conv3x3(DEV, n=4, h=8, w=32, cin=64, cout=320, with_temb=True, fpb=2, tile_cfg=154299, seed=4)   # two time-embedding rows, no residual
     with pytest.raises(Exception):   # shapes it does not carry are refused, not mangled
         KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=160, tile_cfg=154299)
 
