@@ -59,6 +59,8 @@ struct ChArgs {
     int tiles_a;           // Cout / 160
     int hb_bytes;          // bytes of one halo buffer (pieces of 1 KB)
     int np;                // LDS-DMA pieces of a halo tile
+    float* part;           // split-K: fp32 partial slabs [ksplit][N H W][Cout] (igemm.hip's layout; igemm_reduce_kernel sums them and applies the tail), or null
+    int ksplit;            // gridDim.y: slice ks contracts the 64-channel chunks [ks nchunk / ksplit, (ks + 1) nchunk / ksplit) under all nine taps
     int w2_magic;          // ceil(65536 / (W + 2)): halo pixel / (W + 2) == (halo pixel * w2_magic) >> 16 for every halo pixel of a tile (host-checked)
 };
 
@@ -79,7 +81,9 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     unsigned char* const Aring = raw;
     unsigned char* const Hbuf = raw + CH_NAS * CH_ASLOT;
     unsigned char* const Cpre = Hbuf + 2 * g.hb_bytes;      // 1 KB: bias | time-embedding row of the tile (beyond the epilogue's staging area)
-    const int nchunk = g.Cin >> 6, nstep = nchunk * 18;     // a step = (chunk, tap, K half)
+    const int nchunk_all = g.Cin >> 6, ks = blockIdx.y;
+    const int c0 = ks * nchunk_all / g.ksplit, nchunk = (ks + 1) * nchunk_all / g.ksplit - c0;   // this slice's chunks: c0 .. c0 + nchunk
+    const int nstep = nchunk * 18;                          // a step = (chunk, tap, K half)
     const char* zero = reinterpret_cast<const char*>(ch_zero_page);
 
 #ifdef CH_TIMING
@@ -113,7 +117,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
 #pragma unroll 1   /* (rolled: straight-line code that runs once pays for its instruction fetches) */
         for (int p = wave; p < g.np; p += 8) {
             const char* s0 = piece_src(p);
-            fz_glds16(s0 != nullptr ? s0 : zero + lane * 16, Hbuf + p * 1024);
+            fz_glds16(s0 != nullptr ? s0 + c0 * 128 : zero + lane * 16, Hbuf + (c0 & 1) * g.hb_bytes + p * 1024);
         }
         // one more piece behind the halo buffers: bias (lanes 0-19) and the tile's time-embedding row (lanes 20-39) for the epilogue
         if (wave == 3) {
@@ -149,8 +153,8 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
 #ifndef CH_NO_DMA   /* (trial flag: the steady state without a single LDS-DMA -- results are garbage) */
                 if (more && s < 13) {
                     const int p = bl + 4 * s;               // this loader's pieces bl, bl + 2, ..: two per step
-                    if (p < g.np) fire(p, c + 1);
-                    if (p + 2 < g.np) fire(p + 2, c + 1);
+                    if (p < g.np) fire(p, c0 + c + 1);
+                    if (p + 2 < g.np) fire(p + 2, c0 + c + 1);
                 }
 #endif
                 if (s == 16) {
@@ -180,7 +184,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         const char* const a_tile = reinterpret_cast<const char*>(g.wt + (int64_t)a0 * 9 * g.Cin);
         auto issue = [&](int j) {                           // step j = 18 c + 2 t + h
             const int c = j / 18, r = j - 18 * c, t = r >> 1, h = r & 1;
-            const char* base = a_tile + ((int64_t)t * g.Cin + 64 * c + 32 * h) * 2;
+            const char* base = a_tile + ((int64_t)t * g.Cin + 64 * (c0 + c) + 32 * h) * 2;
 #pragma unroll
             for (int i = 0; i < 5; ++i) fz_glds16_so(base, aoff[i], Aring + (j & 3) * CH_ASLOT + (al + 2 * i) * 1024);
         };
@@ -243,7 +247,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         const fz_lds_addr a_kk[2] = {fz_lds_addr_of(Aring) + arow + ((hi ^ asw) << 4), fz_lds_addr_of(Aring) + arow + (((2 + hi) ^ asw) << 4)};
         const int hi4 = hi << 4;
         // (branch-free: a branch in here is a basic-block boundary between two clusters -- nothing of it can sink into the MFMAs' shadow)
-        int rs = 0, rt = 0, rc = 0;                          // read cursor: k sub-step counter (4 per tap), tap, chunk
+        int rs = 0, rt = 0, rc = c0;                         // read cursor: k sub-step counter (4 per tap), tap, chunk (its parity = the halo buffer)
         auto next_addr = [&]() -> Fa {                      // the cursor's addresses; then one sub-step on
             const int rkk = rs & 1, rh = (rs >> 1) & 1, rj = rs >> 1;
             const int ky = rt / 3, kx = rt - 3 * ky, sh = (ky - 1) * W2 + (kx - 1);
@@ -341,6 +345,25 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     // with the first halo chunk (a tile lies inside one frame: one row for all of it), the residual rows are requested before the staging
     // (loader waves) / behind it (consumers: their accumulators are dead then) -- the first version's epilogue was 5.2 us, 2.8 of them the
     // staging waiting for its bias loads.
+    if (g.part != nullptr) {   // split-K: this slice's fp32 tile as it is (igemm.hip's slab layout and store form); the tail kernel does the rest
+        if (wave < 4) {
+            float* const P = g.part + ((int64_t)ks * g.N * hw + px0) * g.Cout + a0;
+#pragma unroll
+            for (int i = 0; i < CH_TA; ++i)
+#pragma unroll
+                for (int q = 0; q < CH_TB; ++q) {
+                    float* const prow = P + (uint32_t)((64 * wave + 32 * q + l31) * g.Cout + i * 32 + 4 * hi);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][q][4 * gq + e];
+                        *reinterpret_cast<f32x4*>(prow + 8 * gq) = v;
+                    }
+                }
+        }
+        return;
+    }
     constexpr int OCH = CH_BA / 8, NOUT = CH_BB * OCH / 512;
     static_assert(CH_BB * OCH % 512 == 0, "the output loop's trip count");
     const half_t* const res_t = g.res != nullptr ? g.res + px0 * g.Cout + a0 : nullptr;
@@ -454,14 +477,15 @@ extern "C" int fz_conv_halo_timing(long long* out) {
 
 // shapes the kernel carries: whole image rows per 256-pixel tile, whole tiles per frame, 160-channel tiles, 64-channel chunks
 int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride) {
-    if (n <= 0 || w < 32 || w > 128 || CH_BB % w || (h * w) % CH_BB || cin % 64 || cin < 64 || cout % CH_BA) return 0;
+    if (n <= 0 || w < 16 || w > 128 || CH_BB % w || (h * w) % CH_BB || cin % 64 || cin < 64 || cout % CH_BA) return 0;
     if (temb_stride % 8) return 0;
     const int np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
     return np <= 50 && (int64_t)n * h * w < (1ll << 31) && (int64_t)h * w * cin * 2 < (1ll << 31);
 }
 
+// part / ksplit: null / 1 = the whole convolution with its tail; else the fp32 slabs of ksplit K slices (the caller runs igemm_reduce_kernel)
 int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
-                        void* y, int n, int h, int w, int cin, int cout, void* stream) {
+                        void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
     ChArgs g = {};
     g.x = (const half_t*)x;
     g.wt = (const half_t*)wt;
@@ -473,6 +497,9 @@ int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const v
     if (temb != nullptr && (temb_group <= 0 || temb_group % ((int64_t)h * w))) return FZ_ERR_UNSUPPORTED;   // whole frames per row
     g.temb_frames = temb != nullptr ? (int)(temb_group / ((int64_t)h * w)) : 1;
     g.N = n; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout;
+    g.ksplit = ksplit > 1 ? ksplit : 1;
+    g.part = g.ksplit > 1 ? part : nullptr;
+    if (g.ksplit > 1 && (part == nullptr || g.ksplit > cin / 64)) return FZ_ERR_BAD_ARG;
     g.tiles_a = cout / CH_BA;
     g.np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
     g.hb_bytes = g.np * 1024;
@@ -494,6 +521,6 @@ int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const v
         if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
 #endif
-    FZ_LAUNCH(conv_halo_kernel, dim3((unsigned)nwg), dim3(512), lds, stream, g);
+    FZ_LAUNCH(conv_halo_kernel, dim3((unsigned)nwg, (unsigned)g.ksplit), dim3(512), lds, stream, g);
     return fz_last_launch_status();
 }

@@ -34,7 +34,7 @@
 // v1 form) instead of inside the MFMA cluster before it
 #ifdef FZ_IGEMM_TRIALS
 __attribute__((weak)) int fz_igemm_trial_no_pp = 0;
-extern "C" { __attribute__((weak)) int fz_igemm_trial_no_kg2 = 0; __attribute__((weak)) int fz_igemm_trial_no_halo = 0; }  // same-process A/B of the K-group substitution (scripts/ab_lib_flag.py)
+extern "C" { __attribute__((weak)) int fz_igemm_trial_no_kg2 = 0; __attribute__((weak)) int fz_igemm_trial_no_halo = 0; __attribute__((weak)) int fz_igemm_trial_no_halo_split = 0; }  // same-process A/B of the K-group substitution (scripts/ab_lib_flag.py)
 __attribute__((weak)) int fz_igemm_trial_pp_splitk_min = 0;  // > 0: substitute under split-K as well when a K slice has at least this many K-64 steps
 #endif
 // The shipped library reads NO environment variable: the A/B switches of rounds 3-4 (tile order, K slices on XCDs, split-K launch cost)
@@ -2144,7 +2144,23 @@ static int temporal_conv3_impl(const void* x, const void* wt, const void* res, c
 // csrc/conv_halo.hip: the stride-1 convolution with the pixel rows + halo resident in LDS across the nine taps (tile id FZ_TILE_CONV_HALO)
 int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride);
 int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
-                        void* y, int n, int h, int w, int cin, int cout, void* stream);
+                        void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream);
+// the halo kernel, whole (ksplit <= 1) or as ksplit K slices into fp32 slabs + the split-K tail kernel (bias / temb / residual applied there)
+static int conv_halo_run(IgArgs& g, const void* x, const void* wt, const void* bias, const void* temb, const void* res, void* y, int n, int hi, int wi,
+                         int cin, int cout, int ksplit, float* workspace, int64_t workspace_floats, void* stream) {
+    if (ksplit <= 1)
+        return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, nullptr, 1, stream);
+    if (workspace == nullptr || (g.Ma % 4) || (g.ldy % 4) || ksplit > cin / 64) return FZ_ERR_UNSUPPORTED;
+    if ((int64_t)ksplit * g.Nb * g.Ma > workspace_floats) return FZ_ERR_BAD_ARG;
+    const int rc = fz_conv_halo_launch(x, wt, nullptr, nullptr, g.temb_stride, g.temb_group, nullptr, y, n, hi, wi, cin, cout, workspace, ksplit, stream);
+    if (rc != FZ_OK) return rc;
+    g.ksplit = ksplit;
+    g.part = workspace;
+    const int64_t total = g.Nb * (g.Ma / 4);
+    dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+    FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, 1);
+    return fz_last_launch_status();
+}
 #define FZ_TILE_CONV_HALO 154299
 
 extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
@@ -2161,19 +2177,27 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
     g.Wo = (wu + 2 - 3) / stride + 1;
     if (conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout) != FZ_OK) return FZ_ERR_UNSUPPORTED;
     if (tile_cfg == FZ_TILE_CONV_HALO) {
-        if (stride != 1 || upsample || split_k > 1 || !fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
-        return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, stream);
+        if (stride != 1 || upsample || !fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
+        return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, split_k, (float*)workspace, workspace_floats, stream);
     }
-    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip once or twice (200-512 workgroups: the 8- and 16-frame
+    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip once or twice (160-512 workgroups: the 8- and 16-frame
     // launches of the 64^2 level, the 16-frame ones of 32^2): +26 % / +21 ... +28 % at one wave of tiles, +1 ... +6 % at two on MI355X
-    // (profiles/r06_conv_halo_ab.txt); with 128 tiles (8 frames x 32^2) the split-K launch of the implicit GEMM is ahead.
+    // (profiles/r06_conv_halo_ab.txt) -- and, in K slices with the split-K tail kernel, where they do not: ~128 tiles (8 frames x 32^2, 16 x 16^2)
+    // in two slices, ~64 (8 frames x 16^2) in four: -8 ... -15 % of the launch against the split-K implicit GEMM (profiles/r06_halo_split_ab.txt);
+    // a slice wants >= 2.5 chunks of 64 channels (Cin = 320 stays whole).
     if (tile_cfg == 0 && split_k <= 1 && stride == 1 && !upsample && fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) {
         const int64_t tiles = (int64_t)(cout / 160) * (g.Nb / 256);
-        bool take = tiles >= 200 && tiles <= 512;
+        const int nchunk = cin / 64;
+        int ks = tiles >= 160 ? 1 : (tiles >= 96 ? 2 : (tiles >= 48 ? 4 : 0));
+        if (ks == 4 && nchunk < 10) ks = 2;
+        if (ks == 2 && nchunk < 6) ks = tiles >= 96 ? 1 : 0;
+        if (ks > 1 && (workspace == nullptr || (int64_t)ks * g.Nb * g.Ma > workspace_floats || (g.Ma % 4) || (g.ldy % 4))) ks = tiles >= 96 ? 1 : 0;
+        bool take = ks >= 1 && tiles <= 512;
 #ifdef FZ_IGEMM_TRIALS
         if (fz_igemm_trial_no_halo) take = false;
+        if (fz_igemm_trial_no_halo_split && (ks > 1 || tiles < 200)) take = false;
 #endif
-        if (take) return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, stream);
+        if (take) return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, ks, (float*)workspace, workspace_floats, stream);
     }
     if (cin % 8) {  // conv_in (4 input channels): direct VALU convolution
         if (cout % 8 || upsample || cin != 4 || (int64_t)9 * cin * cout * 2 > 64 * 1024 || (temb && g.temb_stride % 8))

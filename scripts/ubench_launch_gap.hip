@@ -9,22 +9,19 @@
 #include <vector>
 #include <algorithm>
 
-constexpr int NL = 64;
-__device__ unsigned long long span[NL][3];   // min entry, max exit, max entry
+constexpr int NL = 64, MAXG = 1024;
+__device__ unsigned long long stamp[NL][MAXG][2];   // entry / exit of every workgroup (own slots: same-address atomics would serialise at ~30 ns each)
 
 extern __shared__ unsigned char dyn[];
 __global__ void __launch_bounds__(512) k_span(int id, int busy_ticks, float* sink) {
     const unsigned long long t0 = wall_clock64();
-    if (threadIdx.x == 0) {
-        atomicMin(&span[id][0], t0);
-        atomicMax(&span[id][2], t0);
-    }
+    if (threadIdx.x == 0) stamp[id][blockIdx.x][0] = t0;
     if (busy_ticks > 0) {
         while (wall_clock64() - t0 < (unsigned long long)busy_ticks) __builtin_amdgcn_s_sleep(4);
     }
     if (sink != nullptr && threadIdx.x == 9999) sink[0] = dyn[0];
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&span[id][1], wall_clock64());
+    if (threadIdx.x == 0) stamp[id][blockIdx.x][1] = wall_clock64();
 }
 
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
@@ -42,11 +39,7 @@ int main() {
             for (int threads : {256, 512})
                 for (int lds : {0, 140 * 1024})
                     for (int busy_us : {0, 20}) {
-                        unsigned long long init[NL][3];
-                        auto reset = [&]() {
-                            for (int i = 0; i < NL; ++i) { init[i][0] = ~0ull; init[i][1] = 0; init[i][2] = 0; }
-                            hipMemcpyToSymbol(HIP_SYMBOL(span), init, sizeof(init));
-                        };
+                        auto reset = [&]() {};
                         hipGraphExec_t ge = nullptr;
                         if (graph) {
                             hipGraph_t gr;
@@ -66,8 +59,17 @@ int main() {
                             hipEventSynchronize(e1);
                             hipEventElapsedTime(&ms, e0, e1);
                         }
-                        unsigned long long h[NL][3];
-                        hipMemcpyFromSymbol(h, HIP_SYMBOL(span), sizeof(h));
+                        static unsigned long long hs[NL][MAXG][2];
+                        static unsigned long long h[NL][3];
+                        hipMemcpyFromSymbol(hs, HIP_SYMBOL(stamp), sizeof(hs));
+                        for (int i = 0; i < NL; ++i) {
+                            h[i][0] = ~0ull; h[i][1] = 0; h[i][2] = 0;
+                            for (int w = 0; w < grid; ++w) {
+                                h[i][0] = std::min(h[i][0], hs[i][w][0]);
+                                h[i][2] = std::max(h[i][2], hs[i][w][0]);
+                                h[i][1] = std::max(h[i][1], hs[i][w][1]);
+                            }
+                        }
                         std::vector<double> sp, gap, ramp;
                         for (int i = 8; i < NL; ++i) {
                             sp.push_back((h[i][1] - h[i][0]) / 100.0);

@@ -323,8 +323,18 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     KC.case_conv3x3(DEV, n=2, h=16, w=32, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=154299)
     KC.case_conv3x3(DEV, n=1, h=8, w=64, cin=192, cout=160, with_res=True, tile_cfg=154299, seed=3)
     KC.case_conv3x3(DEV, n=4, h=8, w=32, cin=64, cout=320, with_temb=True, fpb=2, tile_cfg=154299, seed=4)   # two time-embedding rows, no residual
+    KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=160, with_temb=True, with_res=True, tile_cfg=154299, seed=5)   # W = 16: a tile is a frame
     with pytest.raises(Exception):   # shapes it does not carry are refused, not mangled
         KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=160, tile_cfg=154299)
+
+
+def test_conv3x3_pixel_halo_in_k_slices():
+    """The halo kernel under split-K: slice ks contracts its 64-channel chunks under all nine taps into an fp32 slab, the split-K tail kernel of
+    igemm.hip sums the slabs and applies bias / time embedding / residual.  Even and ragged chunk counts per slice, odd first chunks (the halo
+    double buffer starts on its second half), W = 16."""
+    KC.case_conv3x3(DEV, n=1, h=16, w=16, cin=256, cout=160, with_temb=True, with_res=True, tile_cfg=154299, split_k=2)
+    KC.case_conv3x3(DEV, n=2, h=8, w=32, cin=320, cout=320, with_res=True, fpb=2, tile_cfg=154299, split_k=3, seed=1)
+    KC.case_conv3x3(DEV, n=1, h=16, w=16, cin=256, cout=160, tile_cfg=154299, split_k=4, seed=2)
 
 
 def test_k_group_pingpong_conv_modes():

@@ -231,6 +231,11 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     print(KC.case_conv3x3(DEV, n=16, h=64, w=64, cin=640, cout=320, with_res=True, fpb=8, tile_cfg=154299, seed=1))
     print(KC.case_conv3x3(DEV, n=16, h=32, w=32, cin=640, cout=640, with_temb=True, fpb=8, tile_cfg=154299, seed=2))
     print(KC.case_conv3x3(DEV, n=3, h=8, w=32, cin=64, cout=160, tile_cfg=154299, seed=3))
+    # split-K (fp32 slabs + the tail kernel) where the halo tiles alone do not fill the chip: 8 frames x 32^2, the 16^2 level (W = 16: a tile is a frame)
+    print(KC.case_conv3x3(DEV, n=8, h=32, w=32, cin=640, cout=640, with_temb=True, with_res=True, fpb=8, tile_cfg=154299, split_k=2, seed=4))
+    print(KC.case_conv3x3(DEV, n=16, h=16, w=16, cin=1280, cout=1280, with_temb=True, fpb=8, tile_cfg=154299, split_k=2, seed=5))
+    print(KC.case_conv3x3(DEV, n=8, h=16, w=16, cin=2560, cout=1280, with_res=True, fpb=8, tile_cfg=154299, split_k=4, seed=6))
+    print(KC.case_conv3x3(DEV, n=8, h=16, w=16, cin=640, cout=1280, fpb=8, tile_cfg=154299, seed=7))
 
 
 @pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222, 252218])
