@@ -119,6 +119,10 @@ _SIGS = {
     "fz_groupnorm_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "fz_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
                                      C.c_int, C.c_int, _P, _P]),
+    "fz_conv3x3_up2_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fz_conv3x3_up2_pack_halves": (C.c_int64, [C.c_int, C.c_int]),
+    "fz_conv3x3_up2_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "fz_conv3x3_up2": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "fz_conv3x3": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "fz_temporal_conv3": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64,

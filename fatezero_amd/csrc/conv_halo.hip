@@ -61,10 +61,18 @@ struct ChArgs {
     int np;                // LDS-DMA pieces of a halo tile
     float* part;           // split-K: fp32 partial slabs [ksplit][N H W][Cout] (igemm.hip's layout; igemm_reduce_kernel sums them and applies the tail), or null
     int ksplit;            // gridDim.y: slice ks contracts the 64-channel chunks [ks nchunk / ksplit, (ks + 1) nchunk / ksplit) under all nine taps
+    int w_magic;           // the same for / W on the tile's 256 pixels (upsampling form: output rows)
     int w2_magic;          // ceil(65536 / (W + 2)): halo pixel / (W + 2) == (halo pixel * w2_magic) >> 16 for every halo pixel of a tile (host-checked)
 };
 
+// TAPS = 9: the 3x3 convolution.  TAPS = 4: nearest-2x upsampling + 3x3 convolution (UpsamplePseudo3D, resnet.py:145) as FOUR 2x2 convolutions
+// of the low-resolution input, one per output parity (py, px) = blockIdx.z: U[y][x] = X[y >> 1][x >> 1] makes the three taps of a row hit only
+// two input rows -- r - 1 and r for even output rows (weights w[0] and w[1] + w[2]), r and r + 1 for odd ones (w[0] + w[1], w[2]), columns
+// alike: 4 instead of 9 MACs per output and input channel, on weights summed once at pack time (wt = [4 parities][Cout][4 taps][Cin]).
+template <int TAPS>
 FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
+    constexpr int SPC = 2 * TAPS;                           // K-32 steps per 64-channel chunk
+    const int py = TAPS == 4 ? (int)(blockIdx.z >> 1) : 0, pxp = TAPS == 4 ? (int)(blockIdx.z & 1) : 0;
     FZ_DYN_SMEM(raw);
     const int tid = threadIdx.x, wave = fz_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     // XCD-aware order (igemm.hip): blocks b, b + 8, .. share an XCD and get consecutive tiles; a-tile fastest: the two (or more) channel tiles of
@@ -83,7 +91,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     unsigned char* const Cpre = Hbuf + 2 * g.hb_bytes;      // 1 KB: bias | time-embedding row of the tile (beyond the epilogue's staging area)
     const int nchunk_all = g.Cin >> 6, ks = blockIdx.y;
     const int c0 = ks * nchunk_all / g.ksplit, nchunk = (ks + 1) * nchunk_all / g.ksplit - c0;   // this slice's chunks: c0 .. c0 + nchunk
-    const int nstep = nchunk * 18;                          // a step = (chunk, tap, K half)
+    const int nstep = nchunk * SPC;                         // a step = (chunk, tap, K half)
     const char* zero = reinterpret_cast<const char*>(ch_zero_page);
 
 #ifdef CH_TIMING
@@ -146,25 +154,29 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         if (blockIdx.x == 0 && tid == 384) { ch_timing3[0] = w_p0 - w_entry; ch_timing3[1] = w_p1 - w_entry; ch_timing3[2] = wall_clock64() - w_entry; }
 #endif
         fz_barrier_raw();                                   // B(0)
+        constexpr int PPS = TAPS == 9 ? 2 : 5;              // pieces per step and loader: (SPC - 3) PPS >= 25
+        static_assert((SPC - 3) * PPS >= 25, "the next chunk's halo tile must fit its fire steps");
         for (int c = 0; c < nchunk; ++c) {
             const bool more = c + 1 < nchunk;
 #pragma unroll 1
-            for (int s = 0; s < 18; ++s) {
+            for (int s = 0; s < SPC; ++s) {
 #ifndef CH_NO_DMA   /* (trial flag: the steady state without a single LDS-DMA -- results are garbage) */
-                if (more && s < 13) {
-                    const int p = bl + 4 * s;               // this loader's pieces bl, bl + 2, ..: two per step
-                    if (p < g.np) fire(p, c0 + c + 1);
-                    if (p + 2 < g.np) fire(p + 2, c0 + c + 1);
+                if (more && s < SPC - 3) {
+#pragma unroll
+                    for (int u = 0; u < PPS; ++u) {         // this loader's pieces bl, bl + 2, ..: PPS per step
+                        const int p = bl + 2 * (PPS * s + u);
+                        if (p < g.np) fire(p, c0 + c + 1);
+                    }
                 }
 #endif
-                if (s == 16) {
+                if (s == SPC - 2) {
                     CH_T0();
-                    fz_wait_vm0();                          // the next chunk's tile is complete in front of B(18 c + 17)
+                    fz_wait_vm0();                          // the next chunk's tile is complete in front of the chunk's last barrier
                     CH_T1(0);
                 }
                 {
                     CH_T0();
-                    fz_barrier_raw();                       // B(18 c + s + 1)
+                    fz_barrier_raw();                       // B(SPC c + s + 1)
                     CH_T1(1);
                 }
             }
@@ -179,11 +191,11 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         for (int i = 0; i < 5; ++i) {
             const int row = 16 * (al + 2 * i) + (lane >> 2);
             const int lc = (lane & 3) ^ ((row >> 2) & 3);
-            aoff[i] = (uint32_t)(((int64_t)row * 9 * g.Cin + lc * 8) * 2);
+            aoff[i] = (uint32_t)(((int64_t)row * TAPS * g.Cin + lc * 8) * 2);
         }
-        const char* const a_tile = reinterpret_cast<const char*>(g.wt + (int64_t)a0 * 9 * g.Cin);
-        auto issue = [&](int j) {                           // step j = 18 c + 2 t + h
-            const int c = j / 18, r = j - 18 * c, t = r >> 1, h = r & 1;
+        const char* const a_tile = reinterpret_cast<const char*>(g.wt + ((int64_t)(TAPS == 4 ? blockIdx.z : 0) * g.Cout + a0) * TAPS * g.Cin);
+        auto issue = [&](int j) {                           // step j = SPC c + 2 t + h
+            const int c = j / SPC, r = j - SPC * c, t = r >> 1, h = r & 1;
             const char* base = a_tile + ((int64_t)t * g.Cin + 64 * (c0 + c) + 32 * h) * 2;
 #pragma unroll
             for (int i = 0; i < 5; ++i) fz_glds16_so(base, aoff[i], Aring + (j & 3) * CH_ASLOT + (al + 2 * i) * 1024);
@@ -250,7 +262,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         int rs = 0, rt = 0, rc = c0;                         // read cursor: k sub-step counter (4 per tap), tap, chunk (its parity = the halo buffer)
         auto next_addr = [&]() -> Fa {                      // the cursor's addresses; then one sub-step on
             const int rkk = rs & 1, rh = (rs >> 1) & 1, rj = rs >> 1;
-            const int ky = rt / 3, kx = rt - 3 * ky, sh = (ky - 1) * W2 + (kx - 1);
+            const int ky = TAPS == 9 ? rt / 3 : (rt >> 1) + py, kx = TAPS == 9 ? rt - 3 * ky : (rt & 1) + pxp, sh = (ky - 1) * W2 + (kx - 1);
             const fz_lds_addr hs = fz_lds_addr_of(Hbuf) + (rc & 1) * g.hb_bytes;
             const int S = (4 * rh + 2 * rkk) << 4;
             Fa f;
@@ -261,7 +273,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
                 f.b[q] = hs + hp * 128 + ((hi4 ^ ((hp << 3) & 0x70)) ^ S);
             }
             const int adv = (rs & 3) == 3;                   // the next sub-step opens a new tap
-            const int rt2 = rt + adv, wrap = rt2 == 9;
+            const int rt2 = rt + adv, wrap = rt2 == TAPS;
             rt = wrap ? 0 : rt2;
             rc += wrap;
             ++rs;
@@ -367,7 +379,14 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     constexpr int OCH = CH_BA / 8, NOUT = CH_BB * OCH / 512;
     static_assert(CH_BB * OCH % 512 == 0, "the output loop's trip count");
     const half_t* const res_t = g.res != nullptr ? g.res + px0 * g.Cout + a0 : nullptr;
-    half_t* const y_t = g.y + px0 * g.Cout + a0;
+    // output row of the tile's pixel pl, in halves from y_t: the pixel itself -- or, upsampling, output pixel (2 y + py, 2 x + px) of the frame
+    half_t* const y_t = TAPS == 9 ? g.y + px0 * g.Cout + a0
+                                  : g.y + ((((int64_t)fn * 2 * g.H + 2 * y0 + py) * 2 * W + pxp)) * g.Cout + a0;
+    auto out_off = [&](int pl) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (TAPS == 9) return (uint32_t)(pl * g.Cout);
+        const int yl = (pl * g.w_magic) >> 16, xl = pl - yl * W;
+        return (uint32_t)((4 * yl * W + 2 * xl) * g.Cout);
+    };
     half8_t rv[NOUT];
     auto load_res = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -440,7 +459,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
-        fz_st_h8(y_t + (uint32_t)(pl * g.Cout + ch * 8), o);
+        fz_st_h8(y_t + out_off(pl) + ch * 8, o);
     }
 #ifdef CH_TIMING
     if (tid == 0) {
@@ -484,8 +503,8 @@ int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride)
 }
 
 // part / ksplit: null / 1 = the whole convolution with its tail; else the fp32 slabs of ksplit K slices (the caller runs igemm_reduce_kernel)
-int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
-                        void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
+static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group,
+                                 const void* res, void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
     ChArgs g = {};
     g.x = (const half_t*)x;
     g.wt = (const half_t*)wt;
@@ -511,16 +530,68 @@ int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const v
     const size_t lds = ring > stage ? ring : stage;
     if (lds > 160 * 1024) return FZ_ERR_UNSUPPORTED;
     const int64_t nwg = (int64_t)g.tiles_a * ((int64_t)n * h * w / CH_BB);
+    g.w_magic = 65536 / w + 1;
+    for (int pl = 0; pl < CH_BB; ++pl)
+        if (((pl * g.w_magic) >> 16) != pl / w) return FZ_ERR_UNSUPPORTED;
+    if (taps == 4 && (g.ksplit > 1 || temb != nullptr || res != nullptr)) return FZ_ERR_UNSUPPORTED;   // the upsampler's convolution: bias only
+    void (*kern)(ChArgs) = taps == 4 ? &conv_halo_kernel<4> : &conv_halo_kernel<9>;
 #ifndef FZ_EMU
-    static std::atomic<uint64_t> attr_set_mask{0};  // LDS above 64 KB is an opt-in function attribute, per device
+    static std::atomic<uint64_t> attr_set_mask[2] = {{0}, {0}};  // LDS above 64 KB is an opt-in function attribute, per device and instantiation
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FZ_ERR_LAUNCH;
-    if (dev >= 64 || !(attr_set_mask.load(std::memory_order_relaxed) >> dev & 1)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    std::atomic<uint64_t>& mask = attr_set_mask[taps == 4];
+    if (dev >= 64 || !(mask.load(std::memory_order_relaxed) >> dev & 1)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return FZ_ERR_LAUNCH;
-        if (dev < 64) attr_set_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
+        if (dev < 64) mask.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
 #endif
-    FZ_LAUNCH(conv_halo_kernel, dim3((unsigned)nwg, (unsigned)g.ksplit), dim3(512), lds, stream, g);
+    if (taps == 4) {
+        FZ_LAUNCH(conv_halo_kernel<4>, dim3((unsigned)nwg, 1, 4), dim3(512), lds, stream, g);
+    } else {
+        FZ_LAUNCH(conv_halo_kernel<9>, dim3((unsigned)nwg, (unsigned)g.ksplit), dim3(512), lds, stream, g);
+    }
     return fz_last_launch_status();
+}
+
+int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
+                        void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
+    return conv_halo_launch_taps(9, x, wt, bias, temb, temb_stride, temb_group, res, y, n, h, w, cin, cout, part, ksplit, stream);
+}
+
+// ---- nearest-2x upsampling + 3x3 convolution as four 2x2 convolutions of the input (conv_halo_kernel<4>) ---------------------------------------
+// wt_up[z = 2 py + px][co][t = 2 ty + tx][ci] = sum of w[co][ky][kx][ci] over ky in rows(py, ty), kx in rows(px, tx) with
+// rows(0, 0) = {0}, rows(0, 1) = {1, 2}, rows(1, 0) = {0, 1}, rows(1, 1) = {2}; summed in fp32 in (ky, kx) order, rounded once to fp16.
+FZ_KERNEL void __launch_bounds__(256) conv_up2_pack_kernel(const half_t* w9, half_t* wu, int cout, int cin) {
+    const int64_t total = (int64_t)16 * cout * cin;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(id % cin);
+        int64_t r = id / cin;
+        const int t = (int)(r & 3);
+        r >>= 2;
+        const int co = (int)(r % cout), z = (int)(r / cout);
+        const int py = z >> 1, px = z & 1, ty = t >> 1, tx = t & 1;
+        const int ky0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int kx0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        float acc = 0.0f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) acc += (float)w9[((int64_t)co * 9 + ky * 3 + kx) * cin + ci];
+        wu[id] = (half_t)acc;
+    }
+}
+
+// C ABI (include/fatezero_hip.h)
+extern "C" int fz_conv3x3_up2_ok(int n, int h, int w, int cin, int cout) { return fz_conv_halo_ok(n, h, w, cin, cout, 0); }
+extern "C" int64_t fz_conv3x3_up2_pack_halves(int cin, int cout) { return (int64_t)16 * cin * cout; }
+extern "C" int fz_conv3x3_up2_pack(const void* wt, void* wt_up, int cin, int cout, void* stream) {
+    if (!wt || !wt_up || cin <= 0 || cout <= 0) return FZ_ERR_BAD_ARG;
+    const int64_t total = (int64_t)16 * cin * cout;
+    FZ_LAUNCH(conv_up2_pack_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, stream, (const half_t*)wt,
+              (half_t*)wt_up, cout, cin);
+    return fz_last_launch_status();
+}
+extern "C" int fz_conv3x3_up2(const void* x, const void* wt_up, const void* bias, void* y, int n, int h, int w, int cin, int cout, void* stream) {
+    if (!x || !wt_up || !y) return FZ_ERR_BAD_ARG;
+    if (!fz_conv_halo_ok(n, h, w, cin, cout, 0)) return FZ_ERR_UNSUPPORTED;
+    return conv_halo_launch_taps(4, x, wt_up, bias, nullptr, 0, 0, nullptr, y, n, h, w, cin, cout, nullptr, 1, stream);
 }

@@ -877,6 +877,38 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], *, 
     return out, (ho, wo)
 
 
+def conv3x3_up2_ok(n: int, h: int, w: int, cin: int, cout: int) -> bool:
+    """Does the sub-pixel form of nearest-2x + 3x3 convolution (fz_conv3x3_up2: four 2x2 convolutions of the input) carry this shape?"""
+    return bool(N.lib().fz_conv3x3_up2_ok(n, h, w, cin, cout))
+
+
+def pack_conv3x3_up2_weight(wt: torch.Tensor) -> torch.Tensor:
+    """wt: fz_conv3x3's packed weights [Cout, 9, Cin] -> [4 parities, Cout, 4 taps, Cin], the taps summed per output parity (fz_conv3x3_up2_pack)."""
+    cout, nine, cin = wt.shape
+    assert nine == 9 and wt.is_contiguous() and wt.dtype == torch.float16
+    out = torch.empty(4, cout, 4, cin, dtype=torch.float16, device=wt.device)
+    assert out.numel() == N.lib().fz_conv3x3_up2_pack_halves(cin, cout)
+    rc = N.lib().fz_conv3x3_up2_pack(wt.data_ptr(), out.data_ptr(), cin, cout, _stream(wt))
+    if rc:
+        N.check(rc, "fz_conv3x3_up2_pack")
+    return out
+
+
+def conv3x3_up2(x: torch.Tensor, wt_up: torch.Tensor, bias: Optional[torch.Tensor], *, hw: Tuple[int, int], out: Optional[torch.Tensor] = None):
+    """x: [N, H*W, Cin] -> nearest-2x upsampling + 3x3 convolution -> [N, 4 H*W, Cout] on the summed weights of pack_conv3x3_up2_weight."""
+    n, _, cin = x.shape
+    h, w = hw
+    cout = wt_up.shape[1]
+    if not (x.is_contiguous() and wt_up.is_contiguous() and tuple(wt_up.shape) == (4, cout, 4, cin) and x.dtype == torch.float16):
+        raise ValueError("fz_conv3x3_up2: x [N, H*W, Cin] and wt_up [4, Cout, 4, Cin] must be contiguous fp16")
+    if out is None:
+        out = torch.empty(n, 4 * h * w, cout, dtype=torch.float16, device=x.device)
+    rc = N.lib().fz_conv3x3_up2(x.data_ptr(), wt_up.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), n, h, w, cin, cout, _stream(x))
+    if rc:
+        N.check(rc, "fz_conv3x3_up2")
+    return out, (2 * h, 2 * w)
+
+
 def gn_epilogue_ok(tokens: int, cout: int, groups: int) -> bool:
     """Can a producer of a [N, tokens, cout] tensor emit its GroupNorm(groups) statistics from its epilogue (fz_gemm_gn /
     fz_temporal_conv3_gn)?  (whole 128-row chunks per frame, 320-wide tiles holding whole groups of an even width)"""

@@ -20,6 +20,9 @@ from .lora import LoRALinearLayer, _Conv1dParams, pack_temporal_weight, temporal
 # without split-K -- the 64^2 level: the consuming GroupNorm then runs finalize + normalise only (no statistics pass over the tensor).
 # The env switch is for same-box A/B runs of bench.py.
 GN_FROM_EPILOGUE = os.environ.get("FZ_NO_GN_EPILOGUE") is None
+# nearest-2x + 3x3 convolution as four 2x2 convolutions of the input on summed weights (fz_conv3x3_up2: 4 / 9 of the multiply-adds) where the
+# kernel carries the shape; FZ_NO_CONV_UP2=1: the nine-tap form through fz_conv3x3(upsample=1) everywhere
+CONV_UP2 = os.environ.get("FZ_NO_CONV_UP2") is None
 
 
 class Tokens:
@@ -97,6 +100,7 @@ class PseudoConv3d(nn.Module):
         else:
             self.conv_temporal = None
         self._packed = None
+        self._packed_up = None
 
     def _pack(self, dtype, device):
         if self._packed is None or self._packed[0].dtype != dtype or self._packed[0].device != device:
@@ -151,10 +155,16 @@ class PseudoConv3d(nn.Module):
             fused = fuse_tail and temb is None
         else:
             xin = x.data if x.data.is_contiguous() else x.data.contiguous()
-            y, (oh, ow) = K.conv3x3(xin, w, bias, hw=(x.h, x.w), stride=self.stride, upsample=upsample,
-                                    temb=temb if fuse_tail else None, frames_per_batch=x.f,
-                                    res=residual if fuse_tail else None)
-            fused = fuse_tail
+            if upsample and CONV_UP2 and self.stride == 1 and K.conv3x3_up2_ok(n, x.h, x.w, self.in_channels, self.out_channels):
+                if self._packed_up is None or self._packed_up[0] is not w:
+                    self._packed_up = (w, K.pack_conv3x3_up2_weight(w))   # (once per packed weight)
+                y, (oh, ow) = K.conv3x3_up2(xin, self._packed_up[1], bias, hw=(x.h, x.w))
+                fused = fuse_tail and temb is None and residual is None
+            else:
+                y, (oh, ow) = K.conv3x3(xin, w, bias, hw=(x.h, x.w), stride=self.stride, upsample=upsample,
+                                        temb=temb if fuse_tail else None, frames_per_batch=x.f,
+                                        res=residual if fuse_tail else None)
+                fused = fuse_tail
         gn = None
         if lora is not None and temporal_active:
             y4 = lora.forward_tokens(y.view(x.b, x.f, oh * ow, self.out_channels), temb=temb, residual=residual, gn_groups=gn_groups)

@@ -123,7 +123,7 @@ class UNetPseudo3DConditionModel(nn.Module):
         if getattr(self, "_issuer", None) is not None:
             self._issuer.clear()  # recorded plans point at the packed weights
         for m in self.modules():
-            for a in ("_packed", "_qk", "_qkv", "_ctx_kv", "_ln_fold", "_chain"):
+            for a in ("_packed", "_packed_up", "_qk", "_qkv", "_ctx_kv", "_ln_fold", "_chain"):
                 if hasattr(m, a):
                     setattr(m, a, None)
             if hasattr(m, "_xchain"):

@@ -297,6 +297,21 @@ int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb
                void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
                void* workspace, int64_t workspace_floats, int tile_cfg, int split_k, void* stream);
 
+/* Nearest-2x upsampling + 3x3 convolution (UpsamplePseudo3D, /root/reference/video_diffusion/models/resnet.py:145 + :57-64) as FOUR 2x2
+ * convolutions of the low-resolution input, one per output parity: U[y][x] = X[y >> 1][x >> 1] makes the three taps of a kernel row hit only
+ * two input rows, so 4 instead of 9 multiply-adds per output and input channel -- on weights summed ONCE:
+ *   wt_up[z = 2 py + px][co][t = 2 ty + tx][ci] = sum of wt[co][3 ky + kx][ci] over ky in R(py, ty), kx in R(px, tx),
+ *   R(0, 0) = {0}, R(0, 1) = {1, 2}, R(1, 0) = {0, 1}, R(1, 1) = {2}      (fp32 sums in (ky, kx) order, one rounding to fp16)
+ * and y[n][2 r + py][2 c + px][co] = bias[co] + sum_{t, ci} wt_up[z][co][t][ci] x[n][r + ty + py - 1][c + tx + px - 1][ci] (zero outside).
+ * fz_conv3x3_up2_pack builds wt_up (fz_conv3x3_up2_pack_halves(cin, cout) halves) from fz_conv3x3's packed weights [cout][9][cin].
+ * x: [n][h][w][cin]; y: [n][2 h][2 w][cout].  fz_conv3x3_up2_ok: the shapes the kernel carries (16 <= w <= 128 and 256 % w == 0, whole
+ * 256-pixel tiles per frame, cin % 64 == 0, cout % 160 == 0); elsewhere fz_conv3x3(..., upsample = 1) is the path.  Against that path the
+ * result differs by the fp16 rounding of the summed weights (both are checked against the same fp32 reference). */
+int fz_conv3x3_up2_ok(int n, int h, int w, int cin, int cout);
+int64_t fz_conv3x3_up2_pack_halves(int cin, int cout);
+int fz_conv3x3_up2_pack(const void* wt, void* wt_up, int cin, int cout, void* stream);
+int fz_conv3x3_up2(const void* x, const void* wt_up, const void* bias, void* y, int n, int h, int w, int cin, int cout, void* stream);
+
 /* Temporal k=3 convolution over the frame axis (the two Conv1d of LoRALinearLayer, lora.py:31-54, applied on
  * '(b h w) c f'): y[n][tok][co] = sum_{t=0..2, ci} x[n - f + (f+t-1)][tok][ci] * wt[co][t][ci] (+ res), zero padded at the
  * clip ends (f = n % clip_len).  x: [n][tokens][cin]; wt: [cout][3][cin]; y/res/res2: [n][tokens][cout];

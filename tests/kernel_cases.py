@@ -406,6 +406,36 @@ def case_conv3x3(device, *, n, h, w, cin, cout, stride=1, upsample=False, with_t
     return {"max_err": err}
 
 
+def case_conv3x3_up2(device, *, n, h, w, cin, cout, seed=0):
+    """fz_conv3x3_up2 (nearest-2x + 3x3 convolution as four 2x2 convolutions on summed weights) against torch's interpolate + conv2d in fp32,
+    and against fz_conv3x3(upsample=1) on the same operands (differs only by the fp16 rounding of the summed weights)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, h * w, cin, generator=g).half().to(device)
+    wgt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    bias = (torch.randn(cout, generator=g) * 0.1).half().to(device)
+    wt = K.pack_conv3x3_weight(wgt).to(device)
+    wup = K.pack_conv3x3_up2_weight(wt)
+    # the packed weights against their definition
+    w9 = wgt.float()
+    rows = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    for z in range(4):
+        for t in range(4):
+            ref = sum(w9[:, :, ky, kx] for ky in rows[(z >> 1, t >> 1)] for kx in rows[(z & 1, t & 1)])
+            assert torch.equal(wup[z, :, t, :].cpu(), ref.half()), (z, t)
+    assert K.conv3x3_up2_ok(n, h, w, cin, cout)
+    y, (ho, wo) = K.conv3x3_up2(x, wup, bias, hw=(h, w))
+    assert (ho, wo) == (2 * h, 2 * w)
+    xi = F.interpolate(x.float().cpu().reshape(n, h, w, cin).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    yr = F.conv2d(xi, wgt.float(), bias.float().cpu(), padding=1).permute(0, 2, 3, 1).reshape(n, ho * wo, cout)
+    err = (y.float().cpu() - yr).abs().max().item()
+    assert torch.isfinite(y.float()).all()
+    assert err < 4e-3 * max(1.0, float(yr.abs().max())), err
+    y9, _ = K.conv3x3(x, wt, bias, hw=(h, w), upsample=True)
+    d9 = (y.float() - y9.float()).abs().max().item()
+    assert d9 < 4e-3 * max(1.0, float(yr.abs().max())), d9
+    return {"max_err": err, "vs_nine_taps": d9}
+
+
 def case_groupnorm_cat(device, *, n, span, tokens, c1, c2, groups, silu=True, seed=0):
     """fz_groupnorm_cat == fz_groupnorm on the materialised torch.cat([x1, x2], channel): same kernels, same arithmetic -> bit-equal;
     and against torch's GroupNorm on the 5-D view (resnet.py:338 after unet_3d_blocks.py:384-395)."""

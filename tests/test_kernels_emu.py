@@ -337,6 +337,15 @@ def test_conv3x3_pixel_halo_in_k_slices():
     KC.case_conv3x3(DEV, n=1, h=16, w=16, cin=256, cout=160, tile_cfg=154299, split_k=4, seed=2)
 
 
+def test_conv3x3_up2_four_subpixel_convolutions():
+    """fz_conv3x3_up2: nearest-2x + 3x3 as four 2x2 convolutions of the input on summed weights (conv_halo_kernel<4>): every output parity, image
+    borders (the zero row / column of the UPSAMPLED image is the zero row / column of the input), W = 16 and 32, several chunks, two channel tiles."""
+    KC.case_conv3x3_up2(DEV, n=1, h=16, w=16, cin=64, cout=160)
+    KC.case_conv3x3_up2(DEV, n=2, h=8, w=32, cin=192, cout=320, seed=1)
+    KC.case_conv3x3_up2(DEV, n=1, h=32, w=16, cin=128, cout=160, seed=2)   # two tiles per frame
+    assert not K.conv3x3_up2_ok(1, 8, 8, 64, 160)
+
+
 def test_k_group_pingpong_conv_modes():
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252218)
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252218)

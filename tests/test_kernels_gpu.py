@@ -238,6 +238,13 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     print(KC.case_conv3x3(DEV, n=8, h=16, w=16, cin=640, cout=1280, fpb=8, tile_cfg=154299, seed=7))
 
 
+def test_conv3x3_up2_four_subpixel_convolutions():
+    """fz_conv3x3_up2 at the UNet's upsamplers (16^2 x 1280 and 32^2 x 640, 8 / 16 frames) against torch fp32 and the nine-tap path."""
+    print(KC.case_conv3x3_up2(DEV, n=8, h=16, w=16, cin=1280, cout=1280))
+    print(KC.case_conv3x3_up2(DEV, n=16, h=32, w=32, cin=640, cout=640, seed=1))
+    print(KC.case_conv3x3_up2(DEV, n=3, h=32, w=16, cin=128, cout=160, seed=2))
+
+
 @pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222, 252218])
 def test_gemm_every_tile_shape(tile_cfg):
     KC.case_gemm(DEV, rows=3000, k=640, o=960, n_res=1, tile_cfg=tile_cfg)
