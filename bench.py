@@ -522,6 +522,15 @@ def install_timers(K, timer):
         return ("conv3x3", 2.0 * 9 * cin * cout * n * ho * wo, alg)
     timer.wrap(K, "conv3x3", sel_conv)
 
+    def sel_conv_up2(x, wt_up, bias, **kw):  # nearest-2x + 3x3 as four 2x2 convolutions: priced at the FLOPs of the operation (nine taps per output)
+        if not timer.extra:
+            return None
+        h, w = kw["hw"]
+        n, cin, cout = x.shape[0], x.shape[2], wt_up.shape[1]
+        alg = 2.0 * (x.numel() + n * 4 * h * w * cout + 9 * cin * cout)
+        return ("conv3x3", 2.0 * 9 * cin * cout * n * 4 * h * w, alg)
+    timer.wrap(K, "conv3x3_up2", sel_conv_up2)
+
     def sel_gemm(x, w, bias=None, **kw):
         if not timer.extra:
             return None
@@ -644,7 +653,9 @@ def rooflines(summ):
             roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
     job_pmc, job_src = pmc_job_traffic()
     for name, kernel, bound, peak, unit, scale in (
-            ("conv3x3", "igemm_kernel<.., MODE 1 / 3> (all 3x3 convolutions, 2*9*Cin*Cout FLOP per output pixel)", "mfma", 2500.0, "TFLOP/s", 1e12),
+            ("conv3x3", "all 3x3 convolutions at 2*9*Cin*Cout FLOP per output pixel: igemm_kernel<.., MODE 1 / 3>, conv_halo_kernel<9> (whole, or K slices + the split-K "
+                        "tail), conv_halo_kernel<4> (nearest-2x + 3x3 as four 2x2 convolutions: 4 / 9 of the multiply-adds, priced at the operation's nine)", "mfma", 2500.0,
+             "TFLOP/s", 1e12),
             ("gemm_mfma", "igemm_kernel<.., MODE 0> MFMA class: GEGLU projections and K >= 1280 projections with >= 1024 rows (2*K*N FLOP per row)",
              "mfma", 2500.0, "TFLOP/s", 1e12),
             ("gemm_hbm", "igemm_kernel<.., MODE 0> HBM class: plain projections with K <= 640 and >= 1024 rows (algorithmic bytes "

@@ -120,6 +120,7 @@ _SIGS = {
     "fz_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
                                      C.c_int, C.c_int, _P, _P]),
     "fz_conv3x3_up2_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fz_conv3x3_up2_preferred": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "fz_conv3x3_up2_pack_halves": (C.c_int64, [C.c_int, C.c_int]),
     "fz_conv3x3_up2_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "fz_conv3x3_up2": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

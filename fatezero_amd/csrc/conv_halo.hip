@@ -62,6 +62,9 @@ struct ChArgs {
     float* part;           // split-K: fp32 partial slabs [ksplit][N H W][Cout] (igemm.hip's layout; igemm_reduce_kernel sums them and applies the tail), or null
     int ksplit;            // gridDim.y: slice ks contracts the 64-channel chunks [ks nchunk / ksplit, (ks + 1) nchunk / ksplit) under all nine taps
     int w_magic;           // the same for / W on the tile's 256 pixels (upsampling form: output rows)
+    int fpt;               // frames per tile: 1 (a frame is one or several tiles), or 256 / (H W) whole frames (H W < 256: the 8 x 8 level), each with its own halo
+    int fh_px;             // halo pixels per frame of the tile: (rows + 2)(W + 2), rows = 256 / W (fpt == 1) or H
+    int fh_magic;          // ceil(2^20 / fh_px): halo pixel / fh_px == (halo pixel * fh_magic) >> 20 (host-checked)
     int w2_magic;          // ceil(65536 / (W + 2)): halo pixel / (W + 2) == (halo pixel * w2_magic) >> 16 for every halo pixel of a tile (host-checked)
 };
 
@@ -82,7 +85,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int ta = lid % g.tiles_a, tb = lid / g.tiles_a;
     const int a0 = ta * CH_BA;
-    const int W = g.W, W2 = W + 2, R = CH_BB / W;
+    const int W = g.W, W2 = W + 2;
     const int64_t px0 = (int64_t)tb * CH_BB;                 // first output pixel of the tile (flattened n, y, x)
     const int hw = g.H * W;
     const int fn = (int)(px0 / hw), y0 = (int)((px0 - (int64_t)fn * hw) / W);
@@ -114,11 +117,12 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     const half_t* const xf = g.x + (int64_t)fn * hw * g.Cin;
     auto piece_src = [&](int p) __attribute__((always_inline)) -> const char* {
         const int hp = 8 * p + (lane >> 3), pc = lane & 7;
-        const int yy = (hp * g.w2_magic) >> 16, xx = hp - yy * W2;
+        const int fi = (hp * g.fh_magic) >> 20, hr = hp - fi * g.fh_px;           // frame of the tile, halo pixel inside that frame's block
+        const int yy = (hr * g.w2_magic) >> 16, xx = hr - yy * W2;
         const int iy = y0 + yy - 1, ix = xx - 1;
-        const bool ok = yy < R + 2 && iy >= 0 && iy < g.H && ix >= 0 && ix < W;
+        const bool ok = fi < g.fpt && iy >= 0 && iy < g.H && ix >= 0 && ix < W;    // (yy < rows + 2 by construction: hr < fh_px)
         const int lc = pc ^ ((hp >> 1) & 7);
-        return ok ? reinterpret_cast<const char*>(xf) + (uint32_t)(((iy * W + ix) * g.Cin + lc * 8) * 2) : nullptr;
+        return ok ? reinterpret_cast<const char*>(xf) + (uint32_t)((((fi * g.H + iy) * W + ix) * g.Cin + lc * 8) * 2) : nullptr;
     };
     // chunk 0 of the halo tile: ALL eight waves fetch it (pieces wave, wave + 8, ..: at most 7 each), then take their roles
     {
@@ -246,8 +250,9 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         int hp0[CH_TB];
 #pragma unroll
         for (int q = 0; q < CH_TB; ++q) {
-            const int pl = 64 * wave + 32 * q + l31, yl = pl / W, xl = pl - yl * W;
-            hp0[q] = (yl + 1) * W2 + xl + 1;
+            const int pl = 64 * wave + 32 * q + l31;
+            const int fi = g.fpt > 1 ? pl / hw : 0, pr = pl - fi * hw, yl = pr / W, xl = pr - yl * W;
+            hp0[q] = fi * g.fh_px + (yl + 1) * W2 + xl + 1;
         }
         half8_t af0[CH_TA], bf0[CH_TB], af1[CH_TA], bf1[CH_TB];
         // LDS addresses of the fragments the READ cursor points at -- it runs one k sub-step ahead of the MFMAs: ONE address for the weight tile
@@ -384,7 +389,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
                                   : g.y + ((((int64_t)fn * 2 * g.H + 2 * y0 + py) * 2 * W + pxp)) * g.Cout + a0;
     auto out_off = [&](int pl) __attribute__((always_inline)) -> uint32_t {
         if constexpr (TAPS == 9) return (uint32_t)(pl * g.Cout);
-        const int yl = (pl * g.w_magic) >> 16, xl = pl - yl * W;
+        const int yl = (pl * g.w_magic) >> 16, xl = pl - yl * W;   // (row of the TILE: with several frames per tile, frame fi's rows start at fi H -- and so do its output rows, at 2 fi H)
         return (uint32_t)((4 * yl * W + 2 * xl) * g.Cout);
     };
     half8_t rv[NOUT];
@@ -496,10 +501,17 @@ extern "C" int fz_conv_halo_timing(long long* out) {
 
 // shapes the kernel carries: whole image rows per 256-pixel tile, whole tiles per frame, 160-channel tiles, 64-channel chunks
 int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride) {
-    if (n <= 0 || w < 16 || w > 128 || CH_BB % w || (h * w) % CH_BB || cin % 64 || cin < 64 || cout % CH_BA) return 0;
+    if (n <= 0 || h <= 0 || w < 8 || w > 128 || CH_BB % w || cin % 64 || cin < 64 || cout % CH_BA) return 0;
     if (temb_stride % 8) return 0;
-    const int np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
-    return np <= 50 && (int64_t)n * h * w < (1ll << 31) && (int64_t)h * w * cin * 2 < (1ll << 31);
+    const int hw = h * w;
+    int np;
+    if (hw % CH_BB == 0) {                       // a frame is one or several tiles
+        np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
+    } else {                                     // several whole frames per tile, each with its own halo
+        if (CH_BB % hw || n % (CH_BB / hw)) return 0;
+        np = ((CH_BB / hw) * (h + 2) * (w + 2) + 7) / 8;
+    }
+    return np <= 50 && (int64_t)n * h * w < (1ll << 31) && (int64_t)h * w * cin * 2 * (hw < CH_BB ? CH_BB / hw : 1) < (1ll << 31);
 }
 
 // part / ksplit: null / 1 = the whole convolution with its tail; else the fp32 slabs of ksplit K slices (the caller runs igemm_reduce_kernel)
@@ -520,10 +532,16 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
     g.part = g.ksplit > 1 ? part : nullptr;
     if (g.ksplit > 1 && (part == nullptr || g.ksplit > cin / 64)) return FZ_ERR_BAD_ARG;
     g.tiles_a = cout / CH_BA;
-    g.np = ((CH_BB / w + 2) * (w + 2) + 7) / 8;
+    g.fpt = h * w < CH_BB ? CH_BB / (h * w) : 1;
+    g.fh_px = ((g.fpt > 1 ? h : CH_BB / w) + 2) * (w + 2);
+    g.fh_magic = (1 << 20) / g.fh_px + 1;
+    g.np = (g.fpt * g.fh_px + 7) / 8;
     g.hb_bytes = g.np * 1024;
-    g.w2_magic = 65536 / (w + 2) + 1;
     for (int hp = 0; hp < 8 * g.np; ++hp)
+        if (((hp * g.fh_magic) >> 20) != hp / g.fh_px) return FZ_ERR_UNSUPPORTED;
+    if (temb != nullptr && g.temb_frames % g.fpt) return FZ_ERR_UNSUPPORTED;      // one time-embedding row per tile
+    g.w2_magic = 65536 / (w + 2) + 1;
+    for (int hp = 0; hp < g.fh_px; ++hp)
         if (((hp * g.w2_magic) >> 16) != hp / (w + 2)) return FZ_ERR_UNSUPPORTED;   // (never for the widths fz_conv_halo_ok admits)
     const size_t ring = (size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes + 1024, stage = (size_t)CH_BB * CH_OSTR * 2;
     if ((size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes < stage) return FZ_ERR_UNSUPPORTED;   // the bias / temb piece must lie beyond the staging area
@@ -582,6 +600,12 @@ FZ_KERNEL void __launch_bounds__(256) conv_up2_pack_kernel(const half_t* w9, hal
 
 // C ABI (include/fatezero_hip.h)
 extern "C" int fz_conv3x3_up2_ok(int n, int h, int w, int cin, int cout) { return fz_conv_halo_ok(n, h, w, cin, cout, 0); }
+// where it is FASTER than fz_conv3x3(upsample = 1) on MI355X (profiles/r06_conv_up2_ab.txt): from 128 workgroups on (4 parities x tiles) -- the
+// 8-frame launch of the 8 x 8 level (64 workgroups of 160 steps each) is the one UNet shape below
+extern "C" int fz_conv3x3_up2_preferred(int n, int h, int w, int cin, int cout) {
+    if (!fz_conv_halo_ok(n, h, w, cin, cout, 0)) return 0;
+    return 4 * (int64_t)(cout / CH_BA) * ((int64_t)n * h * w / CH_BB) >= 128 ? 1 : 0;
+}
 extern "C" int64_t fz_conv3x3_up2_pack_halves(int cin, int cout) { return (int64_t)16 * cin * cout; }
 extern "C" int fz_conv3x3_up2_pack(const void* wt, void* wt_up, int cin, int cout, void* stream) {
     if (!wt || !wt_up || cin <= 0 || cout <= 0) return FZ_ERR_BAD_ARG;

@@ -1346,32 +1346,46 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
 #endif
 }
 
-// split-K tail: y[b][a] = sum_s part[s][b][a] + bias[a] (+ temb) (+ res) (+ res2); one thread per 4 outputs
+// split-K tail: y[b][a] = sum_s part[s][b][a] + bias[a] (+ temb) (+ res) (+ res2), the slabs summed in slice order.  One WAVE per output row
+// (4 rows per workgroup), a lane per 4 consecutive outputs: what depends on the row only -- batch element, time-embedding row -- is wave-uniform
+// and worked out once per row (the first form, a flat index per thread, spent two or three 64-bit divisions per 4 outputs).
 FZ_KERNEL void __launch_bounds__(256) igemm_reduce_kernel(IgArgs g, int batch) {
-    const int64_t per = g.Nb * (g.Ma / 4);
-    const int64_t total = per * batch;
-    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-        const int z = (int)(id / per);
-        const int64_t r = id - (int64_t)z * per;
-        const int64_t px = r / (g.Ma / 4);
-        const int co = (int)(r - px * (g.Ma / 4)) * 4;
-        f32x4 s = *reinterpret_cast<const f32x4*>(g.part + ((int64_t)z * g.Nb + px) * g.Ma + co);
-        for (int k = 1; k < g.ksplit; ++k) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(g.part + (((int64_t)k * batch + z) * g.Nb + px) * g.Ma + co);
-            s += t;
+    const int q = g.Ma / 4;
+    const int cl = threadIdx.x & 63, rl = fz_uniform((int)(threadIdx.x >> 6));
+    const int64_t rows = g.Nb * batch;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + rl; row < rows; row += (int64_t)gridDim.x * 4) {
+        int z = 0;
+        int64_t px = row;
+        if (batch > 1) {
+            z = (int)(row / g.Nb);
+            px = row - (int64_t)z * g.Nb;
         }
-        float f[4] = {s[0], s[1], s[2], s[3]};
-        if (g.bias != nullptr)
-            for (int e = 0; e < 4; ++e) f[e] += (float)g.bias[co + e];
-        if (g.temb != nullptr)
-            for (int e = 0; e < 4; ++e) f[e] += (float)g.temb[(px / g.temb_group) * g.temb_stride + co + e];
-        if (g.res != nullptr)
-            for (int e = 0; e < 4; ++e) f[e] += (float)g.res[(int64_t)z * g.res_bs + px * g.ldres + co + e];
-        if (g.res2 != nullptr)
-            for (int e = 0; e < 4; ++e) f[e] += (float)g.res2[(int64_t)z * g.res_bs + px * g.ldres + co + e];
-        half4_t o;
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)f[e];
-        *reinterpret_cast<half4_t*>(g.y + (int64_t)z * g.y_bs + px * g.ldy + co) = o;
+        const float* const p0 = g.part + row * g.Ma;                      // slab 0: [batch][Nb][Ma]
+        const int64_t slab = (int64_t)batch * g.Nb * g.Ma;
+        const half_t* const trow = g.temb != nullptr ? g.temb + (px / g.temb_group) * g.temb_stride : nullptr;
+        const half_t* const r1 = g.res != nullptr ? g.res + (int64_t)z * g.res_bs + px * g.ldres : nullptr;
+        const half_t* const r2 = g.res2 != nullptr ? g.res2 + (int64_t)z * g.res_bs + px * g.ldres : nullptr;
+        half_t* const yrow = g.y + (int64_t)z * g.y_bs + px * g.ldy;
+        for (int c4 = cl; c4 < q; c4 += 64) {
+            const int co = c4 * 4;
+            f32x4 s = *reinterpret_cast<const f32x4*>(p0 + co);
+            for (int k = 1; k < g.ksplit; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p0 + k * slab + co);
+                s += t;
+            }
+            float f[4] = {s[0], s[1], s[2], s[3]};
+            if (g.bias != nullptr)
+                for (int e = 0; e < 4; ++e) f[e] += (float)g.bias[co + e];
+            if (trow != nullptr)
+                for (int e = 0; e < 4; ++e) f[e] += (float)trow[co + e];
+            if (r1 != nullptr)
+                for (int e = 0; e < 4; ++e) f[e] += (float)r1[co + e];
+            if (r2 != nullptr)
+                for (int e = 0; e < 4; ++e) f[e] += (float)r2[co + e];
+            half4_t o;
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)f[e];
+            *reinterpret_cast<half4_t*>(yrow + co) = o;
+        }
     }
 }
 
@@ -1829,8 +1843,8 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
         rc = ig_dispatch_cfg<MODE, GEGLU>(cfg, g, batch, stream);
     }
     if (rc != FZ_OK || ksplit == 1) return rc != FZ_OK ? rc : (gs_dropped ? FZ_GEMM_NO_STATS : FZ_OK);
-    const int64_t total = g.Nb * (g.Ma / 4) * batch;
-    dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+    const int64_t rblocks = (g.Nb * batch + 3) / 4;   // one wave per row, 4 rows per workgroup
+    dim3 grid((unsigned)(rblocks < 16384 ? rblocks : 16384)), block(256);
     FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, batch);
     const int rc2 = fz_last_launch_status();
     return rc2 != FZ_OK ? rc2 : ((stats_dropped || gs_dropped) ? FZ_GEMM_NO_STATS : FZ_OK);
@@ -2156,8 +2170,8 @@ static int conv_halo_run(IgArgs& g, const void* x, const void* wt, const void* b
     if (rc != FZ_OK) return rc;
     g.ksplit = ksplit;
     g.part = workspace;
-    const int64_t total = g.Nb * (g.Ma / 4);
-    dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+    const int64_t rblocks = (g.Nb + 3) / 4;
+    dim3 grid((unsigned)(rblocks < 16384 ? rblocks : 16384)), block(256);
     FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, 1);
     return fz_last_launch_status();
 }
@@ -2188,7 +2202,7 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
     if (tile_cfg == 0 && split_k <= 1 && stride == 1 && !upsample && fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) {
         const int64_t tiles = (int64_t)(cout / 160) * (g.Nb / 256);
         const int nchunk = cin / 64;
-        int ks = tiles >= 160 ? 1 : (tiles >= 96 ? 2 : (tiles >= 48 ? 4 : 0));
+        int ks = tiles >= 160 ? 1 : (tiles >= 96 ? 2 : (tiles >= 48 ? 4 : (tiles >= 24 && nchunk >= 20 ? 8 : 0)));   // (8: 16 frames x 8^2: -6 ... -9 %)
         if (ks == 4 && nchunk < 10) ks = 2;
         if (ks == 2 && nchunk < 6) ks = tiles >= 96 ? 1 : 0;
         if (ks > 1 && (workspace == nullptr || (int64_t)ks * g.Nb * g.Ma > workspace_floats || (g.Ma % 4) || (g.ldy % 4))) ks = tiles >= 96 ? 1 : 0;

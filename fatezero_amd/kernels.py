@@ -882,6 +882,11 @@ def conv3x3_up2_ok(n: int, h: int, w: int, cin: int, cout: int) -> bool:
     return bool(N.lib().fz_conv3x3_up2_ok(n, h, w, cin, cout))
 
 
+def conv3x3_up2_preferred(n: int, h: int, w: int, cin: int, cout: int) -> bool:
+    """... and is it the faster path there (measured rule of the library)?"""
+    return bool(N.lib().fz_conv3x3_up2_preferred(n, h, w, cin, cout))
+
+
 def pack_conv3x3_up2_weight(wt: torch.Tensor) -> torch.Tensor:
     """wt: fz_conv3x3's packed weights [Cout, 9, Cin] -> [4 parities, Cout, 4 taps, Cin], the taps summed per output parity (fz_conv3x3_up2_pack)."""
     cout, nine, cin = wt.shape

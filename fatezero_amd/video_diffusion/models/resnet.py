@@ -155,7 +155,7 @@ class PseudoConv3d(nn.Module):
             fused = fuse_tail and temb is None
         else:
             xin = x.data if x.data.is_contiguous() else x.data.contiguous()
-            if upsample and CONV_UP2 and self.stride == 1 and K.conv3x3_up2_ok(n, x.h, x.w, self.in_channels, self.out_channels):
+            if upsample and CONV_UP2 and self.stride == 1 and K.conv3x3_up2_preferred(n, x.h, x.w, self.in_channels, self.out_channels):
                 if self._packed_up is None or self._packed_up[0] is not w:
                     self._packed_up = (w, K.pack_conv3x3_up2_weight(w))   # (once per packed weight)
                 y, (oh, ow) = K.conv3x3_up2(xin, self._packed_up[1], bias, hw=(x.h, x.w))

@@ -304,10 +304,11 @@ int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb
  *   R(0, 0) = {0}, R(0, 1) = {1, 2}, R(1, 0) = {0, 1}, R(1, 1) = {2}      (fp32 sums in (ky, kx) order, one rounding to fp16)
  * and y[n][2 r + py][2 c + px][co] = bias[co] + sum_{t, ci} wt_up[z][co][t][ci] x[n][r + ty + py - 1][c + tx + px - 1][ci] (zero outside).
  * fz_conv3x3_up2_pack builds wt_up (fz_conv3x3_up2_pack_halves(cin, cout) halves) from fz_conv3x3's packed weights [cout][9][cin].
- * x: [n][h][w][cin]; y: [n][2 h][2 w][cout].  fz_conv3x3_up2_ok: the shapes the kernel carries (16 <= w <= 128 and 256 % w == 0, whole
- * 256-pixel tiles per frame, cin % 64 == 0, cout % 160 == 0); elsewhere fz_conv3x3(..., upsample = 1) is the path.  Against that path the
+ * x: [n][h][w][cin]; y: [n][2 h][2 w][cout].  fz_conv3x3_up2_ok: the shapes the kernel carries (8 <= w <= 128 and 256 % w == 0, frames of whole
+ * 256-pixel tiles or whole frames per tile, cin % 64 == 0, cout % 160 == 0); elsewhere fz_conv3x3(..., upsample = 1) is the path.  Against that path the
  * result differs by the fp16 rounding of the summed weights (both are checked against the same fp32 reference). */
 int fz_conv3x3_up2_ok(int n, int h, int w, int cin, int cout);
+int fz_conv3x3_up2_preferred(int n, int h, int w, int cin, int cout);   /* ... and where it is measured faster than fz_conv3x3(upsample = 1) */
 int64_t fz_conv3x3_up2_pack_halves(int cin, int cout);
 int fz_conv3x3_up2_pack(const void* wt, void* wt_up, int cin, int cout, void* stream);
 int fz_conv3x3_up2(const void* x, const void* wt_up, const void* bias, void* y, int n, int h, int w, int cin, int cout, void* stream);

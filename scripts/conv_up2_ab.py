@@ -31,7 +31,7 @@ def timeit(fns):
 
 
 print("nearest-2x + conv3x3: frames hw cin cout | nine taps   four 2x2   (us per launch)")
-for (n, hw, cin, cout) in [(8, 16, 1280, 1280), (16, 16, 1280, 1280), (8, 32, 640, 640), (16, 32, 640, 640), (24, 32, 640, 640), (32, 16, 1280, 1280)]:
+for (n, hw, cin, cout) in [(8, 8, 1280, 1280), (16, 8, 1280, 1280), (8, 16, 1280, 1280), (16, 16, 1280, 1280), (8, 32, 640, 640), (16, 32, 640, 640), (24, 32, 640, 640), (32, 16, 1280, 1280)]:
     xs = [torch.randn(n, hw * hw, cin, device=dev).half() for _ in range(POOL)]
     wt = K.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3) * 0.02).half().to(dev))
     wup = K.pack_conv3x3_up2_weight(wt)

@@ -20,6 +20,8 @@ def klass(name):
         return "ff_chain"
     if "xattn_chain_kernel" in name:
         return "xattn_chain"
+    if "conv_halo_kernel" in name:  # the halo form of the 3x3 convolution, whole / in K slices / as the upsampler's four 2x2 convolutions (csrc/conv_halo.hip)
+        return "conv3x3"
     if "igemm_reduce" in name:
         return "splitk_reduce"
     if "lora_pair_kernel" in name:  # both temporal LoRA convolutions in one launch (csrc/lora_pair.hip)

@@ -324,8 +324,12 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     KC.case_conv3x3(DEV, n=1, h=8, w=64, cin=192, cout=160, with_res=True, tile_cfg=154299, seed=3)
     KC.case_conv3x3(DEV, n=4, h=8, w=32, cin=64, cout=320, with_temb=True, fpb=2, tile_cfg=154299, seed=4)   # two time-embedding rows, no residual
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=160, with_temb=True, with_res=True, tile_cfg=154299, seed=5)   # W = 16: a tile is a frame
+    # frames smaller than a tile (the 8 x 8 level): four whole frames per tile, each with its own halo; 8 x 16: two
+    KC.case_conv3x3(DEV, n=4, h=8, w=8, cin=128, cout=160, with_temb=True, with_res=True, fpb=4, tile_cfg=154299, seed=6)
+    KC.case_conv3x3(DEV, n=8, h=8, w=8, cin=64, cout=320, with_temb=True, fpb=4, tile_cfg=154299, seed=7)
+    KC.case_conv3x3(DEV, n=2, h=8, w=16, cin=64, cout=160, with_res=True, tile_cfg=154299, seed=8)
     with pytest.raises(Exception):   # shapes it does not carry are refused, not mangled
-        KC.case_conv3x3(DEV, n=1, h=8, w=8, cin=64, cout=160, tile_cfg=154299)
+        KC.case_conv3x3(DEV, n=3, h=8, w=8, cin=64, cout=160, tile_cfg=154299)   # not whole tiles of four frames
 
 
 def test_conv3x3_pixel_halo_in_k_slices():
@@ -335,6 +339,7 @@ def test_conv3x3_pixel_halo_in_k_slices():
     KC.case_conv3x3(DEV, n=1, h=16, w=16, cin=256, cout=160, with_temb=True, with_res=True, tile_cfg=154299, split_k=2)
     KC.case_conv3x3(DEV, n=2, h=8, w=32, cin=320, cout=320, with_res=True, fpb=2, tile_cfg=154299, split_k=3, seed=1)
     KC.case_conv3x3(DEV, n=1, h=16, w=16, cin=256, cout=160, tile_cfg=154299, split_k=4, seed=2)
+    KC.case_conv3x3(DEV, n=8, h=8, w=8, cin=256, cout=160, with_temb=True, with_res=True, fpb=8, tile_cfg=154299, split_k=2, seed=3)
 
 
 def test_conv3x3_up2_four_subpixel_convolutions():
@@ -343,7 +348,8 @@ def test_conv3x3_up2_four_subpixel_convolutions():
     KC.case_conv3x3_up2(DEV, n=1, h=16, w=16, cin=64, cout=160)
     KC.case_conv3x3_up2(DEV, n=2, h=8, w=32, cin=192, cout=320, seed=1)
     KC.case_conv3x3_up2(DEV, n=1, h=32, w=16, cin=128, cout=160, seed=2)   # two tiles per frame
-    assert not K.conv3x3_up2_ok(1, 8, 8, 64, 160)
+    KC.case_conv3x3_up2(DEV, n=4, h=8, w=8, cin=128, cout=160, seed=3)     # four frames per tile
+    assert not K.conv3x3_up2_ok(3, 8, 8, 64, 160)
 
 
 def test_k_group_pingpong_conv_modes():

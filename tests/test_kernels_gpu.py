@@ -236,6 +236,9 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     print(KC.case_conv3x3(DEV, n=16, h=16, w=16, cin=1280, cout=1280, with_temb=True, fpb=8, tile_cfg=154299, split_k=2, seed=5))
     print(KC.case_conv3x3(DEV, n=8, h=16, w=16, cin=2560, cout=1280, with_res=True, fpb=8, tile_cfg=154299, split_k=4, seed=6))
     print(KC.case_conv3x3(DEV, n=8, h=16, w=16, cin=640, cout=1280, fpb=8, tile_cfg=154299, seed=7))
+    # the 8 x 8 level: four whole frames per tile, each with its own halo
+    print(KC.case_conv3x3(DEV, n=16, h=8, w=8, cin=1280, cout=1280, with_temb=True, with_res=True, fpb=8, tile_cfg=154299, split_k=8, seed=8))
+    print(KC.case_conv3x3(DEV, n=8, h=8, w=8, cin=2560, cout=1280, with_temb=True, fpb=8, tile_cfg=154299, split_k=4, seed=9))
 
 
 def test_conv3x3_up2_four_subpixel_convolutions():
@@ -243,6 +246,7 @@ def test_conv3x3_up2_four_subpixel_convolutions():
     print(KC.case_conv3x3_up2(DEV, n=8, h=16, w=16, cin=1280, cout=1280))
     print(KC.case_conv3x3_up2(DEV, n=16, h=32, w=32, cin=640, cout=640, seed=1))
     print(KC.case_conv3x3_up2(DEV, n=3, h=32, w=16, cin=128, cout=160, seed=2))
+    print(KC.case_conv3x3_up2(DEV, n=8, h=8, w=8, cin=1280, cout=1280, seed=3))
 
 
 @pytest.mark.parametrize("tile_cfg", [254222, 254122, 158122, 244222, 224223, 222222, 212222, 254218, 244218, 252222, 252218])
