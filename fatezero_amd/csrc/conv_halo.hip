@@ -57,6 +57,7 @@ struct ChArgs {
     int temb_frames;       // frames per time-embedding row
     int N, H, W, Cin, Cout;
     int tiles_a;           // Cout / 160
+    int xa;                // XCD groups along the channel tiles (1: every XCD walks all of them)
     int hb_bytes;          // bytes of one halo buffer (pieces of 1 KB)
     int np;                // LDS-DMA pieces of a halo tile
     float* part;           // split-K: fp32 partial slabs [ksplit][N H W][Cout] (igemm.hip's layout; igemm_reduce_kernel sums them and applies the tail), or null
@@ -82,8 +83,20 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     // one pixel tile sit next to each other and share its halo rows in L2
     const int nt = gridDim.x, bid = blockIdx.x;
     const int q8 = nt >> 3, r8 = nt & 7, xcd = bid & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ta = lid % g.tiles_a, tb = lid / g.tiles_a;
+    int ta, tb;
+    if (g.xa > 1) {
+        // ... or, where the WEIGHTS are the larger operand (the 16^2 / 8^2 levels: 29.5 MB of them against 5-10 MB of pixels), the eight XCDs as
+        // xa groups along the channel tiles x 8 / xa groups along the pixel tiles (host: the split with the fewest bytes entering the L2s --
+        // with every XCD walking all channel tiles each of the eight L2s pulled the whole weight tensor: 235 MB per launch at 16 f x 16^2 x 1 280)
+        const int idx = bid >> 3, xia = xcd % g.xa, xib = xcd / g.xa;
+        const int ta_per = g.tiles_a / g.xa, tb_per = (nt / g.tiles_a) / (8 / g.xa);
+        ta = xia * ta_per + idx % ta_per;
+        tb = xib * tb_per + idx / ta_per;
+    } else {
+        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        ta = lid % g.tiles_a;
+        tb = lid / g.tiles_a;
+    }
     const int a0 = ta * CH_BA;
     const int W = g.W, W2 = W + 2;
     const int64_t px0 = (int64_t)tb * CH_BB;                 // first output pixel of the tile (flattened n, y, x)
@@ -548,6 +561,23 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
     const size_t lds = ring > stage ? ring : stage;
     if (lds > 160 * 1024) return FZ_ERR_UNSUPPORTED;
     const int64_t nwg = (int64_t)g.tiles_a * ((int64_t)n * h * w / CH_BB);
+    {   // bytes entering the eight L2s: every XCD group along the pixel tiles pulls its channel tiles' weights, every group along the channel tiles its pixels
+        const int64_t tiles_b = (int64_t)n * h * w / CH_BB;
+        const double wbytes = 2.0 * cout * taps * cin, xbytes = 2.0 * n * h * w * cin * (double)(g.fpt * g.fh_px) / CH_BB;
+        g.xa = 1;
+        if (nwg % 8 == 0) {
+            const double base = wbytes * 8 + xbytes;   // (xa = 1: the walk of the first version)
+            double best = 0.9 * base;                   // another split only where it saves >= 10 %
+            for (int xa = 2; xa <= 8; xa *= 2) {
+                if (g.tiles_a % xa || tiles_b % (8 / xa)) continue;
+                const double cost = wbytes * (8 / xa) + xbytes * xa;
+                if (cost < best) {
+                    best = cost;
+                    g.xa = xa;
+                }
+            }
+        }
+    }
     g.w_magic = 65536 / w + 1;
     for (int pl = 0; pl < CH_BB; ++pl)
         if (((pl * g.w_magic) >> 16) != pl / w) return FZ_ERR_UNSUPPORTED;

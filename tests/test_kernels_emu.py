@@ -328,6 +328,8 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
     KC.case_conv3x3(DEV, n=4, h=8, w=8, cin=128, cout=160, with_temb=True, with_res=True, fpb=4, tile_cfg=154299, seed=6)
     KC.case_conv3x3(DEV, n=8, h=8, w=8, cin=64, cout=320, with_temb=True, fpb=4, tile_cfg=154299, seed=7)
     KC.case_conv3x3(DEV, n=2, h=8, w=16, cin=64, cout=160, with_res=True, tile_cfg=154299, seed=8)
+    # weights the larger operand and whole tiles per XCD: the XCDs split along the channel tiles as well (csrc/conv_halo.hip, ChArgs::xa = 2)
+    KC.case_conv3x3(DEV, n=8, h=16, w=16, cin=64, cout=320, with_temb=True, with_res=True, fpb=4, tile_cfg=154299, seed=9)
     with pytest.raises(Exception):   # shapes it does not carry are refused, not mangled
         KC.case_conv3x3(DEV, n=3, h=8, w=8, cin=64, cout=160, tile_cfg=154299)   # not whole tiles of four frames
 
