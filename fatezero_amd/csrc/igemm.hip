@@ -1346,9 +1346,10 @@ FZ_KERNEL void __launch_bounds__((IgCfg<WA, TA, WB, TB, BK, NS, GEGLU, PP>::T), 
 #endif
 }
 
-// split-K tail: y[b][a] = sum_s part[s][b][a] + bias[a] (+ temb) (+ res) (+ res2), the slabs summed in slice order.  One WAVE per output row
-// (4 rows per workgroup), a lane per 4 consecutive outputs: what depends on the row only -- batch element, time-embedding row -- is wave-uniform
-// and worked out once per row (the first form, a flat index per thread, spent two or three 64-bit divisions per 4 outputs).
+// split-K tail: y[b][a] = sum_s part[s][b][a] + bias[a] (+ temb) (+ res) (+ res2), the slabs summed in slice order.  One WAVE per (output row,
+// segment of 256 columns = blockIdx.y), a lane per 4 consecutive outputs, 4 rows per workgroup: what depends on the row only -- batch element,
+// time-embedding row -- is wave-uniform and needs no per-element division (the first form, a flat index per thread, spent two or three 64-bit
+// divisions per 4 outputs; a wave walking its whole row segment by segment serialised 5 memory round trips at 1 280 columns and was slower).
 FZ_KERNEL void __launch_bounds__(256) igemm_reduce_kernel(IgArgs g, int batch) {
     const int q = g.Ma / 4;
     const int cl = threadIdx.x & 63, rl = fz_uniform((int)(threadIdx.x >> 6));
@@ -1366,7 +1367,8 @@ FZ_KERNEL void __launch_bounds__(256) igemm_reduce_kernel(IgArgs g, int batch) {
         const half_t* const r1 = g.res != nullptr ? g.res + (int64_t)z * g.res_bs + px * g.ldres : nullptr;
         const half_t* const r2 = g.res2 != nullptr ? g.res2 + (int64_t)z * g.res_bs + px * g.ldres : nullptr;
         half_t* const yrow = g.y + (int64_t)z * g.y_bs + px * g.ldy;
-        for (int c4 = cl; c4 < q; c4 += 64) {
+        const int c4 = (int)blockIdx.y * 64 + cl;
+        if (c4 < q) {
             const int co = c4 * 4;
             f32x4 s = *reinterpret_cast<const f32x4*>(p0 + co);
             for (int k = 1; k < g.ksplit; ++k) {
@@ -1844,7 +1846,7 @@ static int ig_run(IgArgs g, int batch, int cfg, int ksplit, float* workspace, in
     }
     if (rc != FZ_OK || ksplit == 1) return rc != FZ_OK ? rc : (gs_dropped ? FZ_GEMM_NO_STATS : FZ_OK);
     const int64_t rblocks = (g.Nb * batch + 3) / 4;   // one wave per row, 4 rows per workgroup
-    dim3 grid((unsigned)(rblocks < 16384 ? rblocks : 16384)), block(256);
+    dim3 grid((unsigned)(rblocks < 16384 ? rblocks : 16384), (unsigned)((g.Ma / 4 + 63) / 64)), block(256);
     FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, batch);
     const int rc2 = fz_last_launch_status();
     return rc2 != FZ_OK ? rc2 : ((stats_dropped || gs_dropped) ? FZ_GEMM_NO_STATS : FZ_OK);
@@ -2171,7 +2173,7 @@ static int conv_halo_run(IgArgs& g, const void* x, const void* wt, const void* b
     g.ksplit = ksplit;
     g.part = workspace;
     const int64_t rblocks = (g.Nb + 3) / 4;
-    dim3 grid((unsigned)(rblocks < 16384 ? rblocks : 16384)), block(256);
+    dim3 grid((unsigned)(rblocks < 16384 ? rblocks : 16384), (unsigned)((g.Ma / 4 + 63) / 64)), block(256);
     FZ_LAUNCH(igemm_reduce_kernel, grid, block, 0, stream, g, 1);
     return fz_last_launch_status();
 }

@@ -36,7 +36,9 @@ struct Problem {
     _Float16 *x, *w, *b, *y;
 };
 
-static int launch(const Problem& p, int cfg, void* ws, int64_t ws_floats) {
+static int launch(const Problem& p0, int cfg, void* ws, int64_t ws_floats) {
+    Problem p = p0;
+    if (getenv("FZ_TIMELINE_NOBIAS")) p.b = nullptr;   // (what the bias fetch in the epilogue costs: run with and without)
     if (cfg < 0) {  // the library's own choice: -1 = ring tiles only, -2 = with the ping-pong substitution, -N (N >= 4) = also under
         fz_igemm_trial_no_pp = cfg == -1;                      // split-K when a K slice has at least N K-64 steps
         fz_igemm_trial_pp_splitk_min = cfg <= -4 ? -cfg : 0;
