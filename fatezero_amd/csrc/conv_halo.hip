@@ -257,6 +257,9 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         }
     } else {
         // ================================================ consumers ========================================================================
+#if !defined(FZ_EMU) && defined(CH_CONSUMER_PRIO)
+        __builtin_amdgcn_s_setprio(CH_CONSUMER_PRIO);        // (trial: the MFMA waves ahead of their SIMD partners' address arithmetic in the issue arbiter)
+#endif
         // weight fragment (tile i, k sub-step kk): row 32 i + l31 of the slot, chunk (2 kk + hi) ^ ((row >> 2) & 3); a row = 64 bytes
         const int arow = l31 * 64, asw = (l31 >> 2) & 3;
         // pixel fragment (tile q, tap, chunk lc): halo pixel hp0[q] + tap shift, chunk lc ^ ((hp >> 1) & 7); a pixel = 128 bytes
