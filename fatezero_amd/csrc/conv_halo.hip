@@ -18,6 +18,19 @@
 //   waves 6-7  PIXEL loaders: the NEXT chunk's halo tile (<= 50 pieces of 8 pixels x 128 B), spread over the first 16 of the chunk's 18 steps,
 //              into the other of two halo buffers.
 // One barrier per K-32 step.  Barrier B(j) has weight tiles <= j + 1 landed and, in front of a chunk's last step, the next chunk's halo tile.
+//
+// Forms of the one kernel (round 6):
+//   * whole (fz_conv3x3's own choice from 160 tiles on) or in K SLICES (gridDim.y; slice ks contracts its 64-channel chunks under all nine taps into
+//     igemm.hip's fp32 slab layout, igemm_reduce_kernel sums the slabs and applies bias / time embedding / residual) where the tiles alone do not fill
+//     the chip: 8 frames x 32^2, the 16^2 and 8^2 levels;
+//   * a tile = 256 / W whole image rows of one frame (W >= 32), one whole frame (16 x 16), or SEVERAL whole frames each with its own halo block (8 x 8:
+//     four) -- the halo pixel index is (frame of the tile, halo row, halo column), every division a host-checked multiply-shift;
+//   * conv_halo_kernel<4>: nearest-2x upsampling + 3x3 convolution as four 2x2 convolutions of the low-resolution input, one output parity per
+//     blockIdx.z, on weights summed at pack time (fz_conv3x3_up2*);
+//   * the eight XCDs either all walk every channel tile (pixels shared in L2) or split into groups along the channel tiles (weights the larger operand):
+//     the host picks the split with the fewest bytes entering the L2s.
+// The first halo chunk is fetched by all eight waves together with one more LDS-DMA piece carrying the tile's bias slice and time-embedding row, so the
+// first MFMA issues 1.9 us after entry and the epilogue waits for no memory but the residual rows it requested before staging.
 #include "fz_rt.h"
 #include <atomic>
 #include "../../include/fatezero_hip.h"
