@@ -155,9 +155,13 @@ class PseudoConv3d(nn.Module):
             fused = fuse_tail and temb is None
         else:
             xin = x.data if x.data.is_contiguous() else x.data.contiguous()
-            if upsample and CONV_UP2 and self.stride == 1 and K.conv3x3_up2_preferred(n, x.h, x.w, self.in_channels, self.out_channels):
-                if self._packed_up is None or self._packed_up[0] is not w:
-                    self._packed_up = (w, K.pack_conv3x3_up2_weight(w))   # (once per packed weight)
+            up2 = upsample and CONV_UP2 and self.stride == 1 and self.in_channels % 64 == 0 and self.out_channels % 160 == 0
+            if up2 and (self._packed_up is None or self._packed_up[0] is not w):
+                # once per packed weight, in the FIRST forward that reaches the upsampler whether or not this launch takes the form (the 8-frame
+                # launch of the 8 x 8 level does not, the 16-frame one does): a weight pack must exist before any forward is recorded as an issue
+                # plan (issue.py: a block the plans' pool hands out later can alias what an older plan's replay overwrites)
+                self._packed_up = (w, K.pack_conv3x3_up2_weight(w))
+            if up2 and K.conv3x3_up2_preferred(n, x.h, x.w, self.in_channels, self.out_channels):
                 y, (oh, ow) = K.conv3x3_up2(xin, self._packed_up[1], bias, hw=(x.h, x.w))
                 fused = fuse_tail and temb is None and residual is None
             else:
