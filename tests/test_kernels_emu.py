@@ -354,6 +354,44 @@ def test_conv3x3_up2_four_subpixel_convolutions():
     assert not K.conv3x3_up2_ok(3, 8, 8, 64, 160)
 
 
+def test_upsampler_module_takes_the_subpixel_form_and_caches_its_pack():
+    """UpsamplePseudo3D through PseudoConv3d.forward_tokens: where fz_conv3x3_up2_preferred says so the launch is the four-2x2 form on a weight pack
+    made ONCE (in the first forward that reaches the upsampler, whichever form that launch takes -- issue plans need packs to exist before a forward is
+    recorded), dropped with the other packs by invalidation; FZ_NO_CONV_UP2's switch gives the nine-tap launch; both within the kernels' tolerance of
+    torch's interpolate + conv2d."""
+    import torch.nn.functional as F
+    from fatezero_amd.video_diffusion.models import resnet as R
+    torch.manual_seed(0)
+    assert K.conv3x3_up2_preferred(16, 16, 16, 64, 320) and not K.conv3x3_up2_preferred(1, 16, 16, 64, 320)   # 128 workgroups / 8
+    up = R.UpsamplePseudo3D(64, use_conv=True, out_channels=320).half()
+    with torch.no_grad():
+        up.conv.weight.mul_(0.3)
+    x16 = R.Tokens(torch.randn(16, 256, 64).half(), 2, 8, 16, 16)
+    x1 = R.Tokens(torch.randn(1, 256, 64).half(), 1, 1, 16, 16)
+
+    @torch.no_grad()
+    def ref(t):
+        xi = F.interpolate(t.data.float().reshape(-1, 16, 16, 64).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+        y = F.conv2d(xi, up.conv.weight.float().reshape(320, 64, 3, 3), up.conv.bias.float(), padding=1)
+        return y.permute(0, 2, 3, 1).reshape(t.data.shape[0], 1024, 320)
+    assert up.conv._packed_up is None
+    y1 = up.forward_tokens(x1)                       # 8 workgroups: the nine-tap launch -- and the pack is made all the same
+    pack = up.conv._packed_up
+    assert pack is not None and (y1.h, y1.w) == (32, 32)
+    y16 = up.forward_tokens(x16)                     # 128 workgroups: the sub-pixel form, on the same pack
+    assert up.conv._packed_up is pack
+    for t, y in ((x1, y1), (x16, y16)):
+        r = ref(t)
+        assert (y.data.float() - r).abs().max() < 4e-3 * max(1.0, float(r.abs().max()))
+    old = R.CONV_UP2
+    try:
+        R.CONV_UP2 = False
+        y9 = up.forward_tokens(x16)
+    finally:
+        R.CONV_UP2 = old
+    assert (y9.data.float() - y16.data.float()).abs().max() < 4e-3 * max(1.0, float(ref(x16).abs().max()))   # (the two forms round differently)
+
+
 def test_k_group_pingpong_conv_modes():
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=128, cout=320, with_temb=True, with_res=True, fpb=2, tile_cfg=252218)
     KC.case_conv3x3(DEV, n=2, h=16, w=16, cin=64, cout=96, stride=2, tile_cfg=252218)
