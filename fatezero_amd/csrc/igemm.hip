@@ -1370,40 +1370,23 @@ FZ_KERNEL void __launch_bounds__(256) igemm_reduce_kernel(IgArgs g, int batch) {
         const int c4 = (int)blockIdx.y * 64 + cl;
         if (c4 < q) {
             const int co = c4 * 4;
-            // everything the element needs is REQUESTED first -- the tail operands, then the slabs of up to eight slices -- and combined behind ONE
-            // memory round trip, the slabs in slice order (a chain of load -> add waits for every operand in turn: ksplit + 4 round trips of ~0.6 us
-            // in a kernel that is nothing else)
-            half4_t bv = {}, tv = {}, r1v = {}, r2v = {};
-            if (g.bias != nullptr) bv = *reinterpret_cast<const half4_t*>(g.bias + co);
-            if (trow != nullptr) tv = *reinterpret_cast<const half4_t*>(trow + co);
-            if (r1 != nullptr) r1v = *reinterpret_cast<const half4_t*>(r1 + co);
-            if (r2 != nullptr) r2v = *reinterpret_cast<const half4_t*>(r2 + co);
-            f32x4 s;
-            if (g.ksplit <= 8) {
-                f32x4 t[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k < g.ksplit) t[k] = *reinterpret_cast<const f32x4*>(p0 + k * slab + co);   // (wave-uniform: a scalar branch per slice)
-                s = t[0];
-#pragma unroll
-                for (int k = 1; k < 8; ++k)
-                    if (k < g.ksplit) s += t[k];
-            } else {
-                s = *reinterpret_cast<const f32x4*>(p0 + co);
-                for (int k = 1; k < g.ksplit; ++k) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(p0 + k * slab + co);
-                    s += t;
-                }
+            // (requesting every operand before the first add -- the slabs of up to eight slices, bias, temb, residuals -- was built and measured:
+            //  no faster, profiles/r06_igemm_bias_fetch.txt; and under -ffast-math the unrolled sum is free to re-associate, which moved results by
+            //  an ulp: the loop form keeps the slice order)
+            f32x4 s = *reinterpret_cast<const f32x4*>(p0 + co);
+            for (int k = 1; k < g.ksplit; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p0 + k * slab + co);
+                s += t;
             }
             float f[4] = {s[0], s[1], s[2], s[3]};
             if (g.bias != nullptr)
-                for (int e = 0; e < 4; ++e) f[e] += (float)bv[e];
+                for (int e = 0; e < 4; ++e) f[e] += (float)g.bias[co + e];
             if (trow != nullptr)
-                for (int e = 0; e < 4; ++e) f[e] += (float)tv[e];
+                for (int e = 0; e < 4; ++e) f[e] += (float)trow[co + e];
             if (r1 != nullptr)
-                for (int e = 0; e < 4; ++e) f[e] += (float)r1v[e];
+                for (int e = 0; e < 4; ++e) f[e] += (float)r1[co + e];
             if (r2 != nullptr)
-                for (int e = 0; e < 4; ++e) f[e] += (float)r2v[e];
+                for (int e = 0; e < 4; ++e) f[e] += (float)r2[co + e];
             half4_t o;
             for (int e = 0; e < 4; ++e) o[e] = (half_t)f[e];
             *reinterpret_cast<half4_t*>(yrow + co) = o;
