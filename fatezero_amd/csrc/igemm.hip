@@ -2199,7 +2199,7 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
         if (stride != 1 || upsample || !fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
         return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, split_k, (float*)workspace, workspace_floats, stream);
     }
-    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip once or twice (160-512 workgroups: the 8- and 16-frame
+    // The library's own choice takes the halo form where its 160 x 256 tiles fill the chip one to four times (160-1 024 workgroups: the 8- and 16-frame
     // launches of the 64^2 level, the 16-frame ones of 32^2): +26 % / +21 ... +28 % at one wave of tiles, +1 ... +6 % at two on MI355X
     // (profiles/r06_conv_halo_ab.txt) -- and, in K slices with the split-K tail kernel, where they do not: ~128 tiles (8 frames x 32^2, 16 x 16^2)
     // in two slices, ~64 (8 frames x 16^2) in four: -8 ... -15 % of the launch against the split-K implicit GEMM (profiles/r06_halo_split_ab.txt);
@@ -2211,7 +2211,7 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
         if (ks == 4 && nchunk < 10) ks = 2;
         if (ks == 2 && nchunk < 6) ks = tiles >= 96 ? 1 : 0;
         if (ks > 1 && (workspace == nullptr || (int64_t)ks * g.Nb * g.Ma > workspace_floats || (g.Ma % 4) || (g.ldy % 4))) ks = tiles >= 96 ? 1 : 0;
-        bool take = ks >= 1 && tiles <= 512;
+        bool take = ks >= 1 && tiles <= 1024;   // (768 tiles, 24 frames x 64^2: -17 ... -22 % of the launch; 1 024, 32 frames: -5 ... -6 %; profiles/r06_halo_split_ab_large.txt)
 #ifdef FZ_IGEMM_TRIALS
         if (fz_igemm_trial_no_halo) take = false;
         if (fz_igemm_trial_no_halo_split && (ks > 1 || tiles < 200)) take = false;
