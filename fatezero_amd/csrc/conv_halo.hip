@@ -169,8 +169,9 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
 
     if (wave >= 6) {
         // ================================================ pixel loaders ===================================================================
-        // Two pieces per step (26 slots for the <= 25 pieces of the next chunk's tile), their sources worked out on the spot: ~25 VALU per
-        // piece, in a wave that otherwise waits at barriers (a per-piece table cost 3.6 us of set-up in front of the first MFMA).
+        // PPS pieces per step (two of the nine-tap form's 18 steps per chunk, five of the upsampler form's 8: room for the <= 25 pieces of the next
+        // chunk's tile in the chunk's first SPC - 3 steps), their sources worked out on the spot: ~25 VALU per piece, in a wave that otherwise
+        // waits at barriers (a per-piece table cost 3.6 us of set-up in front of the first MFMA).
         const int bl = wave - 6;
         auto fire = [&](int p, int chunk) __attribute__((always_inline)) {
             const char* s0 = piece_src(p);
