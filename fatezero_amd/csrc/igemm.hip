@@ -2214,7 +2214,7 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
         bool take = ks >= 1 && tiles <= 1024;   // (768 tiles, 24 frames x 64^2: -17 ... -22 % of the launch; 1 024, 32 frames: -5 ... -6 %; profiles/r06_halo_split_ab_large.txt)
 #ifdef FZ_IGEMM_TRIALS
         if (fz_igemm_trial_no_halo) take = false;
-        if (fz_igemm_trial_no_halo_split && (ks > 1 || tiles < 200)) take = false;
+        if (fz_igemm_trial_no_halo_split && (ks > 1 || tiles < 200 || tiles > 512)) take = false;   // (= the rule of the first halo commit)
 #endif
         if (take) return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, ks, (float*)workspace, workspace_floats, stream);
     }

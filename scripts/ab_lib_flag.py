@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of an `int` switch INSIDE a trial build of the kernel library (symbols like fz_igemm_trial_no_kg2, only present with
 -DFZ_IGEMM_TRIALS): whole bench jobs with the switch 0 / 1, interleaved.
-    FZ_TRIAL_LIB=build_tmp/libfz_trials.so python scripts/ab_lib_flag.py fz_igemm_trial_no_kg2 [rounds]"""
+    FZ_TRIAL_LIB=build_tmp/libfz_trials.so python scripts/ab_lib_flag.py fz_igemm_trial_no_kg2 [rounds] [frames]"""
 import ctypes
 import os
 import sys
@@ -17,9 +17,10 @@ import bench  # noqa: E402
 
 flag = ctypes.c_int.in_dll(_native.lib(), sys.argv[1])
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 dev = torch.device("cuda:0")
 pipe = bench.build_pipeline(dev)
-z0 = torch.randn(1, 4, 8, 64, 64, generator=torch.Generator().manual_seed(1234)).to(dev)
+z0 = torch.randn(1, 4, frames, 64, 64, generator=torch.Generator().manual_seed(1234)).to(dev)
 times = {0: [], 1: []}
 for rnd in range(rounds + 1):
     for val in (0, 1):
