@@ -86,8 +86,12 @@ struct ChArgs {
 // of the low-resolution input, one per output parity (py, px) = blockIdx.z: U[y][x] = X[y >> 1][x >> 1] makes the three taps of a row hit only
 // two input rows -- r - 1 and r for even output rows (weights w[0] and w[1] + w[2]), r and r + 1 for odd ones (w[0] + w[1], w[2]), columns
 // alike: 4 instead of 9 MACs per output and input channel, on weights summed once at pack time (wt = [4 parities][Cout][4 taps][Cin]).
-template <int TAPS>
+// TA = MFMA tiles of 32 output channels per workgroup: 5 (the 160 x 256 tile) or 2 (64 x 256: five times the workgroups at the same slab traffic
+// where even eight K slices of the wide tile leave the chip idle -- the 8 x 8 level).
+template <int TAPS, int TA = 5>
 FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
+    constexpr int CH_TA = TA, CH_BA = TA * 32;              // (shadow the namespace's wide-tile constants inside the kernel)
+    constexpr int CH_ASLOT = CH_BA * 32 * 2, CH_OSTR = CH_BA + 8, APW = CH_BA / 32;   // APW: weight pieces (16 rows) per loader wave and tile
     constexpr int SPC = 2 * TAPS;                           // K-32 steps per 64-channel chunk
     const int py = TAPS == 4 ? (int)(blockIdx.z >> 1) : 0, pxp = TAPS == 4 ? (int)(blockIdx.z & 1) : 0;
     FZ_DYN_SMEM(raw);
@@ -118,6 +122,8 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     unsigned char* const Aring = raw;
     unsigned char* const Hbuf = raw + CH_NAS * CH_ASLOT;
     unsigned char* const Cpre = Hbuf + 2 * g.hb_bytes;      // 1 KB: bias | time-embedding row of the tile (beyond the epilogue's staging area)
+    uint32_t* const Ptab = reinterpret_cast<uint32_t*>(Cpre + 1024);   // np x 64 words: per (halo piece, lane) the byte offset of its chunk-0 source from the
+                                                                        // frame's base, ~0 = the zero page (written in the prologue, read by the pixel loaders)
     const int nchunk_all = g.Cin >> 6, ks = blockIdx.y;
     const int c0 = ks * nchunk_all / g.ksplit, nchunk = (ks + 1) * nchunk_all / g.ksplit - c0;   // this slice's chunks: c0 .. c0 + nchunk
     const int nstep = nchunk * SPC;                         // a step = (chunk, tap, K half)
@@ -155,14 +161,17 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
 #pragma unroll 1   /* (rolled: straight-line code that runs once pays for its instruction fetches) */
         for (int p = wave; p < g.np; p += 8) {
             const char* s0 = piece_src(p);
+            Ptab[p * 64 + lane] = s0 != nullptr ? (uint32_t)(s0 - reinterpret_cast<const char*>(xf)) : 0xffffffffu;
             fz_glds16(s0 != nullptr ? s0 + c0 * 128 : zero + lane * 16, Hbuf + (c0 & 1) * g.hb_bytes + p * 1024);
         }
-        // one more piece behind the halo buffers: bias (lanes 0-19) and the tile's time-embedding row (lanes 20-39) for the epilogue
+        fz_lds_fence();                                     // (the table's words are in LDS before this wave reaches B(0))
+        // one more piece behind the halo buffers: bias (the first CH_BA / 8 lanes) and the tile's time-embedding row (the next) for the epilogue
         if (wave == 3) {
             const char* s0 = zero + lane * 16;
-            if (lane < 20 && g.bias != nullptr) s0 = reinterpret_cast<const char*>(g.bias + a0 + lane * 8);
-            if (lane >= 20 && lane < 40 && g.temb != nullptr)
-                s0 = reinterpret_cast<const char*>(g.temb + (int64_t)(fn / g.temb_frames) * g.temb_stride + a0 + (lane - 20) * 8);
+            constexpr int BL = CH_BA / 8;   // 16-byte lanes of a channel-tile row
+            if (lane < BL && g.bias != nullptr) s0 = reinterpret_cast<const char*>(g.bias + a0 + lane * 8);
+            if (lane >= BL && lane < 2 * BL && g.temb != nullptr)
+                s0 = reinterpret_cast<const char*>(g.temb + (int64_t)(fn / g.temb_frames) * g.temb_stride + a0 + (lane - BL) * 8);
             fz_glds16(s0, Cpre);
         }
     }
@@ -173,9 +182,11 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         // chunk's tile in the chunk's first SPC - 3 steps), their sources worked out on the spot: ~25 VALU per piece, in a wave that otherwise
         // waits at barriers (a per-piece table cost 3.6 us of set-up in front of the first MFMA).
         const int bl = wave - 6;
+        // (sources from the prologue's table: worked out on the spot -- a dozen integer multiplies and a 64-bit select per piece -- the two pieces
+        //  of a step kept a loader wave busy ~600 cycles per step, the floor of the narrow tile's step and next to the wide one's 760)
         auto fire = [&](int p, int chunk) __attribute__((always_inline)) {
-            const char* s0 = piece_src(p);
-            fz_glds16(s0 != nullptr ? s0 + chunk * 128 : zero + lane * 16, Hbuf + (chunk & 1) * g.hb_bytes + p * 1024);
+            const uint32_t off = Ptab[p * 64 + lane];
+            fz_glds16(off != 0xffffffffu ? reinterpret_cast<const char*>(xf) + off + chunk * 128 : zero + lane * 16, Hbuf + (chunk & 1) * g.hb_bytes + p * 1024);
         };
 #ifdef CH_TIMING
         const long long w_p0 = wall_clock64(), w_p1 = w_p0;
@@ -217,9 +228,9 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         // tile (chunk c, tap t, half h) = rows a0 .. a0 + 160 of wt, 32 halves at k = t Cin + 64 c + 32 h; piece p = rows [16 p, 16 p + 16) x 4
         // chunks of 16 B; lane = (row 16 p + lane / 4, physical chunk lane % 4) fetches logical chunk (lane % 4) ^ ((row >> 2) & 3)
         const int al = wave - 4;
-        uint32_t aoff[5];
+        uint32_t aoff[APW];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < APW; ++i) {
             const int row = 16 * (al + 2 * i) + (lane >> 2);
             const int lc = (lane & 3) ^ ((row >> 2) & 3);
             aoff[i] = (uint32_t)(((int64_t)row * TAPS * g.Cin + lc * 8) * 2);
@@ -229,7 +240,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
             const int c = j / SPC, r = j - SPC * c, t = r >> 1, h = r & 1;
             const char* base = a_tile + ((int64_t)t * g.Cin + 64 * (c0 + c) + 32 * h) * 2;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) fz_glds16_so(base, aoff[i], Aring + (j & 3) * CH_ASLOT + (al + 2 * i) * 1024);
+            for (int i = 0; i < APW; ++i) fz_glds16_so(base, aoff[i], Aring + (j & 3) * CH_ASLOT + (al + 2 * i) * 1024);
         };
 #ifdef CH_TIMING
         const long long w_a0 = wall_clock64();
@@ -241,7 +252,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
         const long long w_a1 = wall_clock64();
 #endif
         if (nstep > 2) {
-            fz_wait_vm<5>();                                // tiles 0, 1 landed; tile 2 in flight
+            fz_wait_vm<APW>();                                // tiles 0, 1 landed; tile 2 in flight
         } else {
             fz_wait_vm0();
         }
@@ -257,7 +268,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
                     issue(j + 3);                           // into the slot tile j - 1 left (all its fragments were read before B(j))
 #endif
                     CH_T1(2);
-                    fz_wait_vm<5>();                        // tile j + 2 landed
+                    fz_wait_vm<APW>();                        // tile j + 2 landed
                 } else {
                     fz_wait_vm0();
                 }
@@ -337,12 +348,13 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
                 for (int q = 0; q < CH_TB; ++q) acc[i][q] = fz_mfma_32x32x16_f16(af[i], bf[q], acc[i][q]);
 #endif
 #ifndef FZ_EMU
+            constexpr int NR = CH_TA + CH_TB, NM = CH_TA * CH_TB, NP = NR < NM ? NR : NM;   // reads, MFMAs, interleaved pairs
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < NP; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if constexpr (NM > NP) __builtin_amdgcn_sched_group_barrier(0x008, NM - NP, 0);
 #endif
         };
         fz_wait_vm0();                                      // (this wave's pieces of the first halo chunk)
@@ -439,7 +451,7 @@ FZ_KERNEL void __launch_bounds__(512, 2) conv_halo_kernel(ChArgs g) {
     const half_t* const bias_l = reinterpret_cast<const half_t*>(Cpre);
     const half_t* const temb_l = reinterpret_cast<const half_t*>(Cpre) + CH_BA;
     if (wave < 4) {
-        half4_t bvs[CH_TA][4];   // (all of them first: read one by one, each ds_read was waited for on the spot -- 20 LDS latencies in a row)
+        half4_t bvs[CH_TA][4];   // (all of them first: read one by one, each ds_read was waited for on the spot -- 4 TA LDS latencies in a row)
 #pragma unroll
         for (int i = 0; i < CH_TA; ++i)
 #pragma unroll
@@ -530,8 +542,8 @@ extern "C" int fz_conv_halo_timing(long long* out) {
 #endif
 
 // shapes the kernel carries: whole image rows per 256-pixel tile, whole tiles per frame, 160-channel tiles, 64-channel chunks
-int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride) {
-    if (n <= 0 || h <= 0 || w < 8 || w > 128 || CH_BB % w || cin % 64 || cin < 64 || cout % CH_BA) return 0;
+static int conv_halo_ok_ba(int n, int h, int w, int cin, int cout, int64_t temb_stride, int ba) {
+    if (n <= 0 || h <= 0 || w < 8 || w > 128 || CH_BB % w || cin % 64 || cin < 64 || cout % ba) return 0;
     if (temb_stride % 8) return 0;
     const int hw = h * w;
     int np;
@@ -543,9 +555,12 @@ int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride)
     }
     return np <= 50 && (int64_t)n * h * w < (1ll << 31) && (int64_t)h * w * cin * 2 * (hw < CH_BB ? CH_BB / hw : 1) < (1ll << 31);
 }
+int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride) { return conv_halo_ok_ba(n, h, w, cin, cout, temb_stride, CH_BA); }
+// the narrow form (64 output channels per workgroup, conv_halo_kernel<9, 2>)
+int fz_conv_halo64_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride) { return conv_halo_ok_ba(n, h, w, cin, cout, temb_stride, 64); }
 
 // part / ksplit: null / 1 = the whole convolution with its tail; else the fp32 slabs of ksplit K slices (the caller runs igemm_reduce_kernel)
-static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group,
+static int conv_halo_launch_taps(int taps, int ta, const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group,
                                  const void* res, void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
     ChArgs g = {};
     g.x = (const half_t*)x;
@@ -561,7 +576,9 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
     g.ksplit = ksplit > 1 ? ksplit : 1;
     g.part = g.ksplit > 1 ? part : nullptr;
     if (g.ksplit > 1 && (part == nullptr || g.ksplit > cin / 64)) return FZ_ERR_BAD_ARG;
-    g.tiles_a = cout / CH_BA;
+    const int ba = ta * 32, aslot = ba * 32 * 2, ostr = ba + 8;   // (the kernel's per-instantiation constants)
+    if ((ta != 5 && ta != 2) || (taps == 4 && ta != 5) || cout % ba) return FZ_ERR_UNSUPPORTED;
+    g.tiles_a = cout / ba;
     g.fpt = h * w < CH_BB ? CH_BB / (h * w) : 1;
     g.fh_px = ((g.fpt > 1 ? h : CH_BB / w) + 2) * (w + 2);
     g.fh_magic = (1 << 20) / g.fh_px + 1;
@@ -573,8 +590,8 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
     g.w2_magic = 65536 / (w + 2) + 1;
     for (int hp = 0; hp < g.fh_px; ++hp)
         if (((hp * g.w2_magic) >> 16) != hp / (w + 2)) return FZ_ERR_UNSUPPORTED;   // (never for the widths fz_conv_halo_ok admits)
-    const size_t ring = (size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes + 1024, stage = (size_t)CH_BB * CH_OSTR * 2;
-    if ((size_t)CH_NAS * CH_ASLOT + 2 * (size_t)g.hb_bytes < stage) return FZ_ERR_UNSUPPORTED;   // the bias / temb piece must lie beyond the staging area
+    const size_t ring = (size_t)CH_NAS * aslot + 2 * (size_t)g.hb_bytes + 1024 + (size_t)g.np * 256, stage = (size_t)CH_BB * ostr * 2;
+    if ((size_t)CH_NAS * aslot + 2 * (size_t)g.hb_bytes < stage) return FZ_ERR_UNSUPPORTED;   // the bias / temb piece must lie beyond the staging area
     const size_t lds = ring > stage ? ring : stage;
     if (lds > 160 * 1024) return FZ_ERR_UNSUPPORTED;
     const int64_t nwg = (int64_t)g.tiles_a * ((int64_t)n * h * w / CH_BB);
@@ -599,12 +616,12 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
     for (int pl = 0; pl < CH_BB; ++pl)
         if (((pl * g.w_magic) >> 16) != pl / w) return FZ_ERR_UNSUPPORTED;
     if (taps == 4 && (g.ksplit > 1 || temb != nullptr || res != nullptr)) return FZ_ERR_UNSUPPORTED;   // the upsampler's convolution: bias only
-    void (*kern)(ChArgs) = taps == 4 ? &conv_halo_kernel<4> : &conv_halo_kernel<9>;
+    void (*kern)(ChArgs) = taps == 4 ? &conv_halo_kernel<4> : (ta == 2 ? &conv_halo_kernel<9, 2> : &conv_halo_kernel<9>);
 #ifndef FZ_EMU
-    static std::atomic<uint64_t> attr_set_mask[2] = {{0}, {0}};  // LDS above 64 KB is an opt-in function attribute, per device and instantiation
+    static std::atomic<uint64_t> attr_set_mask[3] = {{0}, {0}, {0}};  // LDS above 64 KB is an opt-in function attribute, per device and instantiation
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FZ_ERR_LAUNCH;
-    std::atomic<uint64_t>& mask = attr_set_mask[taps == 4];
+    std::atomic<uint64_t>& mask = attr_set_mask[taps == 4 ? 1 : (ta == 2 ? 2 : 0)];
     if (dev >= 64 || !(mask.load(std::memory_order_relaxed) >> dev & 1)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return FZ_ERR_LAUNCH;
@@ -613,6 +630,8 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
 #endif
     if (taps == 4) {
         FZ_LAUNCH(conv_halo_kernel<4>, dim3((unsigned)nwg, 1, 4), dim3(512), lds, stream, g);
+    } else if (ta == 2) {
+        FZ_LAUNCH((conv_halo_kernel<9, 2>), dim3((unsigned)nwg, (unsigned)g.ksplit), dim3(512), lds, stream, g);
     } else {
         FZ_LAUNCH(conv_halo_kernel<9>, dim3((unsigned)nwg, (unsigned)g.ksplit), dim3(512), lds, stream, g);
     }
@@ -621,7 +640,11 @@ static int conv_halo_launch_taps(int taps, const void* x, const void* wt, const 
 
 int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
                         void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
-    return conv_halo_launch_taps(9, x, wt, bias, temb, temb_stride, temb_group, res, y, n, h, w, cin, cout, part, ksplit, stream);
+    return conv_halo_launch_taps(9, 5, x, wt, bias, temb, temb_stride, temb_group, res, y, n, h, w, cin, cout, part, ksplit, stream);
+}
+int fz_conv_halo64_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
+                          void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream) {
+    return conv_halo_launch_taps(9, 2, x, wt, bias, temb, temb_stride, temb_group, res, y, n, h, w, cin, cout, part, ksplit, stream);
 }
 
 // ---- nearest-2x upsampling + 3x3 convolution as four 2x2 convolutions of the input (conv_halo_kernel<4>) ---------------------------------------
@@ -664,5 +687,5 @@ extern "C" int fz_conv3x3_up2_pack(const void* wt, void* wt_up, int cin, int cou
 extern "C" int fz_conv3x3_up2(const void* x, const void* wt_up, const void* bias, void* y, int n, int h, int w, int cin, int cout, void* stream) {
     if (!x || !wt_up || !y) return FZ_ERR_BAD_ARG;
     if (!fz_conv_halo_ok(n, h, w, cin, cout, 0)) return FZ_ERR_UNSUPPORTED;
-    return conv_halo_launch_taps(4, x, wt_up, bias, nullptr, 0, 0, nullptr, y, n, h, w, cin, cout, nullptr, 1, stream);
+    return conv_halo_launch_taps(4, 5, x, wt_up, bias, nullptr, 0, 0, nullptr, y, n, h, w, cin, cout, nullptr, 1, stream);
 }

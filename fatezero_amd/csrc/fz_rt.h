@@ -140,6 +140,8 @@ FZ_DEVICE void fz_barrier_nodrain() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_ba
 // the bare s_barrier: neither vmcnt nor lgkmcnt is drained (gfx950 backs off a barrier with memory operations outstanding), so
 // ds_reads issued before it are still in flight after it -- the compiler's own lgkmcnt wait in front of their first use orders them
 FZ_DEVICE void fz_barrier_raw() { __builtin_amdgcn_s_barrier(); }
+// this wave's LDS writes (and reads) are complete: in front of a bare barrier behind which OTHER waves read what this one wrote
+FZ_DEVICE void fz_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // LDS hand-over INSIDE one wave (lane a's ds_write read by lane b of the same wave): the LDS unit executes a wave's
 // instructions in order, so no s_barrier is needed -- only the compiler has to keep the order
 FZ_DEVICE void fz_wave_lds_sync() {
@@ -266,6 +268,7 @@ template <int N>
 static inline void fz_wait_vm() { fz_emu::dma_wait(N); }
 static inline void fz_barrier_nodrain() { fz_emu::sync_block_nodrain(); }
 static inline void fz_barrier_raw() { fz_emu::sync_block_nodrain(); }
+static inline void fz_lds_fence() {}
 static inline void fz_wave_lds_sync() {  // all 64 lane fibers of the wave meet
     int mine = 0, all[64];
     fz_emu::wave_exchange(&mine, all, sizeof(int));

@@ -2164,14 +2164,18 @@ static int temporal_conv3_impl(const void* x, const void* wt, const void* res, c
 int fz_conv_halo_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride);
 int fz_conv_halo_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
                         void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream);
+int fz_conv_halo64_ok(int n, int h, int w, int cin, int cout, int64_t temb_stride);
+int fz_conv_halo64_launch(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, int64_t temb_group, const void* res,
+                          void* y, int n, int h, int w, int cin, int cout, float* part, int ksplit, void* stream);
 // the halo kernel, whole (ksplit <= 1) or as ksplit K slices into fp32 slabs + the split-K tail kernel (bias / temb / residual applied there)
 static int conv_halo_run(IgArgs& g, const void* x, const void* wt, const void* bias, const void* temb, const void* res, void* y, int n, int hi, int wi,
-                         int cin, int cout, int ksplit, float* workspace, int64_t workspace_floats, void* stream) {
+                         int cin, int cout, int ksplit, float* workspace, int64_t workspace_floats, void* stream, bool narrow = false) {
+    auto launch = narrow ? fz_conv_halo64_launch : fz_conv_halo_launch;
     if (ksplit <= 1)
-        return fz_conv_halo_launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, nullptr, 1, stream);
+        return launch(x, wt, bias, temb, g.temb_stride, g.temb_group, res, y, n, hi, wi, cin, cout, nullptr, 1, stream);
     if (workspace == nullptr || (g.Ma % 4) || (g.ldy % 4) || ksplit > cin / 64) return FZ_ERR_UNSUPPORTED;
     if ((int64_t)ksplit * g.Nb * g.Ma > workspace_floats) return FZ_ERR_BAD_ARG;
-    const int rc = fz_conv_halo_launch(x, wt, nullptr, nullptr, g.temb_stride, g.temb_group, nullptr, y, n, hi, wi, cin, cout, workspace, ksplit, stream);
+    const int rc = launch(x, wt, nullptr, nullptr, g.temb_stride, g.temb_group, nullptr, y, n, hi, wi, cin, cout, workspace, ksplit, stream);
     if (rc != FZ_OK) return rc;
     g.ksplit = ksplit;
     g.part = workspace;
@@ -2181,6 +2185,7 @@ static int conv_halo_run(IgArgs& g, const void* x, const void* wt, const void* b
     return fz_last_launch_status();
 }
 #define FZ_TILE_CONV_HALO 154299
+#define FZ_TILE_CONV_HALO64 154264   /* the same kernel with 64 output channels per workgroup (conv_halo_kernel<9, 2>) */
 
 extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
                           void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
@@ -2195,6 +2200,10 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
     g.Ho = (hu + 2 - 3) / stride + 1;
     g.Wo = (wu + 2 - 3) / stride + 1;
     if (conv_common(g, x, wt, bias, temb, temb_stride, res, nullptr, y, cin, cout) != FZ_OK) return FZ_ERR_UNSUPPORTED;
+    if (tile_cfg == FZ_TILE_CONV_HALO64) {   // the narrow form of the halo kernel (64 output channels per workgroup), pinned
+        if (stride != 1 || upsample || !fz_conv_halo64_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
+        return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, split_k, (float*)workspace, workspace_floats, stream, true);
+    }
     if (tile_cfg == FZ_TILE_CONV_HALO) {
         if (stride != 1 || upsample || !fz_conv_halo_ok(n, hi, wi, cin, cout, g.temb_stride)) return FZ_ERR_UNSUPPORTED;
         return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, split_k, (float*)workspace, workspace_floats, stream);
@@ -2217,6 +2226,16 @@ extern "C" int fz_conv3x3(const void* x, const void* wt, const void* bias, const
         if (fz_igemm_trial_no_halo_split && (ks > 1 || tiles < 200 || tiles > 512)) take = false;   // (= the rule of the first halo commit)
 #endif
         if (take) return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, ks, (float*)workspace, workspace_floats, stream);
+        // fewer than 24 wide tiles (8 frames x 8^2: 16): the NARROW form -- 64 output channels per workgroup, five times the workgroups at the same
+        // slab traffic -- in 5 (Cin 1 280) / 6 (2 560) K slices: -16 / -12 % against the split-K implicit GEMM (profiles/r06_halo_narrow_ab.txt)
+        if (ks == 0 && tiles >= 8 && tiles < 24 && nchunk >= 20 && fz_conv_halo64_ok(n, hi, wi, cin, cout, g.temb_stride)) {
+            const int ks64 = nchunk >= 40 ? 6 : 5;
+            bool take64 = workspace != nullptr && (int64_t)ks64 * g.Nb * g.Ma <= workspace_floats && (g.Ma % 4) == 0 && (g.ldy % 4) == 0;
+#ifdef FZ_IGEMM_TRIALS
+            if (fz_igemm_trial_no_halo || fz_igemm_trial_no_halo_split) take64 = false;
+#endif
+            if (take64) return conv_halo_run(g, x, wt, bias, temb, res, y, n, hi, wi, cin, cout, ks64, (float*)workspace, workspace_floats, stream, true);
+        }
     }
     if (cin % 8) {  // conv_in (4 input channels): direct VALU convolution
         if (cout % 8 || upsample || cin != 4 || (int64_t)9 * cin * cout * 2 > 64 * 1024 || (temb && g.temb_stride % 8))

@@ -334,6 +334,15 @@ def test_conv3x3_with_the_pixel_halo_resident_in_lds():
         KC.case_conv3x3(DEV, n=3, h=8, w=8, cin=64, cout=160, tile_cfg=154299)   # not whole tiles of four frames
 
 
+def test_conv3x3_pixel_halo_narrow_tile():
+    """conv_halo_kernel<9, 2> (tile id 154264): 64 output channels per workgroup -- whole and in K slices, time embedding + residual, W = 8 / 16 / 32,
+    several channel tiles (the bias / time-embedding lanes and the staging stride follow the tile width)."""
+    KC.case_conv3x3(DEV, n=1, h=16, w=16, cin=128, cout=64, with_temb=True, with_res=True, tile_cfg=154264)
+    KC.case_conv3x3(DEV, n=4, h=8, w=8, cin=192, cout=192, with_temb=True, with_res=True, fpb=4, tile_cfg=154264, seed=1)
+    KC.case_conv3x3(DEV, n=2, h=8, w=32, cin=256, cout=128, with_res=True, tile_cfg=154264, split_k=2, seed=2)
+    KC.case_conv3x3(DEV, n=8, h=8, w=8, cin=320, cout=320, with_temb=True, fpb=8, tile_cfg=154264, split_k=3, seed=3)
+
+
 def test_conv3x3_pixel_halo_in_k_slices():
     """The halo kernel under split-K: slice ks contracts its 64-channel chunks under all nine taps into an fp32 slab, the split-K tail kernel of
     igemm.hip sums the slabs and applies bias / time embedding / residual.  Even and ragged chunk counts per slice, odd first chunks (the halo
