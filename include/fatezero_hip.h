@@ -292,7 +292,11 @@ int fz_gemm_ln(const FzGemmDesc* desc, const FzGemmLn* ln, const void* x, const 
  * stride 1 or 2; upsample != 0 reads x through a nearest-2x upsampling (UpsamplePseudo3D, resnet.py:145) without
  * materialising it.  cin % 8 == 0 (MFMA path, any cout) or cin < 8 with cout % 8 == 0 (conv_in: direct convolution).
  * workspace / workspace_floats / tile_cfg / split_k: as for fz_gemm (split-K is what fills the chip at the 16x16 and 8x8
- * levels); workspace may be NULL. */
+ * levels); workspace may be NULL.  With tile_cfg = 0 the library picks the data path as well: the implicit GEMM, or -- stride 1, no
+ * upsampling, whole 256-pixel tiles (a frame of whole tiles, or whole frames per tile), cin % 64 == 0, cout % 160 == 0 -- the kernel
+ * that keeps the pixel rows + halo resident in LDS across the nine taps (csrc/conv_halo.hip), whole or in K slices with the split-K
+ * tail; tile_cfg 154299 pins that kernel (split_k = its K slices), 154264 its narrow form (64 output channels per workgroup,
+ * cout % 64 == 0); both return FZ_ERR_UNSUPPORTED for shapes they do not carry. */
 int fz_conv3x3(const void* x, const void* wt, const void* bias, const void* temb, int64_t temb_stride, const void* res,
                void* y, int n, int hi, int wi, int cin, int cout, int stride, int upsample, int frames_per_batch,
                void* workspace, int64_t workspace_floats, int tile_cfg, int split_k, void* stream);
